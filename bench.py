@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the CORDIC rotation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM.  The default workload is BASELINE.json configs[1]:
+basiccordic 16-stage, 32-bit phase -> 32-bit sin/cos, 2^30 samples per GPU,
+phase[n] = (uint32)(n << 2) (the reference bench's ramp, cordic_tb.cpp:138),
+x = 2^31-1, y = 0.  Multi-GPU: independent shards by global sample index,
+no data-path collective (weak scaling); a digest all-reduce after the timed
+region checks the shards, `--gather` additionally times collecting the
+outputs on rank 0 over RCCL.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+# name -> (gencordic-style parameters, bytes/sample, VALU ops/sample counted
+# in the ISA of the kernel that runs it, description)
+WORKLOADS = {
+    "cfg2": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, 16), bytes=12,
+                 shift=2, desc="basiccordic 16-stage, 32-bit phase -> 32-bit "
+                 "sin/cos, phase ramp n<<2, x=2^31-1, y=0"),
+    "cfg4": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, 24), bytes=12,
+                 shift=0, desc="basiccordic 24-stage, 32-bit, phase ramp n"),
+    "cfg3": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, 20), bytes=16,
+                 desc="topolar 20-stage, 24-bit I/Q ramps -> mag + phase"),
+    "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
+                 desc="fused NCO (phase = n*0x01234567) + 16-stage p2r, "
+                 "store only"),
+    "cfg5seq": dict(kind="nco", cli=("sp2r", 32, 32, 2, 32, 16), bytes=8,
+                    desc="fused NCO + seqcordic arithmetic (NSTAGES-2)"),
+}
+MODE = {"p2r": 0, "r2p": 1, "sp2r": 2, "sr2p": 3}
+
+
+def cpu_baseline(workload, seconds_target=12.0):
+    """The oracle (a restatement of the reference RTL, NOT reference code:
+    the reference has no CPU compute path) timed on
+    the host cores of this box on a bounded sample of the same workload."""
+    import oracle_lib as O
+    w = WORKLOADS[workload]
+    m, iw, ow, xtra, pw, ns = w["cli"]
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    cores = os.cpu_count() or 1
+    per = 1 << 21                       # samples per thread per round
+
+    def work(tid, rounds, out):
+        base = tid * per
+        g = np.arange(per, dtype=np.uint64) + np.uint64(base)
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            if w["kind"] == "r2p":
+                sh = 32 - iw
+                x = (((((g * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff))
+                       >> np.uint64(8)).astype(np.uint32) << sh)
+                     .astype(np.int32) >> sh)
+                y = (((((g * np.uint64(0x85EBCA77)) & np.uint64(0xffffffff))
+                       >> np.uint64(8)).astype(np.uint32) << sh)
+                     .astype(np.int32) >> sh)
+                O.topolar(ocfg, x, y)
+            else:
+                ph = ((g << np.uint64(w.get("shift", 0)))
+                      & np.uint64(0xffffffff)).astype(np.uint32)
+                O.rotate(ocfg, 2**31 - 1, 0, ph)
+        out[tid] = time.perf_counter() - t0
+
+    # calibrate on one thread, one round
+    o = {}
+    work(0, 1, o)
+    one = o[0]
+    rounds = max(1, min(64, int(seconds_target / max(one, 1e-3))))
+    outs = {}
+    ths = [threading.Thread(target=work, args=(t, rounds, outs))
+           for t in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - t0
+    total = cores * rounds * per
+    return {
+        "value": total / wall / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d samples (%d threads x %d rounds x 2^21) of the %s "
+                  "workload through oracle/liboracle.so (gcc -O2 scalar "
+                  "restatement of the reference RTL; the reference itself has "
+                  "no CPU compute path)" % (total, cores, rounds, workload),
+        "value_1thread": per / one / 1e6,
+        "cpu": _cpu_model(),
+    }
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--log2-samples", type=int, default=30,
+                    help="samples per GPU = 2^this")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time gathering the outputs on rank 0 (RCCL)")
+    ap.add_argument("--generic", action="store_true",
+                    help="force the generic (not unrolled) kernel")
+    args = ap.parse_args()
+
+    import cordic_amd as ca
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    w = WORKLOADS[args.workload]
+    m, iw, ow, xtra, pw, ns = w["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    if args.generic:
+        cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+    n = 1 << args.log2_samples
+    index0 = rank * n                   # shard by global sample index
+    x0, y0 = (1 << (iw - 1)) - 1, 0
+
+    # ---- resident inputs / outputs
+    a = torch.empty(n, dtype=torch.int32, device=dev)
+    b = torch.empty(n, dtype=torch.int32, device=dev)
+    if w["kind"] == "p2r":
+        phase = torch.empty(n, dtype=torch.int32, device=dev)
+        ca.fill_phase_ramp(phase, index0, w["shift"])
+
+        def step():
+            ca.p2r_const(cfg, x0, y0, phase, a, b)
+    elif w["kind"] == "r2p":
+        xin = torch.empty(n, dtype=torch.int32, device=dev)
+        yin = torch.empty(n, dtype=torch.int32, device=dev)
+        ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
+
+        def step():
+            ca.r2p(cfg, xin, yin, a, b)
+    else:
+        def step():
+            ca.nco(cfg, n, 0, 0x01234567, index0, x0, y0, a, b)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # ---- timed region: exactly K steps; HIP events (on the stream the
+    # kernels are launched on: torch's current stream) bracket every launch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(args.steps):
+        step()
+        ev[k + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+
+    # ---- after the timed region: correctness of what was just computed
+    d = torch.zeros(1, dtype=torch.int64, device=dev)
+    ca.digest_u32(a, index0, d)
+    ca.digest_u32(b, index0 + (1 << 40), d)
+    if dist is not None:
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
+    torch.cuda.synchronize()
+    digest = int(d.cpu().numpy().view(np.uint64)[0])
+
+    check = None
+    if rank == 0:
+        import oracle_lib as O
+        ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+        idx = np.unique(np.concatenate([
+            np.arange(0, min(n, 4096)), np.arange(max(0, n - 4096), n),
+            np.arange(0, n, 65521)])).astype(np.int64)
+        ti = torch.from_numpy(idx).to(dev)
+        ga, gb = a[ti].cpu().numpy(), b[ti].cpu().numpy()
+        if w["kind"] == "r2p":
+            ra, rb = O.topolar(ocfg, xin[ti].cpu().numpy(),
+                               yin[ti].cpu().numpy())
+            rb = rb.view(np.int32)
+        elif w["kind"] == "p2r":
+            ra, rb = O.rotate(ocfg, x0, y0,
+                              phase[ti].cpu().numpy().view(np.uint32))
+        else:
+            ph = ((idx.astype(np.uint64) + np.uint64(index0))
+                  * np.uint64(0x01234567) & np.uint64(0xffffffff))
+            ra, rb = O.rotate(ocfg, x0, y0, ph.astype(np.uint32))
+        check = bool(np.array_equal(ga, ra) and np.array_equal(gb, rb))
+
+    gather_ms = None
+    if args.gather and dist is not None:
+        outs = None
+        if rank == 0:
+            outs = [torch.empty(2 * n, dtype=torch.int32, device=dev)
+                    for _ in range(world)]
+        ab = torch.cat([a, b])
+        barrier()
+        t1 = time.perf_counter()
+        dist.gather(ab, outs, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        total = float(world) * n * args.steps
+        value = total / elapsed / 1e6
+        achieved = w["bytes"] * n / kern_avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(
+                    "hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "Msamples/sec (sin+cos pairs) at 16-stage/32-bit"
+                      if args.workload == "cfg2" else
+                      "Msamples/sec (%s)" % args.workload,
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64" if cfg.ww > 32 else "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s" % (args.workload, w["desc"]),
+                "samples_per_gpu": n,
+                "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
+                "nstages": cfg.nstages, "rotations": cfg.nlive,
+                "kernel": "generic" if args.generic else "unrolled",
+                "parallelism": "shard%d" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_sample": w["bytes"],
+                "kernel_ms_avg": kern_avg_s * 1e3,
+                "kernel_ms_min": float(np.min(kern_ms)),
+                "note": "the path is integer-VALU bound, not HBM bound: see "
+                        "DESIGN.md (roofline) for the VALU ceiling",
+            },
+            "bit_exact_vs_oracle": check,
+            "digest": "%016x" % digest,
+        }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

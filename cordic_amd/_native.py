@@ -1,0 +1,270 @@
+"""ctypes bindings of include/cordic_amd.h (no arithmetic lives here)."""
+import ctypes as C
+import os
+
+P2R, R2P, SP2R, SR2P = 0, 1, 2, 3
+MAX_STAGES = 64
+FLAG_FORCE_GENERIC = 0x1
+FLAG_LDS_TABLE = 0x2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libcordic_amd.so")
+
+
+class CordicError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib().cordic_strerror(status).decode()
+        super().__init__("%s: %s (status %d)" % (what, msg, status))
+
+
+class _CConfig(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("iw", C.c_int32), ("ow", C.c_int32),
+        ("nextra", C.c_int32), ("ww", C.c_int32), ("pw", C.c_int32),
+        ("nstages", C.c_int32), ("clocks_per_output", C.c_int32),
+        ("quantization_variance", C.c_double),
+        ("phase_variance_rad", C.c_double),
+        ("gain", C.c_double), ("best_possible_cnr", C.c_double),
+        ("has_reset", C.c_int32), ("has_aux", C.c_int32),
+        ("async_reset", C.c_int32),
+        ("nlive", C.c_int32), ("needs_wrap", C.c_int32),
+        ("flags", C.c_uint32),
+        ("angle", C.c_uint32 * MAX_STAGES),
+    ]
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_cfgp = C.POINTER(_CConfig)
+
+# name -> (restype, argtypes): every symbol include/cordic_amd.h declares
+ABI = {
+    "cordic_abi_version": (C.c_int, []),
+    "cordic_strerror": (C.c_char_p, [C.c_int]),
+    "cordic_config_init": (C.c_int, [_cfgp] + [C.c_int] * 6),
+    "cordic_config_init_core": (C.c_int, [_cfgp] + [C.c_int] * 6),
+    "cordic_config_from_args": (C.c_int, [_cfgp, C.c_int,
+                                          C.POINTER(C.c_char_p), C.c_char_p,
+                                          C.c_size_t, C.POINTER(C.c_int)]),
+    "cordic_config_write_header": (C.c_int, [_cfgp, C.c_char_p, C.c_char_p,
+                                             C.c_size_t]),
+    "cordic_nextlg": (C.c_int, [C.c_uint]),
+    "cordic_gain": (C.c_double, [C.c_int]),
+    "cordic_phase_variance": (C.c_double, [C.c_int, C.c_int]),
+    "cordic_transform_quantization_variance": (C.c_double, [C.c_int] * 3),
+    "cordic_angles": (C.c_int, [C.c_int, C.c_int, _u32p]),
+    "cordic_calc_stages_ww": (C.c_int, [C.c_int, C.c_int]),
+    "cordic_calc_stages": (C.c_int, [C.c_int]),
+    "cordic_calc_phase_bits": (C.c_int, [C.c_int]),
+    "cordic_p2r": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cordic_p2r_const": (C.c_int, [_cfgp, C.c_size_t, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "cordic_nco": (C.c_int, [_cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
+                             C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
+    "cordic_r2p": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cordic_p2r_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, C.c_int,
+                                  _u32p, _i32p, _i32p]),
+    "cordic_r2p_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, _i32p,
+                                  _u32p]),
+    "cordic_fill_phase_ramp": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64,
+                                         C.c_int, C.c_void_p]),
+    "cordic_fill_iq_ramp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_uint64, C.c_uint32, C.c_uint32,
+                                      C.c_int, C.c_void_p]),
+    "cordic_digest_u32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64,
+                                    C.c_void_p, C.c_void_p]),
+}
+
+
+def lib():
+    """Load libcordic_amd.so; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s not built: run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (there is no CPU fallback)" % path)
+        L = C.CDLL(path)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CordicError(rc, what)
+
+
+class Config:
+    """One generated core (cordic_config)."""
+
+    def __init__(self, c):
+        self.c = c
+
+    @classmethod
+    def from_cli(cls, mode, iw=-1, ow=-1, xtra=2, pw=-1, nstages=-1):
+        c = _CConfig()
+        _check(lib().cordic_config_init(C.byref(c), mode, iw, ow, xtra, pw,
+                                        nstages), "cordic_config_init")
+        return cls(c)
+
+    @classmethod
+    def from_core(cls, mode, nstages, iw, ow, nxtra, pw):
+        c = _CConfig()
+        _check(lib().cordic_config_init_core(C.byref(c), mode, nstages, iw,
+                                             ow, nxtra, pw),
+               "cordic_config_init_core")
+        return cls(c)
+
+    @classmethod
+    def from_args(cls, args):
+        """args: gencordic command line without the program name."""
+        if isinstance(args, str):
+            args = args.split()
+        argv = (C.c_char_p * (len(args) + 1))(
+            b"gencordic", *[a.encode() for a in args])
+        c = _CConfig()
+        fname = C.create_string_buffer(512)
+        hdr = C.c_int(0)
+        _check(lib().cordic_config_from_args(C.byref(c), len(args) + 1, argv,
+                                             fname, 512, C.byref(hdr)),
+               "cordic_config_from_args")
+        cfg = cls(c)
+        cfg.fname = fname.value.decode()
+        cfg.c_header = bool(hdr.value)
+        return cfg
+
+    def header_text(self, name):
+        buf = C.create_string_buffer(4096)
+        n = lib().cordic_config_write_header(C.byref(self.c), name.encode(),
+                                             buf, 4096)
+        if n < 0:
+            raise CordicError(n, "cordic_config_write_header")
+        return buf.value.decode()
+
+    def __getattr__(self, k):
+        return getattr(self.c, k)
+
+    @property
+    def angles(self):
+        return list(self.c.angle[: self.c.nstages])
+
+    def with_flags(self, flags):
+        c = _CConfig()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(_CConfig))
+        c.flags = flags
+        return Config(c)
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or an int / None passed through)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+def p2r(cfg, x, y, phase, ox, oy, n=None, stream=None):
+    n = phase.numel() if n is None else n
+    _check(lib().cordic_p2r(cfg.ref, n, _ptr(x), _ptr(y), _ptr(phase),
+                            _ptr(ox), _ptr(oy), _stream(stream)), "cordic_p2r")
+
+
+def p2r_const(cfg, x0, y0, phase, ox, oy, n=None, stream=None):
+    n = phase.numel() if n is None else n
+    _check(lib().cordic_p2r_const(cfg.ref, n, x0, y0, _ptr(phase), _ptr(ox),
+                                  _ptr(oy), _stream(stream)),
+           "cordic_p2r_const")
+
+
+def nco(cfg, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
+    _check(lib().cordic_nco(cfg.ref, n, phase0 & 0xffffffff, fcw & 0xffffffff,
+                            index0, x0, y0, _ptr(ox), _ptr(oy),
+                            _stream(stream)), "cordic_nco")
+
+
+def r2p(cfg, x, y, mag, ophase, n=None, stream=None):
+    n = x.numel() if n is None else n
+    _check(lib().cordic_r2p(cfg.ref, n, _ptr(x), _ptr(y), _ptr(mag),
+                            _ptr(ophase), _stream(stream)), "cordic_r2p")
+
+
+def p2r_host(cfg, x, y, phase):
+    """numpy in / numpy out through the host-buffer entry point."""
+    import numpy as np
+    phase = np.ascontiguousarray(phase, dtype=np.uint32)
+    n = phase.size
+    scalar = np.ndim(x) == 0
+    xa = np.ascontiguousarray(np.atleast_1d(x), dtype=np.int32)
+    ya = np.ascontiguousarray(np.atleast_1d(y), dtype=np.int32)
+    ox = np.empty(n, dtype=np.int32)
+    oy = np.empty(n, dtype=np.int32)
+    _check(lib().cordic_p2r_host(
+        cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
+        1 if scalar else 0, phase.ctypes.data_as(_u32p),
+        ox.ctypes.data_as(_i32p), oy.ctypes.data_as(_i32p)),
+        "cordic_p2r_host")
+    return ox, oy
+
+
+def r2p_host(cfg, x, y):
+    import numpy as np
+    xa = np.ascontiguousarray(x, dtype=np.int32)
+    ya = np.ascontiguousarray(y, dtype=np.int32)
+    n = xa.size
+    mag = np.empty(n, dtype=np.int32)
+    ph = np.empty(n, dtype=np.uint32)
+    _check(lib().cordic_r2p_host(
+        cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
+        mag.ctypes.data_as(_i32p), ph.ctypes.data_as(_u32p)),
+        "cordic_r2p_host")
+    return mag, ph
+
+
+def fill_phase_ramp(phase, index0, shift, n=None, stream=None):
+    n = phase.numel() if n is None else n
+    _check(lib().cordic_fill_phase_ramp(_ptr(phase), n, index0, shift,
+                                        _stream(stream)),
+           "cordic_fill_phase_ramp")
+
+
+def fill_iq_ramp(x, y, index0, mulx, muly, bits, n=None, stream=None):
+    n = x.numel() if n is None else n
+    _check(lib().cordic_fill_iq_ramp(_ptr(x), _ptr(y), n, index0, mulx, muly,
+                                     bits, _stream(stream)),
+           "cordic_fill_iq_ramp")
+
+
+def digest_u32(words, index0, digest, n=None, stream=None):
+    """digest (int64 device tensor, 1 element) += digest of words."""
+    n = words.numel() if n is None else n
+    _check(lib().cordic_digest_u32(_ptr(words), n, index0, _ptr(digest),
+                                   _stream(stream)), "cordic_digest_u32")

@@ -1,0 +1,209 @@
+// cordic_abi.cpp -- the extern "C" surface declared in include/cordic_amd.h.
+// Thin by design: argument checks, then the host layer (cordic_config.cpp) or
+// the device launchers (cordic_kernels.hip).
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+
+#include "cordic_amd.h"
+#include "cordic_internal.h"
+
+using namespace cordic_amd;
+
+// Host-buffer conveniences.  Every HIP call is checked; buffers are released
+// on all paths.
+namespace {
+struct DevBuf {
+	void *p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess; }
+	template <typename T> T *as() { return static_cast<T *>(p); }
+};
+bool h2d(DevBuf &b, const void *src, size_t bytes)
+{
+	return b.alloc(bytes) && hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+bool d2h(void *dst, DevBuf &b, size_t bytes)
+{
+	return hipMemcpy(dst, b.p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+}
+}
+
+extern "C" {
+
+int cordic_abi_version(void) { return CORDIC_AMD_ABI_VERSION; }
+
+const char *cordic_strerror(int status) { return status_text(status); }
+
+int cordic_config_init(cordic_config *cfg, int mode, int iw, int ow, int xtra,
+		int phase_bits, int nstages)
+{
+	return build_from_cli(cfg, mode, iw, ow, xtra, phase_bits, nstages);
+}
+
+int cordic_config_init_core(cordic_config *cfg, int mode, int nstages, int iw,
+		int ow, int nxtra, int phase_bits)
+{
+	return build_core(cfg, mode, nstages, iw, ow, nxtra, phase_bits);
+}
+
+int cordic_config_from_args(cordic_config *cfg, int argc,
+		const char *const *argv, char *fname, size_t fname_cap,
+		int *c_header)
+{
+	return parse_args(cfg, argc, argv, fname, fname_cap, c_header);
+}
+
+int cordic_config_write_header(const cordic_config *cfg, const char *name,
+		char *buf, size_t cap)
+{
+	return write_header(cfg, name, buf, cap);
+}
+
+int cordic_nextlg(unsigned vl) { return next_lg(vl); }
+double cordic_gain(int nstages) { return rotation_gain(nstages); }
+double cordic_phase_variance(int nstages, int phase_bits)
+{
+	return phase_variance(nstages, phase_bits);
+}
+double cordic_transform_quantization_variance(int nstages, int xtrabits,
+		int dropped_bits)
+{
+	return quantization_variance(nstages, xtrabits, dropped_bits);
+}
+int cordic_angles(int nstages, int phase_bits, uint32_t *out)
+{
+	if (!out || nstages < 0 || phase_bits < 3 || phase_bits > 32)
+		return CORDIC_ERR_ARGS;
+	for (int k = 0; k < nstages; k++)
+		out[k] = arctan_entry((unsigned)k, phase_bits);
+	return CORDIC_OK;
+}
+int cordic_calc_stages_ww(int working_width, int phase_bits)
+{
+	return stages_for(phase_bits, working_width);
+}
+int cordic_calc_stages(int phase_bits) { return stages_for(phase_bits, -1); }
+int cordic_calc_phase_bits(int output_width) { return phase_bits_for(output_width); }
+
+// ------------------------------------------------------------------ device
+
+int cordic_p2r(const cordic_config *cfg, size_t n, const int32_t *d_xval,
+		const int32_t *d_yval, const uint32_t *d_phase, int32_t *d_oxval,
+		int32_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x = d_xval; j.y = d_yval; j.phase = d_phase;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	return launch_rotator(*cfg, Feed::PhaseArray_XYArray, j, stream);
+}
+
+int cordic_p2r_const(const cordic_config *cfg, size_t n, int32_t xval,
+		int32_t yval, const uint32_t *d_phase, int32_t *d_oxval,
+		int32_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x0 = xval; j.y0 = yval; j.phase = d_phase;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	return launch_rotator(*cfg, Feed::PhaseArray_ConstXY, j, stream);
+}
+
+int cordic_nco(const cordic_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, int32_t xval, int32_t yval, int32_t *d_oxval,
+		int32_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
+	j.index0 = index0; j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	return launch_rotator(*cfg, Feed::Nco_ConstXY, j, stream);
+}
+
+int cordic_r2p(const cordic_config *cfg, size_t n, const int32_t *d_xval,
+		const int32_t *d_yval, int32_t *d_omag, uint32_t *d_ophase,
+		void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	return launch_topolar(*cfg, n, d_xval, d_yval, d_omag, d_ophase, stream);
+}
+
+int cordic_p2r_host(const cordic_config *cfg, size_t n, const int32_t *xval,
+		const int32_t *yval, int xy_is_scalar, const uint32_t *phase,
+		int32_t *oxval, int32_t *oyval)
+{
+	if (!cfg || !xval || !yval || !phase || !oxval || !oyval)
+		return CORDIC_ERR_ARGS;
+	if (n == 0)
+		return CORDIC_OK;
+	const size_t bytes = n * sizeof(int32_t);
+	DevBuf dph, dx, dy, dox, doy;
+	if (!h2d(dph, phase, bytes) || !dox.alloc(bytes) || !doy.alloc(bytes))
+		return CORDIC_ERR_DEVICE;
+	int rc;
+	if (xy_is_scalar) {
+		rc = cordic_p2r_const(cfg, n, xval[0], yval[0], dph.as<uint32_t>(),
+				dox.as<int32_t>(), doy.as<int32_t>(), nullptr);
+	} else {
+		if (!h2d(dx, xval, bytes) || !h2d(dy, yval, bytes))
+			return CORDIC_ERR_DEVICE;
+		rc = cordic_p2r(cfg, n, dx.as<int32_t>(), dy.as<int32_t>(),
+				dph.as<uint32_t>(), dox.as<int32_t>(),
+				doy.as<int32_t>(), nullptr);
+	}
+	if (rc != CORDIC_OK)
+		return rc;
+	if (hipDeviceSynchronize() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	if (!d2h(oxval, dox, bytes) || !d2h(oyval, doy, bytes))
+		return CORDIC_ERR_DEVICE;
+	return CORDIC_OK;
+}
+
+int cordic_r2p_host(const cordic_config *cfg, size_t n, const int32_t *xval,
+		const int32_t *yval, int32_t *omag, uint32_t *ophase)
+{
+	if (!cfg || !xval || !yval || !omag || !ophase)
+		return CORDIC_ERR_ARGS;
+	if (n == 0)
+		return CORDIC_OK;
+	const size_t bytes = n * sizeof(int32_t);
+	DevBuf dx, dy, dm, dp;
+	if (!h2d(dx, xval, bytes) || !h2d(dy, yval, bytes) || !dm.alloc(bytes)
+			|| !dp.alloc(bytes))
+		return CORDIC_ERR_DEVICE;
+	int rc = cordic_r2p(cfg, n, dx.as<int32_t>(), dy.as<int32_t>(),
+			dm.as<int32_t>(), dp.as<uint32_t>(), nullptr);
+	if (rc != CORDIC_OK)
+		return rc;
+	if (hipDeviceSynchronize() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	if (!d2h(omag, dm, bytes) || !d2h(ophase, dp, bytes))
+		return CORDIC_ERR_DEVICE;
+	return CORDIC_OK;
+}
+
+int cordic_fill_phase_ramp(uint32_t *d_phase, size_t n, uint64_t index0,
+		int shift, void *stream)
+{
+	return launch_fill_phase_ramp(d_phase, n, index0, shift, stream);
+}
+
+int cordic_fill_iq_ramp(int32_t *d_x, int32_t *d_y, size_t n, uint64_t index0,
+		uint32_t mulx, uint32_t muly, int bits, void *stream)
+{
+	return launch_fill_iq_ramp(d_x, d_y, n, index0, mulx, muly, bits, stream);
+}
+
+int cordic_digest_u32(const uint32_t *d_words, size_t n, uint64_t index0,
+		uint64_t *d_digest, void *stream)
+{
+	return launch_digest_u32(d_words, n, index0, d_digest, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,441 @@
+// cordic_config.cpp -- host side of the engine: parameter derivation, arctan
+// table, quality constants and the constants-header text.  Pure host C++ (no
+// HIP): everything here runs once per generated core, never per sample.
+//
+// The numbers must equal what the reference generator prints, so the
+// floating-point expressions keep the reference's operation order (cited per
+// function); the structure around them is this project's own.
+#include <cctype>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "cordic_amd.h"
+#include "cordic_internal.h"
+
+namespace cordic_amd {
+
+// ---------------------------------------------------------------------------
+// Table math (reference sw/cordiclib.cpp)
+// ---------------------------------------------------------------------------
+
+// cordic_angle[k] in PW-bit phase units.  Reference sw/cordiclib.cpp:161-169:
+//   x = atan2(1., pow(2,k+1));  x *= (4.0*(1ul<<(PW-2))) / (M_PI*2.0);
+//   phase_value = (unsigned)x;
+// The scale factor is evaluated first and x multiplied by it, as there.
+uint32_t arctan_entry(unsigned k, int phase_bits)
+{
+	const double scale = (4.0 * (double)(1ul << (phase_bits - 2)))
+				/ (M_PI * 2.0);
+	double x = std::atan2(1., std::pow(2, k + 1));
+	x *= scale;
+	return (uint32_t)(unsigned)x;
+}
+
+// Product over the stages of sqrt(1 + 2^-2(k+1)); sw/cordiclib.cpp:66-80.
+double rotation_gain(int nstages)
+{
+	double g = 1.0;
+	for (int k = 0; k < nstages; k++)
+		g = g * std::sqrt(1.0 + std::pow(2.0, -2. * (k + 1)));
+	return g;
+}
+
+// Variance (radians^2) of the truncated angle table plus the initial 1/12;
+// sw/cordiclib.cpp:82-109.
+double phase_variance(int nstages, int phase_bits)
+{
+	const double rad_to_phase = (double)(1ul << (phase_bits - 1)) / M_PI;
+	double var = 1. / 12.;
+	for (unsigned k = 0; k < (unsigned)nstages; k++) {
+		const double x = std::atan2(1., std::pow(2, k + 1)) * rad_to_phase;
+		const unsigned long q = (unsigned)x;
+		double e = (double)q - x;
+		e *= e;
+		var += e;
+	}
+	var /= std::pow(rad_to_phase, 2.);
+	return var;
+}
+
+// Rounding-noise model of the x/y datapath; sw/cordiclib.cpp:111-130.
+double quantization_variance(int nstages, int xtrabits, int dropped_bits)
+{
+	double v = std::pow(2, 2 * xtrabits) / 12.;
+	for (int k = 0; k < nstages; k++)
+		v = (1 + std::pow(4, -k - 1)) * v + 1. / 3.;
+	if (dropped_bits > 0)
+		v = std::pow(2, -2 * dropped_bits) * v + 1 / 12.;
+	return v;
+}
+
+// ceil(log2(vl)); sw/cordiclib.cpp:57-63.
+int next_lg(unsigned vl)
+{
+	int lg = 0;
+	for (unsigned r = 1; r < vl; r <<= 1)
+		lg++;
+	return lg;
+}
+
+// Stage count at which the table runs out (and, when a working width is
+// given, at which the shifts run out); sw/cordiclib.cpp:214-244.
+int stages_for(int phase_bits, int working_width /* <0: unbounded */)
+{
+	int n = 0;
+	for (; n < 64; n++) {
+		if (arctan_entry((unsigned)n, phase_bits) == 0)
+			break;
+		if (working_width >= 0 && working_width <= n)
+			break;
+	}
+	return n;
+}
+
+// Smallest PW >= 3 with sin(2pi/2^PW) * (2^w - 1) < 1/2; sw/cordiclib.cpp:
+// 254-263 (the code uses 2^w - 1, not the 2^(w-1) - 1 of its comment).
+int phase_bits_for(int width)
+{
+	int pb = 3;
+	for (; pb < 64; pb++) {
+		const double a = (2.0 * M_PI / (double)(1ul << pb));
+		double ds = std::sin(a);
+		ds *= (double)((1ul << width) - 1);
+		if (ds < 0.5)
+			break;
+	}
+	return pb;
+}
+
+// ---------------------------------------------------------------------------
+// Overflow reachability.  A kernel whose container is wider than WW only
+// matches the WW-bit registers of the generated core if no intermediate value
+// can leave the WW-bit range.  Bound the vector magnitude stage by stage: an
+// exact micro-rotation scales it by sqrt(1+4^-k) and the two floor()s move
+// the point by less than sqrt(2).
+// ---------------------------------------------------------------------------
+static bool overflow_reachable(const cordic_config &c)
+{
+	const bool p2r = (c.mode == CORDIC_P2R || c.mode == CORDIC_SP2R);
+	// |e_x|,|e_y| <= 2^(WW-2) (p2r) or 2^(WW-3) followed by the x+-y fold
+	double m = p2r ? std::sqrt(2.0) * std::ldexp(1.0, c.ww - 2)
+		       : std::ldexp(1.0, c.ww - 2);
+	for (int i = 0; i < c.nlive; i++)
+		m = m * std::sqrt(1.0 + std::ldexp(1.0, -2 * (i + 1)))
+			+ std::sqrt(2.0);
+	const int r = c.ww - c.ow;
+	const double round_add = (c.ww > c.ow + 1) ? std::ldexp(1.0, r - 1) : 0.0;
+	return (m + round_add + 1.0) >= std::ldexp(1.0, c.ww - 1);
+}
+
+// ---------------------------------------------------------------------------
+// Core construction
+// ---------------------------------------------------------------------------
+
+static inline bool mode_ok(int m) { return m >= CORDIC_P2R && m <= CORDIC_SR2P; }
+static inline bool is_rotator(int m) { return m == CORDIC_P2R || m == CORDIC_SP2R; }
+
+int build_core(cordic_config *cfg, int mode, int nstages, int iw, int ow,
+		int nxtra, int phase_bits)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	std::memset(cfg, 0, sizeof(*cfg));
+	if (!mode_ok(mode))
+		return CORDIC_ERR_MODE;
+	if (iw < 1 || iw > 32 || ow < 1 || ow > 32)
+		return CORDIC_ERR_WIDTH;
+	if (phase_bits < 3 || phase_bits > 32)
+		return CORDIC_ERR_PHASE_BITS;
+	if (nstages < 1 || nstages > CORDIC_AMD_MAX_STAGES)
+		return CORDIC_ERR_STAGES;
+
+	// Working width.  Rotators: sw/basiccordic.cpp:67-73 (one guard bit at
+	// least).  Converters: sw/topolar.cpp:67-75 adds nxtra twice.
+	const int wide = (iw > ow) ? iw : ow;
+	int ww;
+	if (is_rotator(mode)) {
+		if (nxtra < 1) nxtra = 1;
+		ww = wide + nxtra;
+	} else {
+		if (nxtra < 2) nxtra = 2;
+		ww = wide + 2 * nxtra;
+	}
+	if (ww > 64)
+		return CORDIC_ERR_WORKING_WIDTH;
+
+	// Cores the reference cannot really build:
+	//  - sp2r with WW == OW+1 emits an "if (i_ce)" with no such port
+	//    (sw/seqcordic.cpp:400-417); with NSTAGES < 2 a zero-width state.
+	//  - sr2p waits for state >= NSTAGES+1 in a nextlg(NSTAGES+1)-bit
+	//    register (sw/seqpolar.cpp:159,239): unreachable if NSTAGES+1 is a
+	//    power of two, so o_done never rises.
+	if (mode == CORDIC_SP2R && (nstages < 2 || ww <= ow + 1))
+		return CORDIC_ERR_UNSUPPORTED;
+	if (mode == CORDIC_SR2P && ((nstages + 1) & nstages) == 0)
+		return CORDIC_ERR_UNSUPPORTED;
+
+	cfg->mode = mode;
+	cfg->iw = iw;
+	cfg->ow = ow;
+	cfg->nextra = nxtra;
+	cfg->ww = ww;
+	cfg->pw = phase_bits;
+	cfg->nstages = nstages;
+	cfg->has_reset = 1;	// reference defaults, sw/main.cpp:99
+	cfg->has_aux = 0;
+	cfg->async_reset = 0;
+	for (int k = 0; k < nstages; k++)
+		cfg->angle[k] = arctan_entry((unsigned)k, phase_bits);
+
+	cfg->quantization_variance = quantization_variance(nstages, ww - iw,
+							ww - ow);
+	cfg->phase_variance_rad = phase_variance(nstages, phase_bits);
+	if (is_rotator(mode)) {
+		cfg->gain = rotation_gain(nstages);
+		// sw/basiccordic.cpp:479-496
+		double amplitude = (double)(1ul << (iw - 1)) - 1.;
+		amplitude *= (double)(1ul << (ww - iw));
+		amplitude *= rotation_gain(nstages);
+		amplitude *= std::pow(2.0, -(ww - ow));
+		const double signal = amplitude * amplitude;
+		double noise = quantization_variance(nstages, ww - iw, ww - ow);
+		noise += signal * phase_variance(nstages, phase_bits)
+				* std::pow(2, rotation_gain(nstages));
+		cfg->best_possible_cnr = 10.0 * std::log(signal / noise)
+						/ std::log(10.0);
+	} else {
+		cfg->gain = rotation_gain(nstages) * std::sqrt(2.0) / 2.;
+	}
+
+	// How many rotations the core really performs.
+	switch (mode) {
+	case CORDIC_P2R:
+	case CORDIC_R2P: {
+		// rtl/cordic.v:253-261, rtl/topolar.v:217-225: a stage whose
+		// angle is zero or whose index reaches WW only copies.  Angles
+		// never increase with k, so the live stages are a prefix.
+		int live = 0;
+		while (live < nstages && cfg->angle[live] != 0 && live < ww)
+			live++;
+		cfg->nlive = live;
+		break;
+	}
+	case CORDIC_SP2R:
+		// rtl/seqcordic.v:318-324 captures before the last two
+		// rotations land; no copy-only stages (:270-291).
+		cfg->nlive = nstages - 2;
+		cfg->clocks_per_output = nstages + 1; // sw/seqcordic.cpp:459
+		break;
+	default:
+		// rtl/seqpolar.v:208 runs every stage; no copy-only stages.
+		cfg->nlive = nstages;
+		cfg->clocks_per_output = nstages + 3; // sw/seqpolar.cpp:396
+		break;
+	}
+	cfg->needs_wrap = overflow_reachable(*cfg) ? 1 : 0;
+	return CORDIC_OK;
+}
+
+// gencordic's defaulting (sw/main.cpp:260-279 rotators, :313-329 converters)
+int build_from_cli(cordic_config *cfg, int mode, int iw, int ow, int xtra,
+		int phase_bits, int nstages)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	if (!mode_ok(mode)) {
+		std::memset(cfg, 0, sizeof(*cfg));
+		return CORDIC_ERR_MODE;
+	}
+	if (iw <= 0 && ow > 0) iw = ow;
+	if (ow <= 0) ow = iw;
+	if (iw <= 0 || ow <= 0) iw = ow = 24;	// DEFAULT_BITWIDTH
+
+	const int bump = is_rotator(mode) ? 1 : 2;
+	const int nxtra = xtra + bump;
+	const int ww_cli = ((ow > iw) ? ow : iw) + nxtra;
+	if (ww_cli > 63 || ww_cli < 1) {
+		std::memset(cfg, 0, sizeof(*cfg));
+		return CORDIC_ERR_WORKING_WIDTH;
+	}
+	if (phase_bits <= 0)
+		phase_bits = phase_bits_for(ww_cli);
+	if (phase_bits > 32) {
+		std::memset(cfg, 0, sizeof(*cfg));
+		return CORDIC_ERR_PHASE_BITS;
+	}
+	if (nstages <= 0)
+		nstages = is_rotator(mode) ? stages_for(phase_bits, ww_cli)
+					   : stages_for(phase_bits, -1);
+	return build_core(cfg, mode, nstages, iw, ow, nxtra, phase_bits);
+}
+
+// ---------------------------------------------------------------------------
+// gencordic argv front end (sw/main.cpp:139-232)
+// ---------------------------------------------------------------------------
+int parse_args(cordic_config *cfg, int argc, const char *const *argv,
+		char *fname, size_t fname_cap, int *c_header)
+{
+	if (!cfg || argc < 1 || !argv)
+		return CORDIC_ERR_ARGS;
+	int nstages = -1, iw = -1, ow = -1, xtra = 2, pw = -1;
+	int mode = CORDIC_R2P;		// sw/main.cpp:100: r2p unless -t says so
+	bool reset = true, aux = false, areset = false, hdr = false;
+	std::string file;
+	const char *deffile = "topolar.v";
+
+	// A small getopt: flags may be bundled ("-vca"), values may be glued
+	// ("-i13") or separate ("-i 13"), as with getopt(3).
+	for (int k = 1; k < argc; k++) {
+		const char *a = argv[k];
+		if (!a || a[0] != '-' || a[1] == '\0')
+			break;			// first non-option ends parsing
+		if (a[1] == '-' && a[2] == '\0')
+			break;
+		for (const char *p = a + 1; *p; p++) {
+			const char f = *p;
+			if (std::strchr("finoptx", f)) {
+				const char *val = p[1] ? p + 1
+					: (k + 1 < argc ? argv[++k] : nullptr);
+				if (!val)
+					return CORDIC_ERR_ARGS;
+				switch (f) {
+				case 'f': file = val; break;
+				case 'i': iw = std::atoi(val); break;
+				case 'n': nstages = std::atoi(val); break;
+				case 'o': ow = std::atoi(val); break;
+				case 'p': pw = std::atoi(val); break;
+				case 'x': xtra = std::atoi(val); break;
+				case 't':
+					if (!std::strcmp(val, "r2p")) {
+						mode = CORDIC_R2P; deffile = "topolar.v";
+					} else if (!std::strcmp(val, "sr2p")) {
+						mode = CORDIC_SR2P; deffile = "seqpolar.v";
+					} else if (!std::strcmp(val, "p2r")) {
+						mode = CORDIC_P2R; deffile = "basiccordic.v";
+					} else if (!std::strcmp(val, "sp2r")) {
+						mode = CORDIC_SP2R; deffile = "seqcordic.v";
+					} else
+						return CORDIC_ERR_MODE;
+					break;
+				}
+				break;		// value consumed the rest of a
+			}
+			switch (f) {
+			case 'a': aux = true; break;
+			case 'A': areset = true; reset = true; break;
+			case 'c': hdr = true; break;
+			case 'R': reset = false; break;
+			case 'r': reset = true; break;
+			case 'v': case 'h': break;
+			default: return CORDIC_ERR_ARGS;
+			}
+		}
+	}
+	int rc = build_from_cli(cfg, mode, iw, ow, xtra, pw, nstages);
+	if (rc != CORDIC_OK)
+		return rc;
+	cfg->has_reset = reset;
+	cfg->has_aux = aux;
+	cfg->async_reset = areset;
+	if (c_header) *c_header = hdr;
+	if (fname && fname_cap) {
+		const std::string &f = file.empty() ? std::string(deffile) : file;
+		std::snprintf(fname, fname_cap, "%s", f.c_str());
+	}
+	return CORDIC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Constants header text
+// ---------------------------------------------------------------------------
+namespace {
+struct TextSink {
+	char *buf; size_t cap; size_t len = 0;
+	void put(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+	{
+		char tmp[256];
+		va_list ap;
+		va_start(ap, fmt);
+		int m = std::vsnprintf(tmp, sizeof(tmp), fmt, ap);
+		va_end(ap);
+		for (int i = 0; i < m; i++, len++)
+			if (buf && len + 1 < cap)
+				buf[len] = tmp[i];
+	}
+	void finish() { if (buf && cap) buf[len < cap ? len : cap - 1] = '\0'; }
+};
+}
+
+int write_header(const cordic_config *c, const char *name, char *buf, size_t cap)
+{
+	if (!c || !name || !mode_ok(c->mode))
+		return CORDIC_ERR_ARGS;
+	// guard = "<name>.h" upper-cased with '.' -> '_'
+	std::string guard = std::string(name) + ".h";
+	for (auto &ch : guard)
+		ch = (ch == '.') ? '_' : (char)std::toupper((unsigned char)ch);
+
+	const bool rot = is_rotator(c->mode);
+	const bool seq = (c->mode == CORDIC_SP2R || c->mode == CORDIC_SR2P);
+	TextSink o{buf, cap};
+	o.put("#ifndef\t%s\n#define\t%s\n", guard.c_str(), guard.c_str());
+	if (c->async_reset)
+		o.put("#define\tASYNC_RESET\n");
+	if (seq) {
+		o.put("#ifdef\tCLOCKS_PER_OUTPUT\n#undef\tCLOCKS_PER_OUTPUT\n"
+		      "#endif\t// CLOCKS_PER_OUTPUT\n");
+		// the rotator's line is followed by a blank line
+		o.put("#define\tCLOCKS_PER_OUTPUT\t%d\n%s", c->clocks_per_output,
+			rot ? "\n" : "");
+	}
+	o.put("const int\tIW = %d;\n", c->iw);
+	o.put("const int\tOW = %d;\n", c->ow);
+	o.put("const int\tNEXTRA = %d;\n", c->nextra);
+	o.put("const int\tWW = %d;\n", c->ww);
+	o.put("const int\tPW = %d;\n", c->pw);
+	o.put("const int\tNSTAGES = %d;\n", c->nstages);
+	if (rot) {
+		o.put("const double\tQUANTIZATION_VARIANCE = %.4e; // (Units^2)\n",
+			c->quantization_variance);
+		o.put("const double\tPHASE_VARIANCE_RAD = %.4e; // (Radians^2)\n",
+			c->phase_variance_rad);
+		o.put("const double\tGAIN = %.16f;\n", c->gain);
+		o.put("const double\tBEST_POSSIBLE_CNR = %.2f;\n",
+			c->best_possible_cnr);
+	} else {
+		o.put("const double\tQUANTIZATION_VARIANCE = %.16f; // (Units^2)\n",
+			c->quantization_variance);
+		o.put("const double\tPHASE_VARIANCE_RAD = %.16f; // (Radians^2)\n",
+			c->phase_variance_rad);
+		o.put("const double\tGAIN = %.16f;\n", c->gain);
+	}
+	o.put("const bool\tHAS_RESET = %s;\n", c->has_reset ? "true" : "false");
+	o.put("const bool\tHAS_AUX   = %s;\n", c->has_aux ? "true" : "false");
+	if (c->has_reset) o.put("#define\tHAS_RESET_WIRE\n");
+	if (c->has_aux)   o.put("#define\tHAS_AUX_WIRES\n");
+	o.put("#endif\t// %s\n", guard.c_str());
+	o.finish();
+	return (int)o.len;
+}
+
+const char *status_text(int s)
+{
+	switch (s) {
+	case CORDIC_OK:			return "ok";
+	case CORDIC_ERR_MODE:		return "unsupported cordic mode";
+	case CORDIC_ERR_WIDTH:		return "input/output width outside 1..32";
+	case CORDIC_ERR_PHASE_BITS:	return "phase bits outside 3..32";
+	case CORDIC_ERR_WORKING_WIDTH:	return "working width above 64 bits";
+	case CORDIC_ERR_STAGES:		return "stage count outside 1..64";
+	case CORDIC_ERR_UNSUPPORTED:	return "the reference core for these parameters cannot be built or never completes";
+	case CORDIC_ERR_ARGS:		return "bad argument";
+	case CORDIC_ERR_DEVICE:		return "HIP runtime error";
+	default:			return "unknown status";
+	}
+}
+
+} // namespace cordic_amd

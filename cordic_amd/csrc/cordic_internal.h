@@ -1,0 +1,61 @@
+// cordic_internal.h -- declarations shared by the host and device halves of
+// libcordic_amd.so.  Not installed; the public surface is include/cordic_amd.h.
+#ifndef CORDIC_INTERNAL_H
+#define CORDIC_INTERNAL_H
+
+#include <cstddef>
+#include <cstdint>
+
+#include "cordic_amd.h"
+
+namespace cordic_amd {
+
+// ---- host: cordic_config.cpp
+uint32_t arctan_entry(unsigned k, int phase_bits);
+double	rotation_gain(int nstages);
+double	phase_variance(int nstages, int phase_bits);
+double	quantization_variance(int nstages, int xtrabits, int dropped_bits);
+int	next_lg(unsigned vl);
+int	stages_for(int phase_bits, int working_width);
+int	phase_bits_for(int width);
+int	build_core(cordic_config *cfg, int mode, int nstages, int iw, int ow,
+		int nxtra, int phase_bits);
+int	build_from_cli(cordic_config *cfg, int mode, int iw, int ow, int xtra,
+		int phase_bits, int nstages);
+int	parse_args(cordic_config *cfg, int argc, const char *const *argv,
+		char *fname, size_t fname_cap, int *c_header);
+int	write_header(const cordic_config *c, const char *name, char *buf,
+		size_t cap);
+const char *status_text(int s);
+
+// ---- device launchers: cordic_kernels.hip
+// Where the rotator's phase / vector inputs come from.
+enum class Feed : int {
+	PhaseArray_ConstXY = 0,	// d_phase[], scalar x/y      (cordic_p2r_const)
+	PhaseArray_XYArray = 1,	// d_phase[], d_x[], d_y[]    (cordic_p2r)
+	Nco_ConstXY	   = 2	// phase from the sample index (cordic_nco)
+};
+
+struct RotatorJob {
+	const int32_t  *x = nullptr, *y = nullptr;	// Feed::PhaseArray_XYArray
+	const uint32_t *phase = nullptr;
+	int32_t  x0 = 0, y0 = 0;			// const feeds
+	uint32_t phase0 = 0, fcw = 0;			// NCO
+	uint64_t index0 = 0;				// NCO
+	int32_t  *ox = nullptr, *oy = nullptr;
+	size_t   n = 0;
+};
+
+int	launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
+		void *stream);
+int	launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
+		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream);
+int	launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
+		void *stream);
+int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
+		uint32_t mulx, uint32_t muly, int bits, void *stream);
+int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
+		uint64_t *digest, void *stream);
+
+} // namespace cordic_amd
+#endif

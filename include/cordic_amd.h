@@ -1,0 +1,214 @@
+/*
+ * cordic_amd.h -- C ABI of the MI355X-native CORDIC rotation engine.
+ *
+ * Drop-in boundary for the hot path of ZipCPU/cordic.
+ * The reference has no FFI layer; the path sits behind three concentric
+ * interfaces and each one is mirrored here:
+ *
+ *  1. the parameter surface of the core generator CLI
+ *        gencordic -t p2r|r2p|sp2r|sr2p -i IW -o OW -p PW -n NSTAGES -x XTRA
+ *        (reference sw/main.cpp:57-92 usage, :139-232 getopt, :260-357
+ *        derivation)                       -> cordic_config_init / _from_args
+ *  2. the emitter signature
+ *        basiccordic(fp,fhp,cmdline,fname,nstages,iw,ow,nxtra,phase_bits,...)
+ *        (reference sw/basiccordic.h:46-50, sw/topolar.h:44-49,
+ *        sw/seqcordic.h:46-50, sw/seqpolar.h:44-49)  -> cordic_config_init_core
+ *     and the generated constants header (reference rtl/cordic.h:46-59,
+ *     rtl/topolar.h:46-59, emitted by sw/basiccordic.cpp:449-505 and
+ *     sw/topolar.cpp:412-451)                -> cordic_config / _write_header
+ *  3. the per-sample port interface of the generated core
+ *        i_xval,i_yval [IW] signed, i_phase [PW] -> o_xval,o_yval [OW] signed
+ *        (reference rtl/cordic.v:58-63, driven one sample per tick by
+ *        bench/cpp/cordic_tb.cpp:127-178)             -> cordic_p2r[_const]
+ *        i_xval,i_yval [IW] signed -> o_mag [OW] signed, o_phase [PW]
+ *        (reference rtl/topolar.v:59-64, bench/cpp/topolar_tb.cpp:127-187)
+ *                                                     -> cordic_r2p
+ *
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ * All batch entry points take DEVICE pointers (HBM resident) and a HIP stream
+ * handle passed as void* (NULL = the null stream); they enqueue work and
+ * return without synchronising.  The *_host variants take host pointers and
+ * do the PCIe copies themselves.  Every function is re-entrant; the config is
+ * an immutable POD the caller owns.
+ *
+ * Results are bit-exact to the arithmetic of the Verilog the reference
+ * generator emits for the same parameters.
+ */
+#ifndef CORDIC_AMD_H
+#define CORDIC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORDIC_AMD_MAX_STAGES	64
+#define CORDIC_AMD_ABI_VERSION	1
+
+/* gencordic -t <type>, reference sw/main.cpp:177-194 */
+enum cordic_mode {
+	CORDIC_P2R  = 0,	/* -t p2r : polar to rectangular, pipelined   */
+	CORDIC_R2P  = 1,	/* -t r2p : rectangular to polar, pipelined   */
+	CORDIC_SP2R = 2,	/* -t sp2r: sequential core's arithmetic      */
+	CORDIC_SR2P = 3		/* -t sr2p: sequential core's arithmetic      */
+};
+
+/* The reference exit(EXIT_FAILURE)s / assert()s on bad parameters
+ * (sw/main.cpp:212-231, sw/basiccordic.cpp:69); the ABI returns codes. */
+enum cordic_status {
+	CORDIC_OK		=  0,
+	CORDIC_ERR_MODE		= -1,	/* unknown -t value                    */
+	CORDIC_ERR_WIDTH	= -2,	/* IW / OW outside 1..32               */
+	CORDIC_ERR_PHASE_BITS	= -3,	/* PW < 3, or > 32 (reference table
+					   wraps at 32 bits, cordiclib.cpp:155) */
+	CORDIC_ERR_WORKING_WIDTH = -4,	/* WW > 64                             */
+	CORDIC_ERR_STAGES	= -5,	/* NSTAGES outside 1..64               */
+	CORDIC_ERR_UNSUPPORTED	= -6,	/* parameters for which the reference
+					   emits a core that cannot elaborate
+					   or never raises o_done              */
+	CORDIC_ERR_ARGS		= -7,	/* NULL pointer / bad command line     */
+	CORDIC_ERR_DEVICE	= -8	/* HIP runtime error (no GPU, launch)  */
+};
+
+/* flags (cordic_config.flags) -- implementation selectors for A/B work */
+#define CORDIC_FLAG_FORCE_GENERIC	0x1u	/* never use an unrolled kernel */
+#define CORDIC_FLAG_LDS_TABLE		0x2u	/* arctan table read from LDS   */
+
+/*
+ * One generated core.  The first block mirrors, field for field, the
+ * constants header the reference writes with -c (rtl/cordic.h:46-59).
+ */
+typedef struct cordic_config {
+	int32_t	mode;			/* enum cordic_mode                   */
+	int32_t	iw;			/* IW                                 */
+	int32_t	ow;			/* OW                                 */
+	int32_t	nextra;			/* NEXTRA (after the CLI's +1 / +2)   */
+	int32_t	ww;			/* WW                                 */
+	int32_t	pw;			/* PW                                 */
+	int32_t	nstages;		/* NSTAGES                            */
+	int32_t	clocks_per_output;	/* CLOCKS_PER_OUTPUT (seq cores) or 0 */
+	double	quantization_variance;	/* QUANTIZATION_VARIANCE              */
+	double	phase_variance_rad;	/* PHASE_VARIANCE_RAD                 */
+	double	gain;			/* GAIN                               */
+	double	best_possible_cnr;	/* BEST_POSSIBLE_CNR (p2r, sp2r)      */
+	int32_t	has_reset;		/* HAS_RESET  (-r / -R)               */
+	int32_t	has_aux;		/* HAS_AUX    (-a)                    */
+	int32_t	async_reset;		/* ASYNC_RESET (-A)                   */
+	/* derived for the device path */
+	int32_t	nlive;			/* rotations the core really performs */
+	int32_t	needs_wrap;		/* WW-bit overflow reachable: kernels
+					   must wrap explicitly               */
+	uint32_t flags;
+	uint32_t angle[CORDIC_AMD_MAX_STAGES]; /* cordic_angle[], PW-bit      */
+} cordic_config;
+
+/* ------------------------------------------------------------------ host */
+
+int	cordic_abi_version(void);
+const char *cordic_strerror(int status);
+
+/* CLI level (sw/main.cpp:260-357): xtra is the -x value (reference default
+ * 2); iw/ow <= 0 follow the reference's defaulting (:262-270); phase_bits
+ * <= 0 and nstages <= 0 are derived with calc_phase_bits / calc_stages. */
+int	cordic_config_init(cordic_config *cfg, int mode, int iw, int ow,
+		int xtra, int phase_bits, int nstages);
+
+/* Emitter level (sw/basiccordic.h:46-50): nxtra is the already incremented
+ * value the emitters receive. */
+int	cordic_config_init_core(cordic_config *cfg, int mode, int nstages,
+		int iw, int ow, int nxtra, int phase_bits);
+
+/* gencordic-compatible argv ("aAcf:hi:n:o:p:Rrt:vx:", sw/main.cpp:139).
+ * argv[0] is the program name.  fname (may be NULL) receives the -f value or
+ * the reference's default file name; *c_header receives the -c flag.
+ * Table generators (-t tbl/qtr/qtbl) return CORDIC_ERR_MODE. */
+int	cordic_config_from_args(cordic_config *cfg, int argc,
+		const char *const *argv, char *fname, size_t fname_cap,
+		int *c_header);
+
+/* Text of the constants header between "#ifndef <GUARD>" and "#endif"
+ * exactly as the reference writes it for `name` (e.g. "cordic" ->
+ * CORDIC_H; sw/basiccordic.cpp:449-505, sw/topolar.cpp:412-451,
+ * sw/seqcordic.cpp:446-500, sw/seqpolar.cpp:383-420), without the licence
+ * banner.  Returns the length (excluding NUL) or a negative status; writes
+ * at most cap bytes. */
+int	cordic_config_write_header(const cordic_config *cfg, const char *name,
+		char *buf, size_t cap);
+
+/* Library functions of sw/cordiclib.h:45-52, exported for callers that used
+ * them directly. */
+int	cordic_nextlg(unsigned vl);
+double	cordic_gain(int nstages);
+double	cordic_phase_variance(int nstages, int phase_bits);
+double	cordic_transform_quantization_variance(int nstages, int xtrabits,
+		int dropped_bits);
+int	cordic_angles(int nstages, int phase_bits, uint32_t *out);
+int	cordic_calc_stages_ww(int working_width, int phase_bits);
+int	cordic_calc_stages(int phase_bits);
+int	cordic_calc_phase_bits(int output_width);
+
+/* ---------------------------------------------------------------- device */
+
+/* Polar to rectangular (sin/cos, vector rotation); cfg->mode P2R or SP2R.
+ * Inputs are taken modulo their port width (IW / PW low bits), outputs are
+ * sign extended OW-bit values.  Replaces one Vcordic tick() per sample
+ * (bench/cpp/cordic_tb.cpp:136-176). */
+int	cordic_p2r(const cordic_config *cfg, size_t n,
+		const int32_t *d_xval, const int32_t *d_yval,
+		const uint32_t *d_phase,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* Same with i_xval / i_yval held constant, the way the reference bench
+ * drives the core (cordic_tb.cpp:68-69): 4 B in + 8 B out per sample. */
+int	cordic_p2r_const(const cordic_config *cfg, size_t n,
+		int32_t xval, int32_t yval, const uint32_t *d_phase,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* Fused NCO: phase[i] = phase0 + (index0 + i) * fcw  (mod 2^PW) generated in
+ * the kernel, then the p2r core: 0 B in + 8 B out per sample. */
+int	cordic_nco(const cordic_config *cfg, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		int32_t xval, int32_t yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* Rectangular to polar (magnitude + atan2); cfg->mode R2P or SR2P.
+ * d_ophase receives the raw PW-bit phase (rtl/topolar.v:269).  Replaces one
+ * Vtopolar tick() per sample (bench/cpp/topolar_tb.cpp:143-187). */
+int	cordic_r2p(const cordic_config *cfg, size_t n,
+		const int32_t *d_xval, const int32_t *d_yval,
+		int32_t *d_omag, uint32_t *d_ophase, void *stream);
+
+/* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
+int	cordic_p2r_host(const cordic_config *cfg, size_t n,
+		const int32_t *xval, const int32_t *yval, int xy_is_scalar,
+		const uint32_t *phase, int32_t *oxval, int32_t *oyval);
+int	cordic_r2p_host(const cordic_config *cfg, size_t n,
+		const int32_t *xval, const int32_t *yval,
+		int32_t *omag, uint32_t *ophase);
+
+/* ------------------------------------------------ device-side test inputs */
+
+/* d_phase[i] = ((index0 + i) << shift) mod 2^32 : the bench's phase ramp
+ * i << (PW-LGNSAMPLES) (cordic_tb.cpp:128-138) for a shard starting at
+ * global sample index0. */
+int	cordic_fill_phase_ramp(uint32_t *d_phase, size_t n, uint64_t index0,
+		int shift, void *stream);
+/* d_x[i] = sext(((index0+i) * mulx) >> 8, bits), d_y likewise with muly:
+ * deterministic I/Q ramps. */
+int	cordic_fill_iq_ramp(int32_t *d_x, int32_t *d_y, size_t n,
+		uint64_t index0, uint32_t mulx, uint32_t muly, int bits,
+		void *stream);
+/* Order-sensitive 64-bit digest of a device word array:
+ * sum over i of mix(index0 + i, d_words[i]) mod 2^64, written to *d_digest
+ * (device, 8 bytes; ACCUMULATED with atomic add -- zero it first).  The CPU
+ * twin lives in tests/; digests of shards add up to the digest of the whole,
+ * which is what the multi-GPU check reduces. */
+int	cordic_digest_u32(const uint32_t *d_words, size_t n, uint64_t index0,
+		uint64_t *d_digest, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORDIC_AMD_H */

@@ -1,0 +1,657 @@
+/*
+ * cordic_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see the header).
+ *
+ * A literal, scalar restatement of the arithmetic emitted by the reference
+ * core generator.  "Literal" means: one C statement per Verilog non-blocking
+ * assignment, explicit WW-bit two's-complement wrap after every x/y
+ * operation, explicit PW-bit wrap after every phase operation, and the
+ * floating-point table math kept in the reference's operation order.
+ *
+ * Sample-level parity is UNPINNED BY REFERENCE FIXTURES (none exist, and the
+ * reference's only executor is a Verilator build that cannot be made here);
+ * table/parameter math is pinned against the real generator's output.
+ */
+#include <math.h>
+#include <string.h>
+#include "cordic_oracle.h"
+
+/* ---------------------------------------------------------------- helpers */
+
+/* v wrapped to a w-bit two's complement number, sign extended to 64 bits */
+static inline int64_t sx(int64_t v, int w)
+{
+	if (w >= 64)
+		return v;
+	return (int64_t)((uint64_t)v << (64 - w)) >> (64 - w);
+}
+
+/* Verilog ">>>" on a signed WW-bit register held sign extended in 64 bits:
+ * shifting by >= the width leaves only copies of the sign bit. */
+static inline int64_t asr(int64_t v, unsigned s)
+{
+	return v >> (s > 63 ? 63 : s);
+}
+
+static inline uint32_t pmask(int pw)
+{
+	return (pw >= 32) ? 0xffffffffu : ((1u << pw) - 1u);
+}
+
+/* ------------------------------------------- sw/cordiclib.cpp restatement */
+
+/* sw/cordiclib.cpp:57-63 */
+int orc_nextlg(unsigned vl)
+{
+	unsigned r, lg = 0;
+	for (r = 1; r < vl; r <<= 1, lg++)
+		;
+	return (int)lg;
+}
+
+/* sw/cordiclib.cpp:66-80 */
+double orc_cordic_gain(int nstages)
+{
+	double gain = 1.0;
+	for (int k = 0; k < nstages; k++) {
+		double dgain = 1.0 + pow(2.0, -2. * (k + 1));
+		dgain = sqrt(dgain);
+		gain = gain * dgain;
+	}
+	return gain;
+}
+
+/* sw/cordiclib.cpp:82-109 */
+double orc_phase_variance(int nstages, int phase_bits)
+{
+	double RAD_TO_PHASE = (1ul << (phase_bits - 1)) / M_PI;
+	double variance = 1. / 12.;
+	for (unsigned k = 0; k < (unsigned)nstages; k++) {
+		double x, err;
+		unsigned long phase_value;
+		x = atan2(1., pow(2, k + 1)) * RAD_TO_PHASE;
+		phase_value = (unsigned)x;
+		err = phase_value - x;
+		err *= err;
+		variance += err;
+	}
+	variance /= pow(RAD_TO_PHASE, 2.);
+	return variance;
+}
+
+/* sw/cordiclib.cpp:111-130 */
+double orc_transform_quantization_variance(int nstages, int xtrabits,
+		int dropped_bits)
+{
+	double current_variance = pow(2, 2 * xtrabits) / 12.;
+	for (int k = 0; k < nstages; k++)
+		current_variance = (1 + pow(4, -k - 1)) * current_variance
+					+ 1. / 3.;
+	if (dropped_bits > 0)
+		current_variance = pow(2, -2 * dropped_bits) * current_variance
+					+ 1 / 12.;
+	return current_variance;
+}
+
+/* one table entry, sw/cordiclib.cpp:161-169 (operation order preserved) */
+static uint32_t angle_entry(unsigned k, int phase_bits)
+{
+	double x = atan2(1., pow(2, k + 1));
+	x *= (4.0 * (1ul << (phase_bits - 2))) / (M_PI * 2.0);
+	return (uint32_t)(unsigned)x;
+}
+
+void orc_cordic_angles(int nstages, int phase_bits, uint32_t *out)
+{
+	for (unsigned k = 0; k < (unsigned)nstages; k++)
+		out[k] = angle_entry(k, phase_bits);
+}
+
+/* sw/cordiclib.cpp:214-229 */
+int orc_calc_stages2(int working_width, int phase_bits)
+{
+	unsigned nstages;
+	for (nstages = 0; nstages < 64; nstages++) {
+		if (angle_entry(nstages, phase_bits) == 0)
+			break;
+		if (working_width <= (int)nstages)
+			break;
+	}
+	return (int)nstages;
+}
+
+/* sw/cordiclib.cpp:231-244 */
+int orc_calc_stages1(int phase_bits)
+{
+	unsigned nstages;
+	for (nstages = 0; nstages < 64; nstages++)
+		if (angle_entry(nstages, phase_bits) == 0)
+			break;
+	return (int)nstages;
+}
+
+/* sw/cordiclib.cpp:246-268 */
+int orc_calc_phase_bits(int output_width)
+{
+	unsigned phase_bits;
+	for (phase_bits = 3; phase_bits < 64; phase_bits++) {
+		double ds, a;
+		a = (2.0 * M_PI / (double)(1ul << phase_bits));
+		ds = sin(a);
+		ds *= ((1ul << output_width) - 1);
+		if (ds < 0.5)
+			break;
+	}
+	if (phase_bits < 3)
+		phase_bits = 3;
+	return (int)phase_bits;
+}
+
+/* ------------------------------------------------ configuration derivation */
+
+static int is_p2r(int mode) { return mode == ORC_P2R || mode == ORC_SP2R; }
+
+/* sw/basiccordic.cpp:67-73,471-496; sw/topolar.cpp:67-75,430-440;
+ * sw/seqcordic.cpp:73-79,459-487; sw/seqpolar.cpp:73-80,396-410 */
+int orc_config_core(orc_config *cfg, int mode, int nstages, int iw, int ow,
+		int nxtra, int phase_bits)
+{
+	int ww;
+
+	memset(cfg, 0, sizeof(*cfg));
+	if (mode < ORC_P2R || mode > ORC_SR2P)
+		return -1;
+	if (iw <= 0 || ow <= 0 || iw > 32 || ow > 32)
+		return -2;
+	if (phase_bits < 3 || phase_bits > 32)
+		return -3;
+	if (nstages < 1 || nstages > ORC_MAX_STAGES)
+		return -5;
+
+	ww = iw;
+	if (is_p2r(mode)) {
+		if (nxtra < 1)
+			nxtra = 1;
+		if (ww < ow)
+			ww = ow;
+		ww += nxtra;
+	} else {
+		if (nxtra < 2)
+			nxtra = 2;
+		if (ww < ow)
+			ww = ow;
+		ww += nxtra;
+		ww += nxtra;
+	}
+	if (ww > 64)
+		return -4;
+	if (mode == ORC_SP2R && (nstages < 2 || ww <= ow + 1))
+		return -6;	/* emitted Verilog does not elaborate */
+	if (mode == ORC_SR2P && ((nstages + 1) & nstages) == 0)
+		return -6;	/* state register cannot reach NSTAGES+1 */
+
+	cfg->mode = mode;
+	cfg->iw = iw;
+	cfg->ow = ow;
+	cfg->nxtra = nxtra;
+	cfg->ww = ww;
+	cfg->pw = phase_bits;
+	cfg->nstages = nstages;
+	orc_cordic_angles(nstages, phase_bits, cfg->angle);
+	cfg->quantization_variance = orc_transform_quantization_variance(
+			nstages, ww - iw, ww - ow);
+	cfg->phase_variance_rad = orc_phase_variance(nstages, phase_bits);
+	if (is_p2r(mode)) {
+		double amplitude, signal_energy, noise_energy;
+		cfg->gain = orc_cordic_gain(nstages);
+		/* sw/basiccordic.cpp:479-496 */
+		amplitude = (1ul << (iw - 1)) - 1.;
+		amplitude *= (1ul << ((ww - iw)));
+		amplitude *= orc_cordic_gain(nstages);
+		amplitude *= pow(2.0, -(ww - ow));
+		signal_energy = amplitude * amplitude;
+		noise_energy = orc_transform_quantization_variance(nstages,
+				ww - iw, ww - ow);
+		noise_energy += signal_energy
+			* orc_phase_variance(nstages, phase_bits)
+			* pow(2, orc_cordic_gain(nstages));
+		cfg->best_possible_cnr = 10.0 * log(signal_energy / noise_energy)
+						/ log(10.0);
+	} else {
+		/* sw/topolar.cpp:439-440 */
+		cfg->gain = orc_cordic_gain(nstages) * sqrt(2.0) / 2.;
+	}
+	if (mode == ORC_SP2R)
+		cfg->clocks_per_output = nstages + 1; /* sw/seqcordic.cpp:459 */
+	if (mode == ORC_SR2P)
+		cfg->clocks_per_output = nstages + 3; /* sw/seqpolar.cpp:396 */
+	return 0;
+}
+
+/* sw/main.cpp:260-279 (p2r, sp2r) and :313-329 (r2p, sr2p) */
+int orc_config_cli(orc_config *cfg, int mode, int iw, int ow, int xtra,
+		int phase_bits, int nstages)
+{
+	const int DEFAULT_BITWIDTH = 24;
+	int nxtra = xtra, ww;
+
+	if (mode < ORC_P2R || mode > ORC_SR2P) {
+		memset(cfg, 0, sizeof(*cfg));
+		return -1;
+	}
+	if ((iw <= 0) && (ow > 0))
+		iw = ow;
+	if (ow <= 0)
+		ow = iw;
+	if ((iw <= 0) || (ow <= 0)) {
+		iw = DEFAULT_BITWIDTH;
+		ow = DEFAULT_BITWIDTH;
+	}
+	ww = (ow > iw) ? ow : iw;
+	if (is_p2r(mode)) {
+		nxtra += 1;
+		ww += nxtra;
+		if (ww > 63) {
+			memset(cfg, 0, sizeof(*cfg));
+			return -4;
+		}
+		if (phase_bits <= 0)
+			phase_bits = orc_calc_phase_bits(ww);
+		if (phase_bits > 32) {
+			memset(cfg, 0, sizeof(*cfg));
+			return -3;
+		}
+		if (nstages <= 0)
+			nstages = orc_calc_stages2(ww, phase_bits);
+	} else {
+		nxtra += 2;
+		ww += nxtra;
+		if (ww > 63) {
+			memset(cfg, 0, sizeof(*cfg));
+			return -4;
+		}
+		if (phase_bits <= 0)
+			phase_bits = orc_calc_phase_bits(ww);
+		if (phase_bits > 32) {
+			memset(cfg, 0, sizeof(*cfg));
+			return -3;
+		}
+		if (nstages <= 0)
+			nstages = orc_calc_stages1(phase_bits);
+	}
+	return orc_config_core(cfg, mode, nstages, iw, ow, nxtra, phase_bits);
+}
+
+/* ------------------------------------------------------ shared sub-steps */
+
+/* Convergent rounding of a WW-bit value to OW bits.
+ * rtl/cordic.v:288-295,311-312 (WW > OW+1) and the "No rounding required"
+ * branch sw/basiccordic.cpp:407-444 (WW == OW+1: plain truncation). */
+static int32_t round_out(int64_t v, int ww, int ow)
+{
+	int r = ww - ow;
+	if (ww > ow + 1) {
+		int64_t b = (v >> r) & 1;
+		/* { OW zeros, b, (r-1) copies of !b } */
+		int64_t add = (b << (r - 1))
+			| (b ? 0 : (((int64_t)1 << (r - 1)) - 1));
+		v = sx(v + add, ww);
+	}
+	return (int32_t)sx(v >> r, ow);
+}
+
+/* p2r input extension + octant fold: rtl/cordic.v:85-86,131-188
+ * (sw/basiccordic.cpp:137-145,196-287); same text in rtl/seqcordic.v:83-84,
+ * 124-182 */
+static void p2r_prerotate(const orc_config *c, int32_t ix, int32_t iy,
+		uint32_t iph, int64_t *x, int64_t *y, uint32_t *p)
+{
+	const int ww = c->ww, pw = c->pw;
+	const uint32_t pm = pmask(pw);
+	int64_t ex, ey;
+	uint32_t ph = iph & pm;
+	uint32_t q = 1u << (pw - 2);
+
+	/* { sign, i_xval, (WW-IW-1) zeros } */
+	ex = sx((int64_t)((uint64_t)sx(ix, c->iw) << (ww - c->iw - 1)), ww);
+	ey = sx((int64_t)((uint64_t)sx(iy, c->iw) << (ww - c->iw - 1)), ww);
+
+	switch ((ph >> (pw - 3)) & 7) {
+	case 0: case 7:
+		*x = ex; *y = ey; *p = ph;
+		break;
+	case 1: case 2:
+		*x = sx(-ey, ww); *y = ex; *p = (ph - q) & pm;
+		break;
+	case 3: case 4:
+		*x = sx(-ex, ww); *y = sx(-ey, ww); *p = (ph - 2 * q) & pm;
+		break;
+	default: /* 5, 6 */
+		*x = ey; *y = sx(-ex, ww); *p = (ph - 3 * q) & pm;
+		break;
+	}
+}
+
+/* one p2r rotation, rtl/cordic.v:262-280 (shift and angle passed in so the
+ * sequential core, rtl/seqcordic.v:270-291, can reuse it) */
+static void p2r_rotate(int ww, uint32_t pm, int pw, unsigned shift,
+		uint32_t ang, int64_t *x, int64_t *y, uint32_t *p)
+{
+	int64_t xo = *x, yo = *y;
+	if ((*p >> (pw - 1)) & 1) {	/* negative phase */
+		*x = sx(xo + asr(yo, shift), ww);
+		*y = sx(yo - asr(xo, shift), ww);
+		*p = (*p + ang) & pm;
+	} else {
+		*x = sx(xo - asr(yo, shift), ww);
+		*y = sx(yo + asr(xo, shift), ww);
+		*p = (*p - ang) & pm;
+	}
+}
+
+/* r2p input extension + quadrant fold: rtl/topolar.v:83-84,122-152
+ * (sw/topolar.cpp:139-151,208-251); WW-IW >= 4 always so only the first
+ * sign-extension form of sw/topolar.cpp:139-151 is reachable */
+static void r2p_prerotate(const orc_config *c, int32_t ix, int32_t iy,
+		int64_t *x, int64_t *y, uint32_t *p)
+{
+	const int ww = c->ww, pw = c->pw;
+	int64_t sxi = sx(ix, c->iw), syi = sx(iy, c->iw);
+	int64_t ex, ey;
+	uint32_t e = 1u << (pw - 3);
+
+	ex = sx((int64_t)((uint64_t)sxi << (ww - c->iw - 2)), ww);
+	ey = sx((int64_t)((uint64_t)syi << (ww - c->iw - 2)), ww);
+
+	switch (((sxi < 0) ? 2 : 0) | ((syi < 0) ? 1 : 0)) {
+	case 1:
+		*x = sx(ex - ey, ww); *y = sx(ex + ey, ww); *p = 7 * e;
+		break;
+	case 2:
+		*x = sx(-ex + ey, ww); *y = sx(-ex - ey, ww); *p = 3 * e;
+		break;
+	case 3:
+		*x = sx(-ex - ey, ww); *y = sx(ex - ey, ww); *p = 5 * e;
+		break;
+	default:
+		*x = sx(ex + ey, ww); *y = sx(-ex + ey, ww); *p = 1 * e;
+		break;
+	}
+	*p &= pmask(pw);
+}
+
+/* one r2p rotation, rtl/topolar.v:226-243 / rtl/seqpolar.v:259-280 */
+static void r2p_rotate(int ww, uint32_t pm, unsigned shift, uint32_t ang,
+		int64_t *x, int64_t *y, uint32_t *p)
+{
+	int64_t xo = *x, yo = *y;
+	if (yo < 0) {			/* yv[WW-1]: below the axis */
+		*x = sx(xo - asr(yo, shift), ww);
+		*y = sx(yo + asr(xo, shift), ww);
+		*p = (*p - ang) & pm;
+	} else {
+		*x = sx(xo + asr(yo, shift), ww);
+		*y = sx(yo - asr(xo, shift), ww);
+		*p = (*p + ang) & pm;
+	}
+}
+
+/* ------------------------------------------------------- pipelined cores */
+
+/* rtl/cordic.v (= sw/basiccordic.cpp output) */
+void orc_p2r(const orc_config *c, size_t n, const int32_t *xi,
+		const int32_t *yi, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		int64_t x, y;
+		uint32_t p;
+		size_t j = xy_stride ? s : 0;
+		p2r_prerotate(c, xi[j], yi[j], phase[s], &x, &y, &p);
+		for (int i = 0; i < c->nstages; i++) {
+			/* rtl/cordic.v:253-261 */
+			if ((c->angle[i] == 0) || (i >= c->ww))
+				continue;
+			p2r_rotate(c->ww, pm, c->pw, (unsigned)i + 1,
+					c->angle[i], &x, &y, &p);
+		}
+		ox[s] = round_out(x, c->ww, c->ow);
+		oy[s] = round_out(y, c->ww, c->ow);
+	}
+}
+
+/* rtl/topolar.v (= sw/topolar.cpp output) */
+void orc_r2p(const orc_config *c, size_t n, const int32_t *xi,
+		const int32_t *yi, int32_t *omag, uint32_t *ophase)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		int64_t x, y;
+		uint32_t p;
+		r2p_prerotate(c, xi[s], yi[s], &x, &y, &p);
+		for (int i = 0; i < c->nstages; i++) {
+			/* rtl/topolar.v:217-225 */
+			if ((c->angle[i] == 0) || (i >= c->ww))
+				continue;
+			r2p_rotate(c->ww, pm, (unsigned)i + 1, c->angle[i],
+					&x, &y, &p);
+		}
+		omag[s] = round_out(x, c->ww, c->ow);	/* :251-255,268 */
+		ophase[s] = p;				/* :269 */
+	}
+}
+
+/* ------------------------------------------ sequential cores, closed form */
+
+/* rtl/seqcordic.v: the capture at state >= NSTAGES-1 (:318-324) reads xv
+ * before that edge's own rotation lands, and the first rotation happens
+ * with state == 1, so exactly NSTAGES-2 rotations (shift = state = i+1,
+ * cangle = cordic_angle[state-1] = angle[i]) are seen; no zero-angle skip. */
+void orc_seq_p2r(const orc_config *c, size_t n, const int32_t *xi,
+		const int32_t *yi, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		int64_t x, y;
+		uint32_t p;
+		size_t j = xy_stride ? s : 0;
+		p2r_prerotate(c, xi[j], yi[j], phase[s], &x, &y, &p);
+		for (int i = 0; i < c->nstages - 2; i++)
+			p2r_rotate(c->ww, pm, c->pw, (unsigned)i + 1,
+					c->angle[i], &x, &y, &p);
+		ox[s] = round_out(x, c->ww, c->ow);
+		oy[s] = round_out(y, c->ww, c->ow);
+	}
+}
+
+/* rtl/seqpolar.v: last_state = state >= NSTAGES+1 (:208), so all NSTAGES
+ * rotations are seen; no zero-angle / i>=WW skip (:254-281). */
+void orc_seq_r2p(const orc_config *c, size_t n, const int32_t *xi,
+		const int32_t *yi, int32_t *omag, uint32_t *ophase)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		int64_t x, y;
+		uint32_t p;
+		r2p_prerotate(c, xi[s], yi[s], &x, &y, &p);
+		for (int i = 0; i < c->nstages; i++)
+			r2p_rotate(c->ww, pm, (unsigned)i + 1, c->angle[i],
+					&x, &y, &p);
+		omag[s] = round_out(x, c->ww, c->ow);
+		ophase[s] = p;
+	}
+}
+
+/* ------------------------------------- sequential cores, clock by clock */
+
+/* rtl/seqcordic.v:124-324, every register updated from the pre-edge values
+ * (non-blocking semantics).  The "mem" angle table has 2^nextlg(NSTAGES)
+ * entries, all computed by the formula (sw/cordiclib.cpp:145-149). */
+int orc_seq_p2r_cycle(const orc_config *c, int32_t ix, int32_t iy,
+		uint32_t iph, int32_t *ox, int32_t *oy)
+{
+	const int ns = c->nstages, ww = c->ww, pw = c->pw;
+	const uint32_t pm = pmask(pw);
+	const int sbits = orc_nextlg((unsigned)ns);
+	const unsigned smask = (1u << sbits) - 1u;
+	const unsigned tlen = 1u << sbits;
+	uint32_t table[128];
+	/* registers */
+	int64_t prex = 0, prey = 0, xv = 0, yv = 0;
+	uint32_t preph = 0, ph = 0, cangle = 0;
+	int idle = 1, pre_valid = 0, o_done = 0;
+	unsigned state = 0;
+	int32_t o_x = 0, o_y = 0;
+
+	for (unsigned k = 0; k < tlen; k++)
+		table[k] = angle_entry(k, pw);
+
+	for (int tick = 1; tick <= 4 * ns + 16; tick++) {
+		int i_stb = (tick == 1);
+		/* next-state values */
+		int64_t n_prex, n_prey, n_xv, n_yv;
+		uint32_t n_preph, n_ph, n_cangle;
+		int n_idle, n_pre_valid, n_o_done;
+		unsigned n_state;
+		int32_t n_ox = o_x, n_oy = o_y;
+
+		p2r_prerotate(c, ix, iy, iph, &n_prex, &n_prey, &n_preph);
+
+		if (i_stb)			n_idle = 0;
+		else if (state == (unsigned)(ns - 1))	n_idle = 1;
+		else				n_idle = idle;
+
+		n_pre_valid = i_stb && idle;
+		n_cangle = table[state & (tlen - 1)];
+
+		if (idle)			n_state = 0;
+		else if (state == (unsigned)(ns - 1))	n_state = 0;
+		else				n_state = (state + 1) & smask;
+
+		n_xv = xv; n_yv = yv; n_ph = ph;
+		if (pre_valid) {
+			n_xv = prex; n_yv = prey; n_ph = preph;
+		} else
+			p2r_rotate(ww, pm, pw, state, cangle,
+					&n_xv, &n_yv, &n_ph);
+
+		n_o_done = (state >= (unsigned)(ns - 1));
+		if (state >= (unsigned)(ns - 1)) {
+			n_ox = round_out(xv, ww, c->ow);
+			n_oy = round_out(yv, ww, c->ow);
+		}
+
+		/* clock edge */
+		prex = n_prex; prey = n_prey; preph = n_preph;
+		idle = n_idle; pre_valid = n_pre_valid; cangle = n_cangle;
+		state = n_state; xv = n_xv; yv = n_yv; ph = n_ph;
+		o_done = n_o_done; o_x = n_ox; o_y = n_oy;
+
+		if (o_done) {
+			*ox = o_x; *oy = o_y;
+			return tick;
+		}
+	}
+	return -1;
+}
+
+/* rtl/seqpolar.v:121-307 */
+int orc_seq_r2p_cycle(const orc_config *c, int32_t ix, int32_t iy,
+		int32_t *omag, uint32_t *ophase)
+{
+	const int ns = c->nstages, ww = c->ww, pw = c->pw;
+	const uint32_t pm = pmask(pw);
+	const int sbits = orc_nextlg((unsigned)ns + 1);
+	const unsigned smask = (1u << sbits) - 1u;
+	const unsigned tlen = 1u << orc_nextlg((unsigned)ns);
+	uint32_t table[128];
+	int64_t prex = 0, prey = 0, xv = 0, yv = 0;
+	uint32_t preph = 0, ph = 0, cangle = 0, o_ph = 0;
+	int idle = 1, pre_valid = 0, o_done = 0;
+	unsigned state = 0;
+	int32_t o_m = 0;
+
+	for (unsigned k = 0; k < tlen; k++)
+		table[k] = angle_entry(k, pw);
+
+	for (int tick = 1; tick <= 4 * ns + 16; tick++) {
+		int i_stb = (tick == 1);
+		int last_state = (state >= (unsigned)(ns + 1));
+		int64_t n_prex, n_prey, n_xv, n_yv;
+		uint32_t n_preph, n_ph, n_cangle, n_oph = o_ph;
+		int n_idle, n_pre_valid, n_o_done;
+		unsigned n_state;
+		int32_t n_om = o_m;
+
+		r2p_prerotate(c, ix, iy, &n_prex, &n_prey, &n_preph);
+
+		if (i_stb)		n_idle = 0;
+		else if (last_state)	n_idle = 1;
+		else			n_idle = idle;
+
+		n_pre_valid = i_stb && idle;
+
+		if (idle)		n_state = 0;
+		else if (last_state)	n_state = 0;
+		else			n_state = (state + 1) & smask;
+
+		n_cangle = table[state & (tlen - 1)];
+
+		n_xv = xv; n_yv = yv; n_ph = ph;
+		if (pre_valid) {
+			n_xv = prex; n_yv = prey; n_ph = preph;
+		} else
+			r2p_rotate(ww, pm, state, cangle, &n_xv, &n_yv, &n_ph);
+
+		n_o_done = last_state;
+		if (last_state) {
+			n_om = round_out(xv, ww, c->ow);
+			n_oph = ph;
+		}
+
+		prex = n_prex; prey = n_prey; preph = n_preph;
+		idle = n_idle; pre_valid = n_pre_valid; cangle = n_cangle;
+		state = n_state; xv = n_xv; yv = n_yv; ph = n_ph;
+		o_done = n_o_done; o_m = n_om; o_ph = n_oph;
+
+		if (o_done) {
+			*omag = o_m; *ophase = o_ph;
+			return tick;
+		}
+	}
+	return -1;
+}
+
+/* ---------------------------------------------------------------- dispatch */
+
+void orc_rotate(const orc_config *c, size_t n, const int32_t *x,
+		const int32_t *y, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy)
+{
+	if (c->mode == ORC_SP2R)
+		orc_seq_p2r(c, n, x, y, xy_stride, phase, ox, oy);
+	else
+		orc_p2r(c, n, x, y, xy_stride, phase, ox, oy);
+}
+
+void orc_topolar(const orc_config *c, size_t n, const int32_t *x,
+		const int32_t *y, int32_t *omag, uint32_t *ophase)
+{
+	if (c->mode == ORC_SR2P)
+		orc_seq_r2p(c, n, x, y, omag, ophase);
+	else
+		orc_r2p(c, n, x, y, omag, ophase);
+}
+
+void orc_nco(const orc_config *c, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, int32_t x0, int32_t y0,
+		int32_t *ox, int32_t *oy)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		uint32_t ph = (uint32_t)(phase0
+				+ (uint32_t)(index0 + s) * fcw) & pm;
+		orc_rotate(c, 1, &x0, &y0, 0, &ph, &ox[s], &oy[s]);
+	}
+}

@@ -1,0 +1,104 @@
+/*
+ * cordic_oracle.h -- CPU oracle for the CORDIC rotation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call it, and only as the checker / the reported CPU baseline.
+ *
+ * What this is: a plain-C, one-sample-at-a-time restatement of the integer
+ * arithmetic that the reference's core generator EMITS (the reference has no
+ * C++ function that computes a CORDIC sample; its executable model is the
+ * Verilator build of the emitted Verilog, and Verilator is absent here).
+ * Every function cites the reference file:line it follows.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - table / parameter math (angles, gain, variances, WW/PW/NSTAGES
+ *     derivation): PINNED against outputs of the real reference generator
+ *     built from /root/reference/sw by oracle/Makefile (oracle/_ref/gencordic)
+ *     and against the checked-in rtl/{cordic,topolar,seqcordic,seqpolar}.{v,h}
+ *     values, committed as fixtures under tests/golden/.
+ *   - per-sample arithmetic (pre-rotation, stages, rounding): the reference
+ *     holds NO per-sample golden vectors and its only executor cannot be
+ *     built here, so sample-level parity is UNPINNED BY REFERENCE FIXTURES.
+ *     It rests on (a) this restatement being literal, (b) the reference's own
+ *     pass criteria (bench/cpp/cordic_tb.cpp:285-337,
+ *     bench/cpp/topolar_tb.cpp:303-315) evaluated on this oracle's output at
+ *     the checked-in configuration, (c) tests/vsim.py, an independent
+ *     evaluator that executes the Verilog text emitted by oracle/_ref/gencordic
+ *     and must agree with this file sample for sample.
+ */
+#ifndef CORDIC_ORACLE_H
+#define CORDIC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_P2R = 0, ORC_R2P = 1, ORC_SP2R = 2, ORC_SR2P = 3 };
+#define ORC_MAX_STAGES 64
+
+typedef struct orc_config {
+	int	mode;
+	int	iw, ow, nxtra, ww, pw, nstages;
+	uint32_t angle[ORC_MAX_STAGES];	/* PW-bit, right justified */
+	double	quantization_variance, phase_variance_rad, gain;
+	double	best_possible_cnr;	/* p2r / sp2r only */
+	int	clocks_per_output;	/* sequential cores only, else 0 */
+} orc_config;
+
+/* sw/cordiclib.cpp restatements */
+int	orc_nextlg(unsigned vl);
+double	orc_cordic_gain(int nstages);
+double	orc_phase_variance(int nstages, int phase_bits);
+double	orc_transform_quantization_variance(int nstages, int xtrabits,
+		int dropped_bits);
+void	orc_cordic_angles(int nstages, int phase_bits, uint32_t *out);
+int	orc_calc_stages2(int working_width, int phase_bits);
+int	orc_calc_stages1(int phase_bits);
+int	orc_calc_phase_bits(int output_width);
+
+/* sw/main.cpp:260-357 -- CLI level: xtra is the -x value (default 2),
+ * phase_bits / nstages <= 0 mean "derive".  Returns 0 or a negative code. */
+int	orc_config_cli(orc_config *cfg, int mode, int iw, int ow, int xtra,
+		int phase_bits, int nstages);
+/* emitter level (sw/basiccordic.h:46-50 etc.): nxtra already incremented */
+int	orc_config_core(orc_config *cfg, int mode, int nstages, int iw, int ow,
+		int nxtra, int phase_bits);
+
+/* Per-sample arithmetic.  xy_stride = 1: x[i], y[i]; 0: x[0], y[0] for all. */
+void	orc_p2r(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy);
+void	orc_r2p(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int32_t *omag, uint32_t *ophase);
+/* closed forms of the sequential cores */
+void	orc_seq_p2r(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy);
+void	orc_seq_r2p(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int32_t *omag, uint32_t *ophase);
+/* clock-by-clock models of rtl/seqcordic.v / rtl/seqpolar.v; return the
+ * number of ticks from i_stb to o_done (must equal clocks_per_output) or -1 */
+int	orc_seq_p2r_cycle(const orc_config *cfg, int32_t x, int32_t y,
+		uint32_t phase, int32_t *ox, int32_t *oy);
+int	orc_seq_r2p_cycle(const orc_config *cfg, int32_t x, int32_t y,
+		int32_t *omag, uint32_t *ophase);
+
+/* dispatch on cfg->mode */
+void	orc_rotate(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int xy_stride, const uint32_t *phase,
+		int32_t *ox, int32_t *oy);
+void	orc_topolar(const orc_config *cfg, size_t n, const int32_t *x,
+		const int32_t *y, int32_t *omag, uint32_t *ophase);
+/* NCO: phase[i] = phase0 + (index0+i)*fcw mod 2^PW, then orc_rotate */
+void	orc_nco(const orc_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, int32_t x0, int32_t y0,
+		int32_t *ox, int32_t *oy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

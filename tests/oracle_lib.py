@@ -1,0 +1,158 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+P2R, R2P, SP2R, SR2P = 0, 1, 2, 3
+MAX_STAGES = 64
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int),
+        ("iw", C.c_int), ("ow", C.c_int), ("nxtra", C.c_int),
+        ("ww", C.c_int), ("pw", C.c_int), ("nstages", C.c_int),
+        ("angle", C.c_uint32 * MAX_STAGES),
+        ("quantization_variance", C.c_double),
+        ("phase_variance_rad", C.c_double),
+        ("gain", C.c_double),
+        ("best_possible_cnr", C.c_double),
+        ("clocks_per_output", C.c_int),
+    ]
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "cordic_oracle.c")
+    if (not os.path.exists(_SO)
+            or os.path.getmtime(_SO) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        i32p = C.POINTER(C.c_int32)
+        u32p = C.POINTER(C.c_uint32)
+        cfgp = C.POINTER(OrcConfig)
+        L.orc_config_cli.argtypes = [cfgp] + [C.c_int] * 6
+        L.orc_config_core.argtypes = [cfgp] + [C.c_int] * 6
+        for name in ("orc_p2r", "orc_seq_p2r", "orc_rotate"):
+            getattr(L, name).argtypes = [cfgp, C.c_size_t, i32p, i32p,
+                                         C.c_int, u32p, i32p, i32p]
+            getattr(L, name).restype = None
+        for name in ("orc_r2p", "orc_seq_r2p", "orc_topolar"):
+            getattr(L, name).argtypes = [cfgp, C.c_size_t, i32p, i32p,
+                                         i32p, u32p]
+            getattr(L, name).restype = None
+        L.orc_seq_p2r_cycle.argtypes = [cfgp, C.c_int32, C.c_int32,
+                                        C.c_uint32, i32p, i32p]
+        L.orc_seq_r2p_cycle.argtypes = [cfgp, C.c_int32, C.c_int32,
+                                        i32p, u32p]
+        L.orc_nco.argtypes = [cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
+                              C.c_uint64, C.c_int32, C.c_int32, i32p, i32p]
+        L.orc_nco.restype = None
+        L.orc_cordic_gain.restype = C.c_double
+        L.orc_cordic_gain.argtypes = [C.c_int]
+        L.orc_phase_variance.restype = C.c_double
+        L.orc_phase_variance.argtypes = [C.c_int, C.c_int]
+        L.orc_transform_quantization_variance.restype = C.c_double
+        L.orc_transform_quantization_variance.argtypes = [C.c_int] * 3
+        for name in ("orc_calc_stages1", "orc_calc_phase_bits"):
+            getattr(L, name).argtypes = [C.c_int]
+        L.orc_calc_stages2.argtypes = [C.c_int, C.c_int]
+        L.orc_nextlg.argtypes = [C.c_uint]
+        _lib = L
+    return _lib
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def config_cli(mode, iw=-1, ow=-1, xtra=2, pw=-1, nstages=-1):
+    """gencordic -t <mode> -i iw -o ow -x xtra -p pw -n nstages"""
+    cfg = OrcConfig()
+    rc = lib().orc_config_cli(C.byref(cfg), mode, iw, ow, xtra, pw, nstages)
+    if rc:
+        raise ValueError("orc_config_cli rc=%d" % rc)
+    return cfg
+
+
+def config_core(mode, nstages, iw, ow, nxtra, pw):
+    cfg = OrcConfig()
+    rc = lib().orc_config_core(C.byref(cfg), mode, nstages, iw, ow, nxtra, pw)
+    if rc:
+        raise ValueError("orc_config_core rc=%d" % rc)
+    return cfg
+
+
+def rotate(cfg, x, y, phase):
+    """p2r (pipelined or sequential per cfg.mode).  x, y: int32 arrays of
+    len(phase), or scalars (broadcast)."""
+    phase = np.ascontiguousarray(phase, dtype=np.uint32)
+    n = phase.size
+    if np.isscalar(x) or np.ndim(x) == 0:
+        xa = np.array([x], dtype=np.int32)
+        ya = np.array([y], dtype=np.int32)
+        stride = 0
+    else:
+        xa = np.ascontiguousarray(x, dtype=np.int32)
+        ya = np.ascontiguousarray(y, dtype=np.int32)
+        assert xa.size == n and ya.size == n
+        stride = 1
+    ox = np.empty(n, dtype=np.int32)
+    oy = np.empty(n, dtype=np.int32)
+    lib().orc_rotate(C.byref(cfg), n, _i32(xa), _i32(ya), stride,
+                     _u32(phase), _i32(ox), _i32(oy))
+    return ox, oy
+
+
+def topolar(cfg, x, y):
+    xa = np.ascontiguousarray(x, dtype=np.int32)
+    ya = np.ascontiguousarray(y, dtype=np.int32)
+    n = xa.size
+    mag = np.empty(n, dtype=np.int32)
+    ph = np.empty(n, dtype=np.uint32)
+    lib().orc_topolar(C.byref(cfg), n, _i32(xa), _i32(ya), _i32(mag), _u32(ph))
+    return mag, ph
+
+
+def nco(cfg, n, phase0, fcw, index0, x0, y0):
+    ox = np.empty(n, dtype=np.int32)
+    oy = np.empty(n, dtype=np.int32)
+    lib().orc_nco(C.byref(cfg), n, phase0, fcw, index0, x0, y0,
+                  _i32(ox), _i32(oy))
+    return ox, oy
+
+
+def seq_p2r_cycle(cfg, x, y, phase):
+    ox, oy = C.c_int32(), C.c_int32()
+    t = lib().orc_seq_p2r_cycle(C.byref(cfg), x, y, phase,
+                                C.byref(ox), C.byref(oy))
+    return t, ox.value, oy.value
+
+
+def seq_r2p_cycle(cfg, x, y):
+    m, p = C.c_int32(), C.c_uint32()
+    t = lib().orc_seq_r2p_cycle(C.byref(cfg), x, y, C.byref(m), C.byref(p))
+    return t, m.value, p.value

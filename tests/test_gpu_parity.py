@@ -1,0 +1,328 @@
+"""Parity tests proper: the HIP path through the C ABI against the oracle on
+the same inputs -- bit-exact (integer arithmetic: tolerance is zero)."""
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+import quality as Q
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if torch.cuda.is_available():
+    from gpu_util import (DEV, cpu_digest, dev_i32, gpu_digest, gpu_nco,
+                          gpu_p2r, gpu_r2p, to_np)
+
+
+def both(mode, iw=-1, ow=-1, xtra=2, pw=-1, ns=-1):
+    return (ca.Config.from_cli(mode, iw, ow, xtra, pw, ns),
+            O.config_cli(mode, iw, ow, xtra, pw, ns))
+
+
+def rand_inputs(rng, iw, pw, n):
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x = rng.randint(lo, hi, n).astype(np.int32)
+    y = rng.randint(lo, hi, n).astype(np.int32)
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    # adversarial head: extremes and octant / quadrant boundaries
+    ext = [lo, hi - 1, 0, -1, 1, lo + 1]
+    k = 0
+    for a in ext:
+        for b in ext:
+            if k < n:
+                x[k], y[k] = a, b
+                k += 1
+    q = 1 << max(pw - 3, 0)
+    edges = [(j * q + d) & 0xffffffff for j in range(9) for d in (-1, 0, 1)]
+    for j, e in enumerate(edges):
+        if 40 + j < n:
+            ph[40 + j] = e
+    return x, y, ph
+
+
+def assert_p2r(cfg, ocfg, x, y, ph, **kw):
+    gx, gy = gpu_p2r(cfg, x, y, ph, **kw)
+    rx, ry = O.rotate(ocfg, x, y, ph)
+    assert np.array_equal(gx, rx) and np.array_equal(gy, ry)
+
+
+def assert_r2p(cfg, ocfg, x, y, **kw):
+    gm, gp = gpu_r2p(cfg, x, y, **kw)
+    rm, rp = O.topolar(ocfg, x, y)
+    assert np.array_equal(gm, rm) and np.array_equal(gp, rp)
+
+
+# ------------------------------------------------------- BASELINE configs
+
+BASELINE_P2R = {
+    "cfg1": (ca.P2R, 16, 16, 2, 16, 16),
+    "cfg2": (ca.P2R, 32, 32, 2, 32, 16),
+    "cfg4": (ca.P2R, 32, 32, 2, 32, 24),
+    "cfg5_seq": (ca.SP2R, 32, 32, 2, 32, 16),
+    "rtl_cordic": (ca.P2R, 13, 13, 2, -1, -1),
+    "rtl_seqcordic": (ca.SP2R, 13, 13, 2, -1, -1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_P2R))
+def test_p2r_baseline_configs(name):
+    cfg, ocfg = both(*BASELINE_P2R[name])
+    rng = np.random.RandomState(11)
+    n = (1 << 20) + 3
+    x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, n)
+    assert_p2r(cfg, ocfg, x, y, ph)                     # vector inputs
+    x0 = (1 << (cfg.iw - 1)) - 1
+    assert_p2r(cfg, ocfg, x0, 0, ph)                    # bench-style const
+    assert_p2r(cfg, ocfg, -(1 << (cfg.iw - 1)), -(1 << (cfg.iw - 1)), ph)
+    # the bench's ramp (cordic_tb.cpp:138)
+    ramp = (np.arange(n, dtype=np.uint64) << 2).astype(np.uint32)
+    assert_p2r(cfg, ocfg, x0, 0, ramp)
+
+
+BASELINE_R2P = {
+    "cfg3": (ca.R2P, 24, 24, 2, -1, 20),
+    "rtl_topolar": (ca.R2P, 13, 13, 2, -1, -1),
+    "rtl_seqpolar": (ca.SR2P, 13, 13, 2, -1, -1),
+    "seq_cfg3": (ca.SR2P, 24, 24, 2, -1, 20),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_R2P))
+def test_r2p_baseline_configs(name):
+    cfg, ocfg = both(*BASELINE_R2P[name])
+    rng = np.random.RandomState(12)
+    n = (1 << 20) + 1
+    x, y, _ = rand_inputs(rng, cfg.iw, cfg.pw, n)
+    assert_r2p(cfg, ocfg, x, y)
+    # SURVEY 8d config 3 throughput ramps
+    g = np.arange(n, dtype=np.uint64)
+    sh = 32 - cfg.iw
+
+    def ramp(mul):
+        v = (((g * mul) & 0xffffffff) >> 8).astype(np.uint32)
+        return ((v << sh).astype(np.int32) >> sh)
+    assert_r2p(cfg, ocfg, ramp(0x9E3779B1), ramp(0x85EBCA77))
+
+
+# ------------------------------------------ exhaustive, reference criteria
+
+def test_exhaustive_p2r_checked_in_core_and_bench_criteria():
+    """All 2^20 phases of the checked-in core (rtl/cordic.v): equal to the
+    oracle, and the GPU output passes cordic_tb's thresholds."""
+    cfg, ocfg = both(ca.P2R, 13, 13, 2)
+    ph, x0, y0 = Q.p2r_bench_inputs(cfg.iw, cfg.pw)
+    gx, gy = gpu_p2r(cfg, x0, y0, ph)
+    rx, ry = O.rotate(ocfg, x0, y0, ph)
+    assert np.array_equal(gx, rx) and np.array_equal(gy, ry)
+    q = Q.p2r_quality(cfg, ph, x0, y0, gx, gy)
+    assert q["ok"], q
+    assert abs(q["cnr"] - cfg.best_possible_cnr) < 0.5
+
+
+def test_exhaustive_r2p_checked_in_core_and_bench_criteria():
+    cfg, ocfg = both(ca.R2P, 13, 13, 2)
+    x, y, mg = Q.r2p_bench_inputs(cfg.iw, cfg.pw)
+    gm, gp = gpu_r2p(cfg, x, y)
+    rm, rp = O.topolar(ocfg, x, y)
+    assert np.array_equal(gm, rm) and np.array_equal(gp, rp)
+    assert Q.r2p_quality(cfg, x, y, mg, gm, gp)["ok"]
+
+
+def test_exhaustive_small_core_all_inputs():
+    """IW=6: every (x, y, phase) triple of a small core, 2^6*2^6*2^9."""
+    cfg, ocfg = both(ca.P2R, 6, 6, 2, 9, -1)
+    v = np.arange(-32, 32, dtype=np.int32)
+    ph = np.arange(1 << 9, dtype=np.uint32)
+    X, Y, P = np.meshgrid(v, v, ph, indexing="ij")
+    assert_p2r(cfg, ocfg, X.ravel(), Y.ravel(), P.ravel().astype(np.uint32))
+    cfg, ocfg = both(ca.R2P, 9, 9, 2)
+    v = np.arange(-256, 256, dtype=np.int32)
+    X, Y = np.meshgrid(v, v, indexing="ij")
+    assert_r2p(cfg, ocfg, X.ravel(), Y.ravel())
+
+
+# ---------------------------------------------------------- config sweeps
+
+def test_parameter_sweep_all_kernel_paths():
+    """Random parameter sets: unrolled 32- and 64-bit kernels, the generic
+    kernel (stage counts without an unrolled instance) and cores that need
+    explicit WW-bit wrapping."""
+    rng = np.random.RandomState(5)
+    seen = {"wrap": 0, "wide": 0, "narrow": 0}
+    for trial in range(80):
+        mode = int(rng.randint(4))
+        iw, ow = int(rng.randint(1, 33)), int(rng.randint(1, 33))
+        xtra = int(rng.randint(0, 6))
+        pw = int(rng.randint(3, 33))
+        ns = int(rng.randint(1, 41))
+        try:
+            cfg = ca.Config.from_cli(mode, iw, ow, xtra, pw, ns)
+        except ca.CordicError:
+            with pytest.raises(ValueError):
+                O.config_cli(mode, iw, ow, xtra, pw, ns)
+            continue
+        ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
+        seen["wrap"] += cfg.needs_wrap
+        seen["wide" if cfg.ww > 32 else "narrow"] += 1
+        x, y, ph = rand_inputs(rng, iw, pw, 4099)
+        if mode in (ca.P2R, ca.SP2R):
+            assert_p2r(cfg, ocfg, x, y, ph)
+        else:
+            assert_r2p(cfg, ocfg, x, y)
+    assert seen["wrap"] >= 2 and seen["wide"] >= 10 and seen["narrow"] >= 10
+
+
+def test_tiny_cores_wrap_like_the_registers():
+    """WW of a few bits: truncation noise reaches full scale and the WW-bit
+    registers really overflow; the kernel must wrap exactly as they do."""
+    rng = np.random.RandomState(6)
+    hit = 0
+    for iw, ow, nx, pw, ns in [(1, 1, 1, 8, 6), (2, 1, 1, 6, 5), (1, 2, 1, 5, 8),
+                               (2, 2, 2, 7, 7), (3, 3, 1, 9, 12),
+                               (1, 1, 2, 3, 2)]:
+        for mode in (ca.P2R, ca.R2P):
+            try:
+                cfg = ca.Config.from_core(mode, ns, iw, ow, nx, pw)
+            except ca.CordicError:
+                continue
+            ocfg = O.config_core(mode, ns, iw, ow, nx, pw)
+            hit += cfg.needs_wrap
+            x, y, ph = rand_inputs(rng, iw, pw, 2048)
+            if mode == ca.P2R:
+                assert_p2r(cfg, ocfg, x, y, ph)
+            else:
+                assert_r2p(cfg, ocfg, x, y)
+    assert hit >= 3
+
+
+def test_generic_kernel_equals_unrolled_kernel():
+    for args in [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 16, 16, 2, 16, 16),
+                 (ca.R2P, 24, 24, 2, -1, 20)]:
+        cfg, ocfg = both(*args)
+        gen = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+        rng = np.random.RandomState(8)
+        x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, 70001)
+        if args[0] == ca.P2R:
+            a = gpu_p2r(cfg, x, y, ph)
+            b = gpu_p2r(gen, x, y, ph)
+        else:
+            a = gpu_r2p(cfg, x, y)
+            b = gpu_r2p(gen, x, y)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------- edge cases
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 255, 1023, 1024, 1025,
+                               4096 * 3 + 2])
+def test_ragged_sizes(n):
+    rng = np.random.RandomState(n + 1)
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    x, y, ph = rand_inputs(rng, 32, 32, n)
+    assert_p2r(cfg, ocfg, x, y, ph)
+    assert_p2r(cfg, ocfg, 12345, -777, ph)
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    x, y, _ = rand_inputs(rng, 24, 32, n)
+    assert_r2p(cfg, ocfg, x, y)
+
+
+@pytest.mark.parametrize("offset", [1, 2, 3])
+def test_unaligned_buffers(offset):
+    rng = np.random.RandomState(offset)
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    x, y, ph = rand_inputs(rng, 32, 32, 5000)
+    assert_p2r(cfg, ocfg, x, y, ph, offset=offset)
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    x, y, _ = rand_inputs(rng, 24, 32, 5000)
+    assert_r2p(cfg, ocfg, x, y, offset=offset)
+
+
+def test_inputs_are_taken_modulo_their_port_width():
+    """The ports are IW / PW bits wide (rtl/cordic.v:60-61): bits above them
+    in the 32-bit containers must not matter."""
+    rng = np.random.RandomState(9)
+    cfg, ocfg = both(ca.P2R, 13, 13, 2)
+    n = 10000
+    x, y, ph = rand_inputs(rng, 13, 20, n)
+    junk = rng.randint(0, 1 << 19, n).astype(np.int32)
+    xj = (x & 0x1fff) | (junk << 13)
+    yj = (y & 0x1fff) | ((junk ^ 0x5555) << 13)
+    phj = (ph & np.uint32(0xfffff)) | (junk.astype(np.uint32) << 20)
+    a = gpu_p2r(cfg, xj, yj, phj)
+    b = O.rotate(ocfg, x, y, ph & np.uint32(0xfffff))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    cfg, ocfg = both(ca.R2P, 13, 13, 2)
+    a = gpu_r2p(cfg, xj, yj)
+    b = O.topolar(ocfg, x, y)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_host_buffer_entry_points():
+    rng = np.random.RandomState(10)
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    x, y, ph = rand_inputs(rng, 32, 32, 33333)
+    a = ca.p2r_host(cfg, x, y, ph)
+    b = O.rotate(ocfg, x, y, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = ca.p2r_host(cfg, 2**31 - 1, 0, ph)
+    b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    x, y, _ = rand_inputs(rng, 24, 32, 33333)
+    a = ca.r2p_host(cfg, x, y)
+    b = O.topolar(ocfg, x, y)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_wrong_mode_is_refused_on_device_calls():
+    cfg = ca.Config.from_cli(ca.R2P, 13, 13, 2)
+    t = torch.zeros(16, dtype=torch.int32, device=DEV)
+    with pytest.raises(ca.CordicError):
+        ca.p2r_const(cfg, 1, 0, t, t, t)
+    cfg = ca.Config.from_cli(ca.P2R, 13, 13, 2)
+    with pytest.raises(ca.CordicError):
+        ca.r2p(cfg, t, t, t, t)
+
+
+# --------------------------------------------------------------------- NCO
+
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 16),
+                                  (ca.SP2R, 32, 32, 2, 32, 16),
+                                  (ca.P2R, 13, 13, 2, -1, -1),
+                                  (ca.P2R, 16, 16, 2, 16, 16)])
+def test_nco_equals_oracle(args):
+    cfg, ocfg = both(*args)
+    x0 = (1 << (cfg.iw - 1)) - 1
+    for n, phase0, fcw, index0 in [(100003, 0, 0x01234567, 0),
+                                   (4097, 0xdeadbeef, 0x9e3779b9, 12345),
+                                   (65536, 5, 1, (7 << 32) + 99)]:
+        a = gpu_nco(cfg, n, phase0, fcw, index0, x0, 0)
+        b = O.nco(ocfg, n, phase0, fcw, index0, x0, 0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------ input fills
+
+def test_fill_kernels_and_digest_twin():
+    n = 100000
+    t = torch.empty(n, dtype=torch.int32, device=DEV)
+    ca.fill_phase_ramp(t, (3 << 32) + 17, 2)
+    torch.cuda.synchronize()
+    g = np.arange(n, dtype=np.uint64) + np.uint64((3 << 32) + 17)
+    assert np.array_equal(to_np(t, np.uint32),
+                          ((g << np.uint64(2)) & np.uint64(0xffffffff))
+                          .astype(np.uint32))
+    x = torch.empty(n, dtype=torch.int32, device=DEV)
+    y = torch.empty(n, dtype=torch.int32, device=DEV)
+    ca.fill_iq_ramp(x, y, 5, 0x9E3779B1, 0x85EBCA77, 24)
+    torch.cuda.synchronize()
+    g = (np.arange(n, dtype=np.uint64) + np.uint64(5)) & np.uint64(0xffffffff)
+    ex = ((((g * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff))
+           >> np.uint64(8)).astype(np.uint32) << 8).astype(np.int32) >> 8
+    assert np.array_equal(to_np(x), ex)
+    assert gpu_digest(x, index0=77) == cpu_digest(to_np(x), index0=77)
+    # digests of shards add up to the digest of the whole
+    whole = gpu_digest(x, 0)
+    parts = (gpu_digest(x[:40000], 0) + gpu_digest(x[40000:], 40000)) % 2**64
+    assert whole == parts
