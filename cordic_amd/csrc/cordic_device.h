@@ -1,0 +1,394 @@
+#ifndef CORDIC_DEVICE_H
+#define CORDIC_DEVICE_H
+// cordic_device.h -- gfx950 (CDNA4) device code of the CORDIC rotation engine:
+// kernel-argument block, micro-rotation stages, pre/post steps and the
+// unrolled kernels.  Included by the instantiation units (cordic_inst_*.hip)
+// and by cordic_kernels.hip (generic kernels + launch logic).
+//
+// One lane owns one sample at a time (kVec consecutive samples per tile pass,
+// for 16-byte loads/stores and 4-way ILP over the serially dependent stage
+// chain).  No LDS tiling and no MFMA: the path is a pure streaming map --
+// 4..16 algorithmic bytes per sample against ~10 (WW<=32) or ~16 (WW<=64)
+// integer VALU operations per rotation -- so what matters is (a) the
+// instruction count of one micro-rotation, (b) 1 KiB-per-wave coalesced
+// global accesses, (c) enough waves in flight to cover HBM latency.
+//
+// Arithmetic contract (what "bit-exact" refers to): reference rtl/cordic.v
+// :85-86,131-188,231-283,288-314 and rtl/topolar.v:83-84,122-152,195-246,
+// 251-271, i.e. the Verilog emitted by sw/basiccordic.cpp / sw/topolar.cpp;
+// sequential flavours rtl/seqcordic.v:270-324, rtl/seqpolar.v:208,254-307.
+//
+// Representation:
+//  * phase: left-justified in a 32-bit register (P = phase << (32-PW)), so
+//    the PW-bit wrap is the natural 32-bit wrap, the sign test is bit 31, the
+//    octant is the top 3 bits.  The arctan table is pre-shifted the same way
+//    on the host and arrives in SGPRs through the kernel-argument block.
+//  * x / y: sign extended in a 32-bit (WW<=32) or 64-bit (WW<=64) container.
+//    When WW equals the container width the wrap is natural; when it is
+//    narrower the host has proven (cordic_config.cpp: overflow_reachable)
+//    that no value can leave the WW-bit range, otherwise the job goes to the
+//    generic kernel, which wraps explicitly after every operation.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "cordic_internal.h"
+
+namespace cordic_amd {
+namespace dev {
+
+constexpr int kBlock = 256;		// 4 waves: one per SIMD
+constexpr int kVec = 4;			// samples per lane per pass (16 B)
+constexpr int kTile = kBlock * kVec;	// samples per block per pass
+
+// Kernel-argument block: wave-uniform, so hipcc keeps it in SGPRs (s_load).
+struct CoreParams {
+	uint32_t angle[CORDIC_AMD_MAX_STAGES];	// left-justified arctan table
+	int32_t	nlive;		// rotations to perform (generic kernel)
+	int32_t	iw;		// port width of i_xval / i_yval
+	int32_t	in_shl;		// zeros appended below the input
+	int32_t	pw_shl;		// 32 - PW
+	int32_t	ww, ow;
+	int32_t	r;		// WW - OW: bits dropped at the output
+	uint32_t round_bit;	// 1 if WW > OW+1 (convergent rounding) else 0
+	int64_t	round_base;	// 2^(r-1) - 1 if rounding else 0
+	int32_t	wrap;		// generic kernel: wrap to WW bits explicitly
+	int32_t	x0, y0;		// constant-vector feeds (sign extended)
+	uint32_t phase0, fcw;	// NCO, left-justified
+	uint64_t index0;	// NCO: global index of sample 0
+};
+
+// ---------------------------------------------------------------- utilities
+
+__device__ __forceinline__ int32_t sext32(int32_t v, int w)
+{
+	const int s = 32 - w;		// w in 1..32
+	return (int32_t)((uint32_t)v << s) >> s;
+}
+__device__ __forceinline__ int64_t sext64(int64_t v, int w)
+{
+	const int s = 64 - w;		// w in 1..64
+	return (int64_t)((uint64_t)v << s) >> s;
+}
+
+// Measured on MI355X (tools/valu_microbench.hip, profiles/valu_microbench_r01.txt):
+// two-operand 32-bit integer VALU ops (add/sub/xor/or/not/shift) issue at the
+// full rate, every VOP3 form (three-operand integer ops, carry in/out,
+// v_alignbit) and every 64-bit op (v_ashrrev_i64, v_lshl_add_u64,
+// v_mad_i64_i32) at ~0.6x of it -- and a 64-bit op costs no more than a
+// three-operand 32-bit one.  So the micro-rotation is built around
+// v_mad_i64_i32 (D.i64 = S0.i32 * S1.i32 + S2.i64): with s = +/-1 per lane it
+// is the conditional negate, the carry chain and the 64-bit add of
+//      x' = x -/+ (y >>> k)
+// in ONE instruction, where xor/carry formulations need 4-6.  The same
+// instruction advances the phase (low word of the result; the high word of
+// the phase register pair is don't-care).
+//
+// v_mad_i64_i32 also writes a carry-out SGPR pair (VCC here, declared as a
+// clobber); nothing reads it, so no wait states are owed.
+// -s for s = +/-1 as one full-rate VOP2 (hipcc would fuse (d|1)^-2 into a
+// three-operand v_bitop3_b32)
+__device__ __forceinline__ int32_t op_flip(int32_t s)
+{
+	int32_t r;
+	asm("v_xor_b32 %0, -2, %1" : "=v"(r) : "v"(s));
+	return r;
+}
+__device__ __forceinline__ void op_mad(int64_t &acc, int32_t a, int32_t b)
+{
+	asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+// same with the multiplicand in an SGPR (the arctan table entry)
+__device__ __forceinline__ void op_mad_s(int64_t &acc, uint32_t a_sgpr, int32_t b)
+{
+	asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "s"(a_sgpr), "v"(b) : "vcc");
+}
+
+// x >>> K of a value held in a 32-bit container (low word of the pair)
+template <int K> __device__ __forceinline__ int32_t asr_lo(int64_t v)
+{
+	return (int32_t)(uint32_t)v >> ((K > 31) ? 31 : K);
+}
+// low 32 bits of a 64-bit value >>> K; equals the full result whenever it
+// fits in 32 bits (K >= WW-32)
+template <int K> __device__ __forceinline__ int32_t asr_narrow(int64_t v)
+{
+	const uint32_t lo = (uint32_t)v;
+	const int32_t hi = (int32_t)((uint64_t)v >> 32);
+	if constexpr (K <= 31)
+		return (int32_t)__builtin_amdgcn_alignbit((uint32_t)hi, lo, K);
+	else
+		return hi >> ((K - 32 > 31) ? 31 : K - 32);
+}
+
+// Container tags.  Both keep x, y and the phase in 64-bit register pairs (the
+// mad needs a 64-bit addend); Narrow32 only maintains the low words.
+struct Narrow32 { static constexpr bool wide = false; };
+struct Wide64   { static constexpr bool wide = true; };
+
+// ------------------------------------------------------- rotator: p2r stage
+
+// rtl/cordic.v:262-280 with s = +1 where the residual phase is >= 0, -1 where
+// it is negative:   x' = x - s*(y>>>k),  y' = y + s*(x>>>k),  p' = p - s*a.
+// GENERAL: (y>>>k) may need more than 32 bits (k < WW-32): explicit 64-bit
+// shift, conditional negate and add.
+template <typename C, int K, bool GENERAL>
+__device__ __forceinline__ void rot_stage(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a)
+{
+	const int32_t d = (int32_t)(uint32_t)p >> 31;	// -1: negative phase
+	const int32_t s = d | 1;
+	const int32_t ns = op_flip(s);			// -s
+	if constexpr (!C::wide) {
+		const int32_t sy = asr_lo<K>(y), sx = asr_lo<K>(x);
+		op_mad(x, sy, ns);
+		op_mad(y, sx, s);
+	} else if constexpr (!GENERAL) {
+		const int32_t sy = asr_narrow<K>(y), sx = asr_narrow<K>(x);
+		op_mad(x, sy, ns);
+		op_mad(y, sx, s);
+	} else {
+		constexpr int k = (K > 63) ? 63 : K;
+		const int64_t d64 = (int64_t)d, nd64 = ~d64;
+		const int64_t sy = y >> k, sx = x >> k;
+		x = x + ((sy + nd64) ^ nd64);	// phase >= 0: x - sy
+		y = y + ((sx + d64) ^ d64);	// phase <  0: y - sx
+	}
+	op_mad_s(p, a, ns);
+}
+
+// ---------------------------------------------------- converter: r2p stage
+
+// rtl/topolar.v:226-243 with t = +1 where y >= 0, -1 where y < 0:
+//   x' = x + t*(y>>>k),  y' = y - t*(x>>>k),  p' = p + t*a.
+template <typename C, int K, bool GENERAL>
+__device__ __forceinline__ void pol_stage(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a)
+{
+	const int32_t d = C::wide ? (int32_t)((uint64_t)y >> 32) >> 31
+				  : (int32_t)(uint32_t)y >> 31;
+	const int32_t t = d | 1;
+	const int32_t nt = op_flip(t);
+	if constexpr (!C::wide) {
+		const int32_t sy = asr_lo<K>(y), sx = asr_lo<K>(x);
+		op_mad(x, sy, t);
+		op_mad(y, sx, nt);
+	} else if constexpr (!GENERAL) {
+		const int32_t sy = asr_narrow<K>(y), sx = asr_narrow<K>(x);
+		op_mad(x, sy, t);
+		op_mad(y, sx, nt);
+	} else {
+		constexpr int k = (K > 63) ? 63 : K;
+		const int64_t d64 = (int64_t)d, nd64 = ~d64;
+		const int64_t sy = y >> k, sx = x >> k;
+		x = x + ((sy + d64) ^ d64);	// y < 0: x - sy
+		y = y + ((sx + nd64) ^ nd64);	// y >= 0: y - sx
+	}
+	op_mad_s(p, a, t);
+}
+
+// Compile-time unrolled stage chain over the kVec samples of a lane: stage
+// i of all samples before stage i+1, so the four dependency chains interleave.
+// The first NGEN stages of a Wide64 core use the GENERAL form.
+template <typename C, int NLIVE, int NGEN, int I = 0> struct RotChain {
+	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp)
+	{
+		if constexpr (I < NLIVE) {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				rot_stage<C, I + 1, (I < NGEN)>(x[v], y[v], p[v],
+						kp.angle[I]);
+			RotChain<C, NLIVE, NGEN, I + 1>::run(x, y, p, kp);
+		}
+	}
+};
+template <typename C, int NLIVE, int NGEN, int I = 0> struct PolChain {
+	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp)
+	{
+		if constexpr (I < NLIVE) {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				pol_stage<C, I + 1, (I < NGEN)>(x[v], y[v], p[v],
+						kp.angle[I]);
+			PolChain<C, NLIVE, NGEN, I + 1>::run(x, y, p, kp);
+		}
+	}
+};
+
+// ------------------------------------------------------------- pre / post
+
+// rtl/cordic.v:131-188 on a left-justified phase: q = quadrant of
+// (phase + 45 deg); rotate the vector by q * 90 deg, remove q * 2^(PW-2).
+template <typename T>
+__device__ __forceinline__ void fold_octant(T ex, T ey, uint32_t P, T &x, T &y,
+		uint32_t &p)
+{
+	using U = typename std::make_unsigned<T>::type;
+	const uint32_t q = (P + 0x20000000u) >> 30;
+	p = P - (q << 30);
+	const bool swap = (q & 1u) != 0;
+	const T a = swap ? ey : ex;
+	const T b = swap ? ex : ey;
+	const bool negx = (q == 1u) || (q == 2u);
+	const bool negy = (q >= 2u);
+	x = negx ? (T)((U)0 - (U)a) : a;
+	y = negy ? (T)((U)0 - (U)b) : b;
+}
+
+// rtl/topolar.v:122-152.  With ax = |e_x|, ay = |e_y| (two's complement
+// negation, i.e. exactly the -e_xval / -e_yval terms of the case arms):
+//   x0 = ax + ay in every quadrant; y0 = ay - ax when the signs agree,
+//   ax - ay otherwise; p0 = {1,7,3,5} * 2^(PW-3) for {++,+-,-+,--}.
+template <typename T>
+__device__ __forceinline__ void fold_quadrant(T ex, T ey, bool xneg, bool yneg,
+		T &x, T &y, uint32_t &p)
+{
+	using U = typename std::make_unsigned<T>::type;
+	const U ax = xneg ? (U)0 - (U)ex : (U)ex;
+	const U ay = yneg ? (U)0 - (U)ey : (U)ey;
+	x = (T)(ax + ay);
+	y = (xneg != yneg) ? (T)(ax - ay) : (T)(ay - ax);
+	const uint32_t oct = xneg ? (yneg ? 5u : 3u) : (yneg ? 7u : 1u);
+	p = oct << 29;
+}
+
+// rtl/cordic.v:288-295,311-312 (and the truncating form of
+// sw/basiccordic.cpp:433-438 when WW == OW+1, selected by round_bit == 0).
+template <typename T>
+__device__ __forceinline__ int32_t round_to_ow(T v, const CoreParams &kp)
+{
+	using U = typename std::make_unsigned<T>::type;
+	const U b = ((U)v >> kp.r) & (U)kp.round_bit;
+	const T w = (T)((U)v + (U)(T)kp.round_base + b);
+	return (int32_t)(w >> kp.r);
+}
+
+// ------------------------------------------------------- memory accessors
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+// --------------------------------------------------------- unrolled rotator
+
+// Processes whole 4-sample groups only (nvec of them); the launcher sends the
+// 0..3 trailing samples to the generic kernel.  Keeping the tail out of this
+// kernel is what lets hipcc emit global_load_dwordx4 / global_store_dwordx4.
+template <typename C, int NLIVE, int NGEN, Feed FEED>
+__global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
+		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
+		const u32x4 *__restrict__ phin, i32x4 *__restrict__ ox,
+		i32x4 *__restrict__ oy, size_t nvec)
+{
+	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
+	using U = typename std::make_unsigned<T>::type;
+	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
+			g += (size_t)gridDim.x * kBlock) {
+		uint32_t P[kVec];
+		int32_t ix[kVec], iy[kVec];
+		if constexpr (FEED == Feed::Nco_ConstXY) {
+			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
+			P[0] = kp.phase0 + s0 * kp.fcw;
+#pragma unroll
+			for (int v = 1; v < kVec; v++)
+				P[v] = P[v - 1] + kp.fcw;
+		} else {
+			const u32x4 t = phin[g];
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				P[v] = t[v] << kp.pw_shl;
+		}
+		if constexpr (FEED == Feed::PhaseArray_XYArray) {
+			const i32x4 tx = xin[g];
+			const i32x4 ty = yin[g];
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				ix[v] = sext32(tx[v], kp.iw);
+				iy[v] = sext32(ty[v], kp.iw);
+			}
+		} else {
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				ix[v] = kp.x0;
+				iy[v] = kp.y0;
+			}
+		}
+
+		int64_t x[kVec], y[kVec], p[kVec];
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const T ex = (T)((U)(T)ix[v] << kp.in_shl);
+			const T ey = (T)((U)(T)iy[v] << kp.in_shl);
+			T fx, fy;
+			uint32_t fp;
+			fold_octant<T>(ex, ey, P[v], fx, fy, fp);
+			x[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
+					uint32_t>::type)fx;
+			y[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
+					uint32_t>::type)fy;
+			p[v] = (int64_t)fp;
+		}
+
+		RotChain<C, NLIVE, NGEN>::run(x, y, p, kp);
+
+		i32x4 rx, ry;
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			rx[v] = round_to_ow<T>((T)x[v], kp);
+			ry[v] = round_to_ow<T>((T)y[v], kp);
+		}
+		// outputs are written once and never re-read here: stream them
+		__builtin_nontemporal_store(rx, &ox[g]);
+		__builtin_nontemporal_store(ry, &oy[g]);
+	}
+}
+
+// ------------------------------------------------------- unrolled converter
+
+template <typename C, int NLIVE, int NGEN>
+__global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
+		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
+		i32x4 *__restrict__ omag, u32x4 *__restrict__ oph, size_t nvec)
+{
+	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
+	using U = typename std::make_unsigned<T>::type;
+	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
+			g += (size_t)gridDim.x * kBlock) {
+		const i32x4 tx = xin[g];
+		const i32x4 ty = yin[g];
+		int64_t x[kVec], y[kVec], p[kVec];
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const int32_t ix = sext32(tx[v], kp.iw);
+			const int32_t iy = sext32(ty[v], kp.iw);
+			const T ex = (T)((U)(T)ix << kp.in_shl);
+			const T ey = (T)((U)(T)iy << kp.in_shl);
+			T fx, fy;
+			uint32_t fp;
+			fold_quadrant<T>(ex, ey, ix < 0, iy < 0, fx, fy, fp);
+			x[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
+					uint32_t>::type)fx;
+			y[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
+					uint32_t>::type)fy;
+			p[v] = (int64_t)fp;
+		}
+
+		PolChain<C, NLIVE, NGEN>::run(x, y, p, kp);
+
+		i32x4 rm;
+		u32x4 rp;
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			rm[v] = round_to_ow<T>((T)x[v], kp);
+			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
+		}
+		__builtin_nontemporal_store(rm, &omag[g]);
+		__builtin_nontemporal_store(rp, &oph[g]);
+	}
+}
+
+} // namespace dev
+} // namespace cordic_amd
+#endif

@@ -1,0 +1,73 @@
+// cordic_inst_body.h -- one instantiation unit of the unrolled kernels.
+// The including .hip file defines
+//   CORDIC_INST_KIND       1 = rotator (p2r), 2 = converter (r2p)
+//   CORDIC_INST_NAME       name of the launcher this unit exports
+//   CORDIC_INST_CONTAINER  dev::Narrow32 or dev::Wide64
+//   CORDIC_INST_NGEN       leading stages in the GENERAL 64-bit form
+// Splitting the instances over several translation units keeps the build
+// parallel (each unit compiles in ~15 s).
+#include <hip/hip_runtime.h>
+
+#include "cordic_device.h"
+#include "cordic_launch.h"
+
+namespace cordic_amd {
+
+#if CORDIC_INST_KIND == 1
+namespace {
+template <Feed FEED>
+bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
+		const RotatorJob &j)
+{
+	using namespace dev;
+	constexpr int G = CORDIC_INST_NGEN;
+	switch (nlive) {
+#define X(N) case N: \
+	hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER, N, \
+			(G > N ? N : G), FEED>), dim3(grid), dim3(kBlock), 0, st, \
+		kp, (const i32x4 *)j.x, (const i32x4 *)j.y, \
+		(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec); \
+	return true;
+	CORDIC_ROT_STAGES(X)
+#undef X
+	default:
+		return false;
+	}
+}
+} // namespace
+
+bool CORDIC_INST_NAME(Feed feed, int nlive, int grid, hipStream_t st,
+		const dev::CoreParams &kp, const RotatorJob &j)
+{
+	switch (feed) {
+	case Feed::PhaseArray_ConstXY:
+		return launch_feed<Feed::PhaseArray_ConstXY>(nlive, grid, st, kp, j);
+	case Feed::PhaseArray_XYArray:
+		return launch_feed<Feed::PhaseArray_XYArray>(nlive, grid, st, kp, j);
+	default:
+		return launch_feed<Feed::Nco_ConstXY>(nlive, grid, st, kp, j);
+	}
+}
+#else
+bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,
+		const dev::CoreParams &kp, const int32_t *x, const int32_t *y,
+		int32_t *mag, uint32_t *ph, size_t n)
+{
+	using namespace dev;
+	constexpr int G = CORDIC_INST_NGEN;
+	switch (nlive) {
+#define X(N) case N: \
+	hipLaunchKernelGGL((topolar_unrolled<CORDIC_INST_CONTAINER, N, \
+			(G > N ? N : G)>), dim3(grid), dim3(kBlock), 0, st, kp, \
+		(const i32x4 *)x, (const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, \
+		n / kVec); \
+	return true;
+	CORDIC_POL_STAGES(X)
+#undef X
+	default:
+		return false;
+	}
+}
+#endif
+
+} // namespace cordic_amd

@@ -1,0 +1,6 @@
+// cordic_inst_rot_wide8.hip -- instantiation unit (see cordic_inst_body.h)
+#define CORDIC_INST_KIND 1
+#define CORDIC_INST_NAME launch_rot_wide8
+#define CORDIC_INST_CONTAINER dev::Wide64
+#define CORDIC_INST_NGEN 8
+#include "cordic_inst_body.h"

@@ -1,368 +1,18 @@
-// cordic_kernels.hip -- gfx950 (CDNA4) kernels of the CORDIC rotation engine.
-//
-// One lane owns one sample at a time (kVec consecutive samples per tile pass,
-// for 16-byte loads/stores and 4-way ILP over the serially dependent stage
-// chain).  No LDS tiling and no MFMA: the path is a pure streaming map --
-// 4..16 algorithmic bytes per sample against ~10 (WW<=32) or ~16 (WW<=64)
-// integer VALU operations per rotation -- so what matters is (a) the
-// instruction count of one micro-rotation, (b) 1 KiB-per-wave coalesced
-// global accesses, (c) enough waves in flight to cover HBM latency.
-//
-// Arithmetic contract (what "bit-exact" refers to): reference rtl/cordic.v
-// :85-86,131-188,231-283,288-314 and rtl/topolar.v:83-84,122-152,195-246,
-// 251-271, i.e. the Verilog emitted by sw/basiccordic.cpp / sw/topolar.cpp;
-// sequential flavours rtl/seqcordic.v:270-324, rtl/seqpolar.v:208,254-307.
-//
-// Representation:
-//  * phase: left-justified in a 32-bit register (P = phase << (32-PW)), so
-//    the PW-bit wrap is the natural 32-bit wrap, the sign test is bit 31, the
-//    octant is the top 3 bits.  The arctan table is pre-shifted the same way
-//    on the host and arrives in SGPRs through the kernel-argument block.
-//  * x / y: sign extended in a 32-bit (WW<=32) or 64-bit (WW<=64) container.
-//    When WW equals the container width the wrap is natural; when it is
-//    narrower the host has proven (cordic_config.cpp: overflow_reachable)
-//    that no value can leave the WW-bit range, otherwise the job goes to the
-//    generic kernel, which wraps explicitly after every operation.
+// cordic_kernels.hip -- generic (run-time parameterised) kernels, test-input
+// kernels and the launch logic that picks between them and the unrolled
+// instances (cordic_inst_*.hip).  Device code shared with the instances lives
+// in cordic_device.h.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <type_traits>
 
+#include "cordic_device.h"
 #include "cordic_internal.h"
+#include "cordic_launch.h"
 
 namespace cordic_amd {
 namespace {
-
-constexpr int kBlock = 256;		// 4 waves: one per SIMD
-constexpr int kVec = 4;			// samples per lane per pass (16 B)
-constexpr int kTile = kBlock * kVec;	// samples per block per pass
-
-// Kernel-argument block: wave-uniform, so hipcc keeps it in SGPRs (s_load).
-struct CoreParams {
-	uint32_t angle[CORDIC_AMD_MAX_STAGES];	// left-justified arctan table
-	int32_t	nlive;		// rotations to perform (generic kernel)
-	int32_t	iw;		// port width of i_xval / i_yval
-	int32_t	in_shl;		// zeros appended below the input
-	int32_t	pw_shl;		// 32 - PW
-	int32_t	ww, ow;
-	int32_t	r;		// WW - OW: bits dropped at the output
-	uint32_t round_bit;	// 1 if WW > OW+1 (convergent rounding) else 0
-	int64_t	round_base;	// 2^(r-1) - 1 if rounding else 0
-	int32_t	wrap;		// generic kernel: wrap to WW bits explicitly
-	int32_t	x0, y0;		// constant-vector feeds (sign extended)
-	uint32_t phase0, fcw;	// NCO, left-justified
-	uint64_t index0;	// NCO: global index of sample 0
-};
-
-// ---------------------------------------------------------------- utilities
-
-__device__ __forceinline__ int32_t sext32(int32_t v, int w)
-{
-	const int s = 32 - w;		// w in 1..32
-	return (int32_t)((uint32_t)v << s) >> s;
-}
-__device__ __forceinline__ int64_t sext64(int64_t v, int w)
-{
-	const int s = 64 - w;		// w in 1..64
-	return (int64_t)((uint64_t)v << s) >> s;
-}
-
-// Single-instruction wrappers.  hipcc's instcombine rewrites the
-// conditional-negate identities below into longer add3/xor sequences; making
-// the direction masks opaque and naming v_xad_u32 keeps a WW<=32 rotation at
-// ten VALU operations.  Each statement is one VALU instruction with VGPR/SGPR
-// operands only, so no wait states are owed inside or around it.
-__device__ __forceinline__ uint32_t op_sign_mask(uint32_t v)
-{
-	uint32_t d;
-	asm("v_ashrrev_i32 %0, 31, %1" : "=v"(d) : "v"(v));
-	return d;
-}
-__device__ __forceinline__ uint32_t op_not(uint32_t v)
-{
-	uint32_t d;
-	asm("v_not_b32 %0, %1" : "=v"(d) : "v"(v));
-	return d;
-}
-// (a ^ b) + c
-__device__ __forceinline__ uint32_t op_xad(uint32_t a, uint32_t b, uint32_t c)
-{
-	uint32_t d;
-	asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
-__device__ __forceinline__ uint32_t op_xad_s(uint32_t a_sgpr, uint32_t b,
-		uint32_t c)
-{
-	uint32_t d;
-	asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "s"(a_sgpr), "v"(b), "v"(c));
-	return d;
-}
-
-template <int K> struct ShiftOf {
-	static constexpr int s32 = (K > 31) ? 31 : K;
-	static constexpr int s64 = (K > 63) ? 63 : K;
-};
-
-// ------------------------------------------------------- rotator: p2r stage
-
-// rtl/cordic.v:262-280.  d = -1 where the residual phase is negative.
-//   phase <  0: x' = x + (y>>>k), y' = y - (x>>>k), p' = p + a
-//   phase >= 0: x' = x - (y>>>k), y' = y + (x>>>k), p' = p - a
-// With nd = ~d:  x' = ((y>>>k) ^ nd) + (x - nd)
-//                y' = ((x>>>k) ^ d ) + (y - d )
-//                p' = ( a      ^ nd) + (p - nd)
-template <int K>
-__device__ __forceinline__ void rot_stage(int32_t &x, int32_t &y, uint32_t &p,
-		uint32_t a)
-{
-	const uint32_t d = op_sign_mask(p);
-	const uint32_t nd = op_not(d);
-	const uint32_t sy = (uint32_t)(y >> ShiftOf<K>::s32);
-	const uint32_t sx = (uint32_t)(x >> ShiftOf<K>::s32);
-	const uint32_t xt = (uint32_t)x - nd;
-	const uint32_t yt = (uint32_t)y - d;
-	const uint32_t pt = p - nd;
-	x = (int32_t)op_xad(sy, nd, xt);
-	y = (int32_t)op_xad(sx, d, yt);
-	p = op_xad_s(a, nd, pt);
-}
-
-template <int K>
-__device__ __forceinline__ void rot_stage(int64_t &x, int64_t &y, uint32_t &p,
-		uint32_t a)
-{
-	const int32_t d = (int32_t)p >> 31;
-	const int64_t d64 = (int64_t)d;
-	const uint32_t neg = p >> 31;
-	const int64_t sy = (y >> ShiftOf<K>::s64) ^ d64;
-	const int64_t sx = (x >> ShiftOf<K>::s64) ^ d64;
-	x = x - sy - (int64_t)neg;
-	y = y + sx + (int64_t)neg;
-	p = p - (a ^ (uint32_t)d) - neg;
-}
-
-// ---------------------------------------------------- converter: r2p stage
-
-// rtl/topolar.v:226-243.  d = -1 where y is negative (below the axis).
-//   y <  0: x' = x - (y>>>k), y' = y + (x>>>k), p' = p - a
-//   y >= 0: x' = x + (y>>>k), y' = y - (x>>>k), p' = p + a
-// With nd = ~d:  x' = ((y>>>k) ^ d ) + (x - d )
-//                y' = ((x>>>k) ^ nd) + (y - nd)
-//                p' = ( a      ^ d ) + (p - d )
-template <int K>
-__device__ __forceinline__ void pol_stage(int32_t &x, int32_t &y, uint32_t &p,
-		uint32_t a)
-{
-	const uint32_t d = op_sign_mask((uint32_t)y);
-	const uint32_t nd = op_not(d);
-	const uint32_t sy = (uint32_t)(y >> ShiftOf<K>::s32);
-	const uint32_t sx = (uint32_t)(x >> ShiftOf<K>::s32);
-	const uint32_t xt = (uint32_t)x - d;
-	const uint32_t yt = (uint32_t)y - nd;
-	const uint32_t pt = p - d;
-	x = (int32_t)op_xad(sy, d, xt);
-	y = (int32_t)op_xad(sx, nd, yt);
-	p = op_xad_s(a, d, pt);
-}
-
-template <int K>
-__device__ __forceinline__ void pol_stage(int64_t &x, int64_t &y, uint32_t &p,
-		uint32_t a)
-{
-	const int64_t d64 = y >> 63;
-	const uint32_t d = (uint32_t)d64;
-	const uint32_t neg = d & 1u;
-	const int64_t sy = (y >> ShiftOf<K>::s64) ^ d64;
-	const int64_t sx = (x >> ShiftOf<K>::s64) ^ d64;
-	x = x + sy + (int64_t)neg;
-	y = y - sx - (int64_t)neg;
-	p = p + (a ^ d) + neg;
-}
-
-// Compile-time unrolled stage chain over the kVec samples of a lane: stage
-// i of all samples before stage i+1, so the four dependency chains interleave.
-template <typename T, int NLIVE, int I = 0> struct RotChain {
-	static __device__ __forceinline__ void run(T (&x)[kVec], T (&y)[kVec],
-			uint32_t (&p)[kVec], const CoreParams &kp)
-	{
-		if constexpr (I < NLIVE) {
-#pragma unroll
-			for (int v = 0; v < kVec; v++)
-				rot_stage<I + 1>(x[v], y[v], p[v], kp.angle[I]);
-			RotChain<T, NLIVE, I + 1>::run(x, y, p, kp);
-		}
-	}
-};
-template <typename T, int NLIVE, int I = 0> struct PolChain {
-	static __device__ __forceinline__ void run(T (&x)[kVec], T (&y)[kVec],
-			uint32_t (&p)[kVec], const CoreParams &kp)
-	{
-		if constexpr (I < NLIVE) {
-#pragma unroll
-			for (int v = 0; v < kVec; v++)
-				pol_stage<I + 1>(x[v], y[v], p[v], kp.angle[I]);
-			PolChain<T, NLIVE, I + 1>::run(x, y, p, kp);
-		}
-	}
-};
-
-// ------------------------------------------------------------- pre / post
-
-// rtl/cordic.v:131-188 on a left-justified phase: q = quadrant of
-// (phase + 45 deg); rotate the vector by q * 90 deg, remove q * 2^(PW-2).
-template <typename T>
-__device__ __forceinline__ void fold_octant(T ex, T ey, uint32_t P, T &x, T &y,
-		uint32_t &p)
-{
-	using U = typename std::make_unsigned<T>::type;
-	const uint32_t q = (P + 0x20000000u) >> 30;
-	p = P - (q << 30);
-	const bool swap = (q & 1u) != 0;
-	const T a = swap ? ey : ex;
-	const T b = swap ? ex : ey;
-	const bool negx = (q == 1u) || (q == 2u);
-	const bool negy = (q >= 2u);
-	x = negx ? (T)((U)0 - (U)a) : a;
-	y = negy ? (T)((U)0 - (U)b) : b;
-}
-
-// rtl/topolar.v:122-152.  With ax = |e_x|, ay = |e_y| (two's complement
-// negation, i.e. exactly the -e_xval / -e_yval terms of the case arms):
-//   x0 = ax + ay in every quadrant; y0 = ay - ax when the signs agree,
-//   ax - ay otherwise; p0 = {1,7,3,5} * 2^(PW-3) for {++,+-,-+,--}.
-template <typename T>
-__device__ __forceinline__ void fold_quadrant(T ex, T ey, bool xneg, bool yneg,
-		T &x, T &y, uint32_t &p)
-{
-	using U = typename std::make_unsigned<T>::type;
-	const U ax = xneg ? (U)0 - (U)ex : (U)ex;
-	const U ay = yneg ? (U)0 - (U)ey : (U)ey;
-	x = (T)(ax + ay);
-	y = (xneg != yneg) ? (T)(ax - ay) : (T)(ay - ax);
-	const uint32_t oct = xneg ? (yneg ? 5u : 3u) : (yneg ? 7u : 1u);
-	p = oct << 29;
-}
-
-// rtl/cordic.v:288-295,311-312 (and the truncating form of
-// sw/basiccordic.cpp:433-438 when WW == OW+1, selected by round_bit == 0).
-template <typename T>
-__device__ __forceinline__ int32_t round_to_ow(T v, const CoreParams &kp)
-{
-	using U = typename std::make_unsigned<T>::type;
-	const U b = ((U)v >> kp.r) & (U)kp.round_bit;
-	const T w = (T)((U)v + (U)(T)kp.round_base + b);
-	return (int32_t)(w >> kp.r);
-}
-
-// ------------------------------------------------------- memory accessors
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-
-// --------------------------------------------------------- unrolled rotator
-
-// Processes whole 4-sample groups only (nvec of them); the launcher sends the
-// 0..3 trailing samples to the generic kernel.  Keeping the tail out of this
-// kernel is what lets hipcc emit global_load_dwordx4 / global_store_dwordx4.
-template <typename T, int NLIVE, Feed FEED>
-__global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
-		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
-		const u32x4 *__restrict__ phin, i32x4 *__restrict__ ox,
-		i32x4 *__restrict__ oy, size_t nvec)
-{
-	using U = typename std::make_unsigned<T>::type;
-	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-			g += (size_t)gridDim.x * kBlock) {
-		uint32_t P[kVec];
-		int32_t ix[kVec], iy[kVec];
-		if constexpr (FEED == Feed::Nco_ConstXY) {
-			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
-			P[0] = kp.phase0 + s0 * kp.fcw;
-#pragma unroll
-			for (int v = 1; v < kVec; v++)
-				P[v] = P[v - 1] + kp.fcw;
-		} else {
-			const u32x4 t = phin[g];
-#pragma unroll
-			for (int v = 0; v < kVec; v++)
-				P[v] = t[v] << kp.pw_shl;
-		}
-		if constexpr (FEED == Feed::PhaseArray_XYArray) {
-			const i32x4 tx = xin[g];
-			const i32x4 ty = yin[g];
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				ix[v] = sext32(tx[v], kp.iw);
-				iy[v] = sext32(ty[v], kp.iw);
-			}
-		} else {
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				ix[v] = kp.x0;
-				iy[v] = kp.y0;
-			}
-		}
-
-		T x[kVec], y[kVec];
-		uint32_t p[kVec];
-#pragma unroll
-		for (int v = 0; v < kVec; v++) {
-			const T ex = (T)((U)(T)ix[v] << kp.in_shl);
-			const T ey = (T)((U)(T)iy[v] << kp.in_shl);
-			fold_octant<T>(ex, ey, P[v], x[v], y[v], p[v]);
-		}
-
-		RotChain<T, NLIVE>::run(x, y, p, kp);
-
-		i32x4 rx, ry;
-#pragma unroll
-		for (int v = 0; v < kVec; v++) {
-			rx[v] = round_to_ow<T>(x[v], kp);
-			ry[v] = round_to_ow<T>(y[v], kp);
-		}
-		// outputs are written once and never re-read here: stream them
-		__builtin_nontemporal_store(rx, &ox[g]);
-		__builtin_nontemporal_store(ry, &oy[g]);
-	}
-}
-
-// ------------------------------------------------------- unrolled converter
-
-template <typename T, int NLIVE>
-__global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
-		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
-		i32x4 *__restrict__ omag, u32x4 *__restrict__ oph, size_t nvec)
-{
-	using U = typename std::make_unsigned<T>::type;
-	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-			g += (size_t)gridDim.x * kBlock) {
-		const i32x4 tx = xin[g];
-		const i32x4 ty = yin[g];
-		T x[kVec], y[kVec];
-		uint32_t p[kVec];
-#pragma unroll
-		for (int v = 0; v < kVec; v++) {
-			const int32_t ix = sext32(tx[v], kp.iw);
-			const int32_t iy = sext32(ty[v], kp.iw);
-			const T ex = (T)((U)(T)ix << kp.in_shl);
-			const T ey = (T)((U)(T)iy << kp.in_shl);
-			fold_quadrant<T>(ex, ey, ix < 0, iy < 0, x[v], y[v], p[v]);
-		}
-
-		PolChain<T, NLIVE>::run(x, y, p, kp);
-
-		i32x4 rm;
-		u32x4 rp;
-#pragma unroll
-		for (int v = 0; v < kVec; v++) {
-			rm[v] = round_to_ow<T>(x[v], kp);
-			rp[v] = p[v] >> kp.pw_shl;	// rtl/topolar.v:269
-		}
-		__builtin_nontemporal_store(rm, &omag[g]);
-		__builtin_nontemporal_store(rp, &oph[g]);
-	}
-}
+using namespace dev;
 
 // ------------------------------------------------------------ generic path
 //
@@ -571,26 +221,14 @@ int32_t host_sext(int32_t v, int w)
 	return (int32_t)((uint32_t)v << s) >> s;
 }
 
-// The unrolled instances that exist.  Anything else runs on the generic
-// kernels (same results, lower throughput).
-#define CORDIC_ROT_STAGES(X) X(13) X(14) X(16) X(18) X(20) X(22) X(24) X(30)
-#define CORDIC_POL_STAGES(X) X(16) X(18) X(20) X(24) X(30)
-
-template <typename T, Feed FEED>
-bool launch_rot_unrolled(int nlive, int grid, hipStream_t st, const CoreParams &kp,
-		const RotatorJob &j)
+// Number of leading stages whose shifted operand may not fit in 32 bits
+// (k < WW-32), rounded up to an instantiated value.
+int general_stages_for(int ww)
 {
-	switch (nlive) {
-#define X(N) case N: \
-	hipLaunchKernelGGL((rotator_unrolled<T, N, FEED>), dim3(grid), \
-		dim3(kBlock), 0, st, kp, (const i32x4 *)j.x, (const i32x4 *)j.y, \
-		(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec); \
-	return true;
-	CORDIC_ROT_STAGES(X)
-#undef X
-	default:
-		return false;
-	}
+	const int need = ww - 33;	// stages k = 1 .. WW-33
+	if (need <= 2) return 2;
+	if (need <= 8) return 8;
+	return kAllGeneral;
 }
 
 template <Feed FEED>
@@ -616,9 +254,18 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		const int grid = grid_for(kTile, j.n);
 		if (grid < 0)
 			return CORDIC_ERR_DEVICE;
-		const bool done = (j.n < (size_t)kVec) ? false : (cfg.ww <= 32)
-			? launch_rot_unrolled<int32_t, FEED>(cfg.nlive, grid, st, kp, j)
-			: launch_rot_unrolled<int64_t, FEED>(cfg.nlive, grid, st, kp, j);
+		bool done = false;
+		if (j.n >= (size_t)kVec) {
+			const int ngen = general_stages_for(cfg.ww);
+			if (cfg.ww <= 32)
+				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);
+			else if (ngen == 2)
+				done = launch_rot_wide2(FEED, cfg.nlive, grid, st, kp, j);
+			else if (ngen == 8)
+				done = launch_rot_wide8(FEED, cfg.nlive, grid, st, kp, j);
+			else
+				done = launch_rot_wideall(FEED, cfg.nlive, grid, st, kp, j);
+		}
 		if (done) {
 			// 0..3 trailing samples: generic kernel on the remainder
 			const size_t head = j.n - j.n % kVec;
@@ -643,24 +290,6 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 	hipLaunchKernelGGL((rotator_generic<FEED>), dim3(grid), dim3(kBlock), 0,
 			st, kp, j.x, j.y, j.phase, j.ox, j.oy, j.n);
 	return check_launch();
-}
-
-template <typename T>
-bool launch_pol_unrolled(int nlive, int grid, hipStream_t st, const CoreParams &kp,
-		const int32_t *x, const int32_t *y, int32_t *mag, uint32_t *ph,
-		size_t n)
-{
-	switch (nlive) {
-#define X(N) case N: \
-	hipLaunchKernelGGL((topolar_unrolled<T, N>), dim3(grid), dim3(kBlock), \
-		0, st, kp, (const i32x4 *)x, (const i32x4 *)y, (i32x4 *)mag, \
-		(u32x4 *)ph, n / kVec); \
-	return true;
-	CORDIC_POL_STAGES(X)
-#undef X
-	default:
-		return false;
-	}
 }
 
 } // namespace
@@ -707,11 +336,19 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		const int grid = grid_for(kTile, n);
 		if (grid < 0)
 			return CORDIC_ERR_DEVICE;
-		const bool done = (n < (size_t)kVec) ? false : (cfg.ww <= 32)
-			? launch_pol_unrolled<int32_t>(cfg.nlive, grid, st, kp, x, y,
-					mag, phase, n)
-			: launch_pol_unrolled<int64_t>(cfg.nlive, grid, st, kp, x, y,
-					mag, phase, n);
+		bool done = false;
+		if (n >= (size_t)kVec) {
+			const int ngen = general_stages_for(cfg.ww);
+			if (cfg.ww <= 32)
+				done = launch_pol_narrow(cfg.nlive, grid, st, kp, x, y,
+						mag, phase, n);
+			else if (ngen <= 8)
+				done = launch_pol_wide8(cfg.nlive, grid, st, kp, x, y,
+						mag, phase, n);
+			else
+				done = launch_pol_wideall(cfg.nlive, grid, st, kp, x, y,
+						mag, phase, n);
+		}
 		if (done) {
 			const size_t head = n - n % kVec;
 			if (head == n)

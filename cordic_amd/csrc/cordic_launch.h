@@ -1,0 +1,37 @@
+// cordic_launch.h -- launchers exported by the instantiation units.
+#ifndef CORDIC_LAUNCH_H
+#define CORDIC_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "cordic_device.h"
+#include "cordic_internal.h"
+
+// The unrolled instances that exist (number of live rotations).  Anything
+// else runs on the generic kernels (same results, lower throughput).
+#define CORDIC_ROT_STAGES(X) X(13) X(14) X(16) X(18) X(20) X(22) X(24) X(30)
+#define CORDIC_POL_STAGES(X) X(16) X(18) X(20) X(24) X(30)
+
+namespace cordic_amd {
+
+// every stage in the GENERAL form
+constexpr int kAllGeneral = 1 << 20;
+
+#define CORDIC_ROT_LAUNCHER(NAME) \
+	bool NAME(Feed feed, int nlive, int grid, hipStream_t st, \
+		const dev::CoreParams &kp, const RotatorJob &j)
+#define CORDIC_POL_LAUNCHER(NAME) \
+	bool NAME(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp, \
+		const int32_t *x, const int32_t *y, int32_t *mag, uint32_t *ph, \
+		size_t n)
+
+CORDIC_ROT_LAUNCHER(launch_rot_narrow);		// WW <= 32
+CORDIC_ROT_LAUNCHER(launch_rot_wide2);		// WW <= 35
+CORDIC_ROT_LAUNCHER(launch_rot_wide8);		// WW <= 41
+CORDIC_ROT_LAUNCHER(launch_rot_wideall);	// WW <= 64
+CORDIC_POL_LAUNCHER(launch_pol_narrow);
+CORDIC_POL_LAUNCHER(launch_pol_wide8);
+CORDIC_POL_LAUNCHER(launch_pol_wideall);
+
+} // namespace cordic_amd
+#endif

@@ -68,6 +68,18 @@ KERNEL32(k_pk_add_u16,  "v_pk_add_u16 %0, %0, %1")
 KERNEL32(k_pk_ashr_i16, "v_pk_ashrrev_i16 %0, 3, %0")
 KERNEL32(k_mov_dpp,     "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 KERNEL32(k_fma_f32,     "v_fma_f32 %0, %0, %1, %2")
+KERNEL32(k_or_b32,      "v_or_b32 %0, %0, %1")
+KERNEL32(k_lshlrev_b32, "v_lshlrev_b32 %0, 1, %0")
+KERNEL32(k_min_i32,     "v_min_i32 %0, %0, %1")
+KERNEL32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+KERNEL32(k_mul_i32_i24, "v_mul_i32_i24 %0, %0, %1")
+KERNEL32(k_bitop3,      "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+KERNEL32(k_perm_b32,    "v_perm_b32 %0, %0, %1, %2")
+KERNEL32(k_med3_i32,    "v_med3_i32 %0, %0, %1, %2")
+KERNEL32(k_xor_inline,  "v_xor_b32 %0, -2, %0")
+KERNEL32(k_add_e64,     "v_add_u32_e64 %0, %0, %1")
+KERNEL32(k_fmac_f32,    "v_fmac_f32 %0, %1, %2")
+KERNEL32(k_pk_fma_f32x, "v_add_f32 %0, %0, %1")
 // carry chain pair: lo += b (carry to vcc), hi(%2 reused) += 0 + carry.
 // two wait states are owed between the VCC write and the VCC read on gfx940+,
 // filled here with the two ops of the *other* half of the pair pattern.
@@ -80,6 +92,10 @@ KERNEL64(k_ashr_i64,    "v_ashrrev_i64 %0, 3, %0")
 KERNEL64(k_lshr_b64,    "v_lshrrev_b64 %0, 3, %0")
 KERNEL64(k_lshl_add_u64,"v_lshl_add_u64 %0, %0, 0, %1")
 KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %2, %2, %0")
+KERNEL64(k_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %2, %2, %0")
+KERNEL64(k_mad_i64_sgpr,"v_mad_i64_i32 %0, s[10:11], %2, %2, %0")
+KERNEL64(k_pk_add_f32,  "v_pk_add_f32 %0, %0, %1")
+KERNEL64(k_mov_b64,     "v_mov_b64 %0, %1")
 KERNEL64(k_add_f64,     "v_add_f64 %0, %0, %1")
 KERNEL64(k_fma_f64,     "v_fma_f64 %0, %0, %1, %1")
 
@@ -100,10 +116,10 @@ int main()
 		C(k_ashr_i32, 1), C(k_alignbit, 1), C(k_xad_u32, 1), C(k_add3_u32, 1),
 		C(k_bfe_i32, 1), C(k_and_or, 1), C(k_lshl_add, 1), C(k_mul_lo, 1),
 		C(k_mad_u24, 1), C(k_cndmask, 1), C(k_cmp_gt, 2), C(k_pk_add_u16, 1),
-		C(k_pk_ashr_i16, 1), C(k_mov_dpp, 1), C(k_fma_f32, 1),
+		C(k_pk_ashr_i16, 1), C(k_mov_dpp, 1), C(k_fma_f32, 1), C(k_or_b32, 1), C(k_lshlrev_b32, 1), C(k_min_i32, 1), C(k_mul_u32_u24, 1), C(k_mul_i32_i24, 1), C(k_bitop3, 1), C(k_perm_b32, 1), C(k_med3_i32, 1), C(k_xor_inline, 1), C(k_add_e64, 1), C(k_fmac_f32, 1), C(k_pk_fma_f32x, 1),
 		C(k_addco_pair, 2), C(k_addco_only, 1), C(k_addc_only, 1), C(k_subb_e64, 1),
 		C(k_ashr_i64, 1), C(k_lshr_b64, 1), C(k_lshl_add_u64, 1),
-		C(k_mad_u64_u32, 1), C(k_add_f64, 1), C(k_fma_f64, 1),
+		C(k_mad_u64_u32, 1), C(k_mad_i64_i32, 1), C(k_mad_i64_sgpr, 1), C(k_pk_add_f32, 1), C(k_mov_b64, 1), C(k_add_f64, 1), C(k_fma_f64, 1),
 	};
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
