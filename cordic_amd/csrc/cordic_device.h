@@ -54,6 +54,8 @@ struct CoreParams {
 	uint32_t round_bit;	// 1 if WW > OW+1 (convergent rounding) else 0
 	int64_t	round_base;	// 2^(r-1) - 1 if rounding else 0
 	int32_t	wrap;		// generic kernel: wrap to WW bits explicitly
+	int32_t	r_lj;		// left-justified form: r + LJ
+	int64_t	round_base_lj;	// round_base << LJ
 	int32_t	x0, y0;		// constant-vector feeds (sign extended)
 	uint32_t phase0, fcw;	// NCO, left-justified
 	uint64_t index0;	// NCO: global index of sample 0
@@ -124,8 +126,15 @@ template <int K> __device__ __forceinline__ int32_t asr_narrow(int64_t v)
 
 // Container tags.  Both keep x, y and the phase in 64-bit register pairs (the
 // mad needs a 64-bit addend); Narrow32 only maintains the low words.
-struct Narrow32 { static constexpr bool wide = false; };
-struct Wide64   { static constexpr bool wide = true; };
+struct Narrow32 { static constexpr bool wide = false; static constexpr int lj = 0; };
+struct Wide64   { static constexpr bool wide = true;  static constexpr int lj = 0; };
+// Wide64 with x/y carried LEFT-justified by LJ bits after the first 31-LJ
+// stages (see rot_stage_lj); LJ = 64-WW makes the 64-bit wrap the WW-bit wrap.
+template <int LJ> struct WideLJ {
+	static constexpr bool wide = true;
+	static constexpr int lj = LJ;
+	static constexpr int ngen = 31 - LJ;	// stages with k < 32-LJ
+};
 
 // ------------------------------------------------------- rotator: p2r stage
 
@@ -218,6 +227,59 @@ template <typename C, int NLIVE, int NGEN, int I = 0> struct PolChain {
 	}
 };
 
+// ------------------------------------- rotator: left-justified wide stage
+//
+// For WW in 33..35 most of the cost of a Wide64 stage is not the rotation but
+// getting (y>>>k) into 32 bits (v_alignbit, VOP3) and the +/-1 multipliers.
+// Carry x and y shifted LEFT by LJ (x~ = x << LJ) and the phase as
+// p~ = sext(P) << 31.  Then
+//   * (y >>> k) for k >= 32-LJ is an arithmetic shift of the HIGH word of y~
+//     by k-(32-LJ): one full-rate v_ashrrev_i32, no v_alignbit;
+//   * the multipliers are s~ = +/-2^LJ, read straight off the top bits of the
+//     high word of p~ (= P>>1, whose two top bits both hold the sign):
+//         s~ = (hi(p~) & -2^(LJ+1)) | 2^LJ ,   -s~ = s~ ^ -2^(LJ+1);
+//   * x~' = x~ + (-s~)*(y>>>k),  y~' = y~ + s~*(x>>>k),
+//     p~' = p~ + (-s~)*(a << (31-LJ))      -- three v_mad_i64_i32.
+// The residual phase never leaves [-2^29, 2^29] (after the octant fold
+// |P| <= 2^29 and every stage moves it towards zero by a <= 2^28.3), so
+// sext(P) << 31 cannot wrap and bit 63 == bit 62 always.
+template <int LJ> struct LjConst {
+	static constexpr uint32_t bit = 1u << LJ;
+	static constexpr uint32_t mask = ~((bit << 1) - 1u);
+	static constexpr int first = 32 - LJ;	// first k served by this form
+};
+
+template <int LJ, int K>
+__device__ __forceinline__ void rot_stage_lj(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a_scaled)
+{
+	const uint32_t ph = (uint32_t)((uint64_t)p >> 32);
+	const uint32_t su = (ph & LjConst<LJ>::mask) | LjConst<LJ>::bit;
+	const int32_t s = (int32_t)su;				// +/- 2^LJ
+	const int32_t ns = (int32_t)(su ^ LjConst<LJ>::mask);	// -s
+	constexpr int sh = (K - LjConst<LJ>::first > 31) ? 31
+						: K - LjConst<LJ>::first;
+	const int32_t sy = (int32_t)((uint64_t)y >> 32) >> sh;
+	const int32_t sx = (int32_t)((uint64_t)x >> 32) >> sh;
+	op_mad(x, sy, ns);
+	op_mad(y, sx, s);
+	op_mad_s(p, a_scaled, ns);
+}
+
+template <int LJ, int NLIVE, int I> struct RotChainLJ {
+	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp)
+	{
+		if constexpr (I < NLIVE) {
+			const uint32_t a = kp.angle[I] << (31 - LJ);
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				rot_stage_lj<LJ, I + 1>(x[v], y[v], p[v], a);
+			RotChainLJ<LJ, NLIVE, I + 1>::run(x, y, p, kp);
+		}
+	}
+};
+
 // ------------------------------------------------------------- pre / post
 
 // rtl/cordic.v:131-188 on a left-justified phase: q = quadrant of
@@ -264,6 +326,16 @@ __device__ __forceinline__ int32_t round_to_ow(T v, const CoreParams &kp)
 	const U b = ((U)v >> kp.r) & (U)kp.round_bit;
 	const T w = (T)((U)v + (U)(T)kp.round_base + b);
 	return (int32_t)(w >> kp.r);
+}
+
+// the same on a value carried left-justified by LJ bits
+template <int LJ>
+__device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &kp)
+{
+	const uint64_t b = ((uint64_t)v >> kp.r_lj) & (uint64_t)kp.round_bit;
+	const int64_t w = (int64_t)((uint64_t)v + (uint64_t)kp.round_base_lj
+				+ (b << LJ));
+	return (int32_t)(w >> kp.r_lj);
 }
 
 // ------------------------------------------------------- memory accessors
@@ -331,13 +403,31 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			p[v] = (int64_t)fp;
 		}
 
-		RotChain<C, NLIVE, NGEN>::run(x, y, p, kp);
-
 		i32x4 rx, ry;
+		if constexpr (C::lj == 0) {
+			RotChain<C, NLIVE, NGEN>::run(x, y, p, kp);
 #pragma unroll
-		for (int v = 0; v < kVec; v++) {
-			rx[v] = round_to_ow<T>((T)x[v], kp);
-			ry[v] = round_to_ow<T>((T)y[v], kp);
+			for (int v = 0; v < kVec; v++) {
+				rx[v] = round_to_ow<T>((T)x[v], kp);
+				ry[v] = round_to_ow<T>((T)y[v], kp);
+			}
+		} else {
+			constexpr int LJ = C::lj;
+			constexpr int G = (NGEN < NLIVE) ? NGEN : NLIVE;
+			RotChain<Wide64, G, G>::run(x, y, p, kp);
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				x[v] = (int64_t)((uint64_t)x[v] << LJ);
+				y[v] = (int64_t)((uint64_t)y[v] << LJ);
+				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)(uint32_t)p[v]
+						<< 31);
+			}
+			RotChainLJ<LJ, NLIVE, G>::run(x, y, p, kp);
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				rx[v] = round_to_ow_lj<LJ>(x[v], kp);
+				ry[v] = round_to_ow_lj<LJ>(y[v], kp);
+			}
 		}
 		// outputs are written once and never re-read here: stream them
 		__builtin_nontemporal_store(rx, &ox[g]);

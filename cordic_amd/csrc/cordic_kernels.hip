@@ -212,6 +212,10 @@ CoreParams make_params(const cordic_config &c)
 	kp.round_bit = rounding ? 1u : 0u;
 	kp.round_base = rounding ? (((int64_t)1 << (kp.r - 1)) - 1) : 0;
 	kp.wrap = c.needs_wrap && c.ww < 64;
+	// left-justified wide form (WW 33..35): LJ = 29 for WW 35, else 30
+	const int lj = (c.ww == 35) ? 29 : 30;
+	kp.r_lj = kp.r + lj;
+	kp.round_base_lj = (int64_t)((uint64_t)kp.round_base << lj);
 	return kp;
 }
 
@@ -259,6 +263,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			const int ngen = general_stages_for(cfg.ww);
 			if (cfg.ww <= 32)
 				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);
+			else if (cfg.ww == 35 && !(cfg.flags & CORDIC_FLAG_NO_LJ))
+				done = launch_rot_lj29(FEED, cfg.nlive, grid, st, kp, j);
+			else if (cfg.ww < 35 && !(cfg.flags & CORDIC_FLAG_NO_LJ))
+				done = launch_rot_lj30(FEED, cfg.nlive, grid, st, kp, j);
 			else if (ngen == 2)
 				done = launch_rot_wide2(FEED, cfg.nlive, grid, st, kp, j);
 			else if (ngen == 8)

@@ -26,7 +26,9 @@ constexpr int kAllGeneral = 1 << 20;
 		size_t n)
 
 CORDIC_ROT_LAUNCHER(launch_rot_narrow);		// WW <= 32
-CORDIC_ROT_LAUNCHER(launch_rot_wide2);		// WW <= 35
+CORDIC_ROT_LAUNCHER(launch_rot_lj29);		// WW == 35
+CORDIC_ROT_LAUNCHER(launch_rot_lj30);		// WW == 33, 34
+CORDIC_ROT_LAUNCHER(launch_rot_wide2);		// WW <= 35 (kept for A/B)
 CORDIC_ROT_LAUNCHER(launch_rot_wide8);		// WW <= 41
 CORDIC_ROT_LAUNCHER(launch_rot_wideall);	// WW <= 64
 CORDIC_POL_LAUNCHER(launch_pol_narrow);

@@ -56,6 +56,14 @@ def assert_r2p(cfg, ocfg, x, y, **kw):
 # ------------------------------------------------------- BASELINE configs
 
 BASELINE_P2R = {
+    # WW = 33 / 34 / 35 take the left-justified wide kernels (LJ 30 / 30 / 29)
+    "ww33": (ca.P2R, 30, 30, 2, 32, 16),
+    "ww34": (ca.P2R, 31, 31, 2, 30, 20),
+    "ww34_seq": (ca.SP2R, 31, 28, 2, 32, 24),
+    "ww35_30st": (ca.P2R, 32, 32, 2, 32, 30),
+    "ww36": (ca.P2R, 32, 32, 3, 32, 16),
+    "ww41": (ca.P2R, 32, 20, 8, 32, 24),
+    "ww48": (ca.P2R, 32, 32, 15, 32, 30),
     "cfg1": (ca.P2R, 16, 16, 2, 16, 16),
     "cfg2": (ca.P2R, 32, 32, 2, 32, 16),
     "cfg4": (ca.P2R, 32, 32, 2, 32, 24),
@@ -194,6 +202,22 @@ def test_tiny_cores_wrap_like_the_registers():
             else:
                 assert_r2p(cfg, ocfg, x, y)
     assert hit >= 3
+
+
+def test_left_justified_kernel_equals_right_justified_kernel():
+    """WW 33..35: the LJ kernels against the plain 64-bit unrolled kernel."""
+    for args in [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
+                 (ca.SP2R, 32, 32, 2, 32, 16), (ca.P2R, 30, 30, 2, 32, 16),
+                 (ca.P2R, 31, 31, 2, 30, 20)]:
+        cfg, ocfg = both(*args)
+        rj = cfg.with_flags(ca.FLAG_NO_LJ)
+        rng = np.random.RandomState(18)
+        x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, 50001)
+        a = gpu_p2r(cfg, x, y, ph)
+        b = gpu_p2r(rj, x, y, ph)
+        c = O.rotate(ocfg, x, y, ph)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
 def test_generic_kernel_equals_unrolled_kernel():
