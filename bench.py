@@ -135,6 +135,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true",
                     help="also time gathering the outputs on rank 0 (RCCL)")
+    ap.add_argument("--input", default="ramp", choices=["ramp", "random"],
+                    help="ramp = BASELINE.json's deterministic inputs; random "
+                    "= uniformly random words (worst-case switching activity: "
+                    "the chip clocks lower, MI355X_MICROARCH.md DVFS)")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
     args = ap.parse_args()
@@ -169,6 +173,9 @@ def main():
     if w["kind"] == "p2r":
         phase = torch.empty(n, dtype=torch.int32, device=dev)
         ca.fill_phase_ramp(phase, index0, w["shift"])
+        if args.input == "random":
+            gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+            phase.random_(-2**31, 2**31 - 1, generator=gen)
 
         def step():
             ca.p2r_const(cfg, x0, y0, phase, a, b)
@@ -176,6 +183,10 @@ def main():
         xin = torch.empty(n, dtype=torch.int32, device=dev)
         yin = torch.empty(n, dtype=torch.int32, device=dev)
         ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
+        if args.input == "random":
+            gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+            xin.random_(-2**(iw - 1), 2**(iw - 1) - 1, generator=gen)
+            yin.random_(-2**(iw - 1), 2**(iw - 1) - 1, generator=gen)
 
         def step():
             ca.r2p(cfg, xin, yin, a, b)
@@ -286,6 +297,7 @@ def main():
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else "unrolled",
+                "input": args.input,
                 "parallelism": "shard%d" % world,
             },
             "roofline": {

@@ -249,14 +249,39 @@ template <int LJ> struct LjConst {
 	static constexpr int first = 32 - LJ;	// first k served by this form
 };
 
+// (a & c) | b  and  (a & c) ^ b  as one v_bitop3_b32 each (truth tables with
+// src0 = 0xF0, src1 = 0xCC, src2 = 0xAA): two instructions at 3.3 cycles
+// instead of and + or + xor.  Constants live in VGPRs (VOP3 takes no literal
+// and at most one SGPR on gfx950).
+__device__ __forceinline__ uint32_t op_and_or(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t d;
+	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xec" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+__device__ __forceinline__ uint32_t op_and_xor(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t d;
+	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+// a loop-invariant constant pinned in a VGPR
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t v)
+{
+	uint32_t d;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "s"(v));
+	return d;
+}
+
+struct LjRegs { uint32_t mask, bit, maskbit; };	// VGPR-resident constants
+
 template <int LJ, int K>
 __device__ __forceinline__ void rot_stage_lj(int64_t &x, int64_t &y, int64_t &p,
-		uint32_t a_scaled)
+		uint32_t a_scaled, const LjRegs &c)
 {
 	const uint32_t ph = (uint32_t)((uint64_t)p >> 32);
-	const uint32_t su = (ph & LjConst<LJ>::mask) | LjConst<LJ>::bit;
-	const int32_t s = (int32_t)su;				// +/- 2^LJ
-	const int32_t ns = (int32_t)(su ^ LjConst<LJ>::mask);	// -s
+	const int32_t s = (int32_t)op_and_or(ph, c.bit, c.mask);	// +/- 2^LJ
+	const int32_t ns = (int32_t)op_and_xor(ph, c.maskbit, c.mask);	// -s
 	constexpr int sh = (K - LjConst<LJ>::first > 31) ? 31
 						: K - LjConst<LJ>::first;
 	const int32_t sy = (int32_t)((uint64_t)y >> 32) >> sh;
@@ -268,14 +293,15 @@ __device__ __forceinline__ void rot_stage_lj(int64_t &x, int64_t &y, int64_t &p,
 
 template <int LJ, int NLIVE, int I> struct RotChainLJ {
 	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
-			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp)
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp,
+			const LjRegs &c)
 	{
 		if constexpr (I < NLIVE) {
 			const uint32_t a = kp.angle[I] << (31 - LJ);
 #pragma unroll
 			for (int v = 0; v < kVec; v++)
-				rot_stage_lj<LJ, I + 1>(x[v], y[v], p[v], a);
-			RotChainLJ<LJ, NLIVE, I + 1>::run(x, y, p, kp);
+				rot_stage_lj<LJ, I + 1>(x[v], y[v], p[v], a, c);
+			RotChainLJ<LJ, NLIVE, I + 1>::run(x, y, p, kp, c);
 		}
 	}
 };
@@ -329,6 +355,17 @@ __device__ __forceinline__ int32_t round_to_ow(T v, const CoreParams &kp)
 }
 
 // the same on a value carried left-justified by LJ bits
+// r + LJ == 32 (e.g. WW 35 -> OW 32): the rounded result is the high word;
+// the rounding increment (base + b) * 2^LJ is one more mad.
+template <int LJ>
+__device__ __forceinline__ int32_t round_to_ow_lj32(int64_t v, const CoreParams &kp)
+{
+	const uint32_t b = (uint32_t)((uint64_t)v >> 32) & kp.round_bit;
+	const int32_t t = (int32_t)(b + (uint32_t)kp.round_base);
+	op_mad_s(v, 1u << LJ, t);
+	return (int32_t)((uint64_t)v >> 32);
+}
+
 template <int LJ>
 __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &kp)
 {
@@ -356,10 +393,62 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 {
 	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
 	using U = typename std::make_unsigned<T>::type;
-	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-			g += (size_t)gridDim.x * kBlock) {
+	using Z = typename std::conditional<C::wide, int64_t, uint32_t>::type;
+	constexpr bool kConstXY = (FEED != Feed::PhaseArray_XYArray);
+
+	// Constant-vector feeds: the octant fold (rtl/cordic.v:131-188) can only
+	// produce four vectors, rot90^q(e_x, e_y).  Stage them in LDS once per
+	// block; per sample the fold is then one ds_read_b128 indexed by the
+	// quadrant instead of ~20 VALU selects/negations.
+	__shared__ int64_t fold_tab[4][2];
+	if constexpr (kConstXY) {
+		if (threadIdx.x < 4) {
+			const T ex = (T)((U)(T)kp.x0 << kp.in_shl);
+			const T ey = (T)((U)(T)kp.y0 << kp.in_shl);
+			T fx, fy;
+			uint32_t fp;
+			fold_octant<T>(ex, ey, (uint32_t)threadIdx.x << 30, fx, fy, fp);
+			fold_tab[threadIdx.x][0] = (int64_t)(Z)fx;
+			fold_tab[threadIdx.x][1] = (int64_t)(Z)fy;
+		}
+		__syncthreads();
+	}
+
+	LjRegs ljc{};
+	if constexpr (C::lj != 0) {
+		ljc.mask = vgpr_const(LjConst<C::lj>::mask);
+		ljc.bit = vgpr_const(LjConst<C::lj>::bit);
+		ljc.maskbit = vgpr_const(LjConst<C::lj>::mask | LjConst<C::lj>::bit);
+	}
+
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	// software prefetch: the loads of pass i+1 are issued before the ~750
+	// VALU instructions of pass i, so no wave ever parks on HBM latency
+	u32x4 nph{};
+	i32x4 nx{}, ny{};
+	if (g < nvec) {
+		if constexpr (FEED != Feed::Nco_ConstXY)
+			nph = phin[g];
+		if constexpr (!kConstXY) {
+			nx = xin[g];
+			ny = yin[g];
+		}
+	}
+	for (; g < nvec; g += stride) {
+		const u32x4 tph = nph;
+		const i32x4 tx = nx, ty = ny;
+		const size_t gn = g + stride;
+		if (gn < nvec) {
+			if constexpr (FEED != Feed::Nco_ConstXY)
+				nph = phin[gn];
+			if constexpr (!kConstXY) {
+				nx = xin[gn];
+				ny = yin[gn];
+			}
+		}
+
 		uint32_t P[kVec];
-		int32_t ix[kVec], iy[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
 			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
 			P[0] = kp.phase0 + s0 * kp.fcw;
@@ -367,40 +456,35 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			for (int v = 1; v < kVec; v++)
 				P[v] = P[v - 1] + kp.fcw;
 		} else {
-			const u32x4 t = phin[g];
 #pragma unroll
 			for (int v = 0; v < kVec; v++)
-				P[v] = t[v] << kp.pw_shl;
-		}
-		if constexpr (FEED == Feed::PhaseArray_XYArray) {
-			const i32x4 tx = xin[g];
-			const i32x4 ty = yin[g];
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				ix[v] = sext32(tx[v], kp.iw);
-				iy[v] = sext32(ty[v], kp.iw);
-			}
-		} else {
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				ix[v] = kp.x0;
-				iy[v] = kp.y0;
-			}
+				P[v] = tph[v] << kp.pw_shl;
 		}
 
 		int64_t x[kVec], y[kVec], p[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
-			const T ex = (T)((U)(T)ix[v] << kp.in_shl);
-			const T ey = (T)((U)(T)iy[v] << kp.in_shl);
-			T fx, fy;
-			uint32_t fp;
-			fold_octant<T>(ex, ey, P[v], fx, fy, fp);
-			x[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
-					uint32_t>::type)fx;
-			y[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
-					uint32_t>::type)fy;
-			p[v] = (int64_t)fp;
+			if constexpr (kConstXY) {
+				// q = quadrant of (P + 45 deg); p = P - q * 90 deg
+				const uint32_t pb = P[v] + 0x20000000u;
+				const uint32_t q16 = ((uint32_t)((int32_t)pb >> 26)) & 0x30u;
+				const int64_t *e = reinterpret_cast<const int64_t *>(
+					reinterpret_cast<const char *>(&fold_tab[0][0]) + q16);
+				x[v] = e[0];
+				y[v] = e[1];
+				p[v] = (int64_t)((pb & 0x3fffffffu) - 0x20000000u);
+			} else {
+				const int32_t ix = sext32(tx[v], kp.iw);
+				const int32_t iy = sext32(ty[v], kp.iw);
+				const T ex = (T)((U)(T)ix << kp.in_shl);
+				const T ey = (T)((U)(T)iy << kp.in_shl);
+				T fx, fy;
+				uint32_t fp;
+				fold_octant<T>(ex, ey, P[v], fx, fy, fp);
+				x[v] = (int64_t)(Z)fx;
+				y[v] = (int64_t)(Z)fy;
+				p[v] = (int64_t)fp;
+			}
 		}
 
 		i32x4 rx, ry;
@@ -422,11 +506,19 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)(uint32_t)p[v]
 						<< 31);
 			}
-			RotChainLJ<LJ, NLIVE, G>::run(x, y, p, kp);
+			RotChainLJ<LJ, NLIVE, G>::run(x, y, p, kp, ljc);
+			if (kp.r_lj == 32) {
 #pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				rx[v] = round_to_ow_lj<LJ>(x[v], kp);
-				ry[v] = round_to_ow_lj<LJ>(y[v], kp);
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj32<LJ>(x[v], kp);
+					ry[v] = round_to_ow_lj32<LJ>(y[v], kp);
+				}
+			} else {
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj<LJ>(x[v], kp);
+					ry[v] = round_to_ow_lj<LJ>(y[v], kp);
+				}
 			}
 		}
 		// outputs are written once and never re-read here: stream them
@@ -437,6 +529,26 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 
 // ------------------------------------------------------- unrolled converter
 
+// rtl/topolar.v:122-152 on sign masks (no compares / selects).  With
+// mx = -1 where x < 0 (else 0), my likewise, ax = |e_x|, ay = |e_y| as two's
+// complement negations:  x0 = ax + ay;  y0 = ay - ax where the signs agree,
+// ax - ay otherwise;  p0 = {1,7,3,5} * 2^29 for {++,+-,-+,--}, i.e. bit 31 =
+// (y < 0), bit 30 = (x < 0) ^ (y < 0), bit 29 = 1.
+template <typename T>
+__device__ __forceinline__ void fold_quadrant_masks(T ex, T ey, int32_t ix,
+		int32_t iy, T &x, T &y, uint32_t &p)
+{
+	using U = typename std::make_unsigned<T>::type;
+	const int32_t mx = ix >> 31, my = iy >> 31;
+	const U ax = ((U)ex ^ (U)(T)mx) - (U)(T)mx;
+	const U ay = ((U)ey ^ (U)(T)my) - (U)(T)my;
+	const int32_t mxy = mx ^ my;
+	x = (T)(ax + ay);
+	y = (T)((((ay - ax) ^ (U)(T)mxy)) - (U)(T)mxy);
+	p = ((uint32_t)my & 0x80000000u) | ((uint32_t)mxy & 0x40000000u)
+		| 0x20000000u;
+}
+
 template <typename C, int NLIVE, int NGEN>
 __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
@@ -444,10 +556,22 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 {
 	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
 	using U = typename std::make_unsigned<T>::type;
-	for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-			g += (size_t)gridDim.x * kBlock) {
-		const i32x4 tx = xin[g];
-		const i32x4 ty = yin[g];
+	using Z = typename std::conditional<C::wide, int64_t, uint32_t>::type;
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	// software prefetch (see rotator_unrolled)
+	i32x4 nx{}, ny{};
+	if (g < nvec) {
+		nx = xin[g];
+		ny = yin[g];
+	}
+	for (; g < nvec; g += stride) {
+		const i32x4 tx = nx, ty = ny;
+		const size_t gn = g + stride;
+		if (gn < nvec) {
+			nx = xin[gn];
+			ny = yin[gn];
+		}
 		int64_t x[kVec], y[kVec], p[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
@@ -457,11 +581,9 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			const T ey = (T)((U)(T)iy << kp.in_shl);
 			T fx, fy;
 			uint32_t fp;
-			fold_quadrant<T>(ex, ey, ix < 0, iy < 0, fx, fy, fp);
-			x[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
-					uint32_t>::type)fx;
-			y[v] = (int64_t)(typename std::conditional<C::wide, int64_t,
-					uint32_t>::type)fy;
+			fold_quadrant_masks<T>(ex, ey, ix, iy, fx, fy, fp);
+			x[v] = (int64_t)(Z)fx;
+			y[v] = (int64_t)(Z)fy;
 			p[v] = (int64_t)fp;
 		}
 
