@@ -139,6 +139,9 @@ def main():
                     help="ramp = BASELINE.json's deterministic inputs; random "
                     "= uniformly random words (worst-case switching activity: "
                     "the chip clocks lower, MI355X_MICROARCH.md DVFS)")
+    ap.add_argument("--no-seed", action="store_true",
+                    help="constant-vector feeds: full 16-stage recurrence per "
+                    "sample instead of the table-seeded kernel")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
     args = ap.parse_args()
@@ -163,6 +166,8 @@ def main():
     cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
     if args.generic:
         cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+    if args.no_seed:
+        cfg = cfg.with_flags(ca.FLAG_NO_SEED)
     n = 1 << args.log2_samples
     index0 = rank * n                   # shard by global sample index
     x0, y0 = (1 << (iw - 1)) - 1, 0
@@ -177,8 +182,10 @@ def main():
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
             phase.random_(-2**31, 2**31 - 1, generator=gen)
 
+        plan = ca.Plan(cfg)
+
         def step():
-            ca.p2r_const(cfg, x0, y0, phase, a, b)
+            plan.p2r_const(x0, y0, phase, a, b)
     elif w["kind"] == "r2p":
         xin = torch.empty(n, dtype=torch.int32, device=dev)
         yin = torch.empty(n, dtype=torch.int32, device=dev)
@@ -191,8 +198,10 @@ def main():
         def step():
             ca.r2p(cfg, xin, yin, a, b)
     else:
+        plan = ca.Plan(cfg)
+
         def step():
-            ca.nco(cfg, n, 0, 0x01234567, index0, x0, y0, a, b)
+            plan.nco(n, 0, 0x01234567, index0, x0, y0, a, b)
 
     def barrier():
         if dist is not None:
@@ -296,7 +305,9 @@ def main():
                 "samples_per_gpu": n,
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
-                "kernel": "generic" if args.generic else "unrolled",
+                "kernel": "generic" if args.generic else (
+                    "unrolled" if (args.no_seed or w["kind"] == "r2p")
+                    else "seeded(9)+unrolled"),
                 "input": args.input,
                 "parallelism": "shard%d" % world,
             },

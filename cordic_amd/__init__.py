@@ -14,8 +14,8 @@ Reference interfaces mirrored (see include/cordic_amd.h for file:line):
 """
 from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
-    FLAG_FORCE_GENERIC, FLAG_LDS_TABLE, FLAG_NO_LJ,
-    Config, CordicError,
+    FLAG_FORCE_GENERIC, FLAG_LDS_TABLE, FLAG_NO_LJ, FLAG_NO_SEED,
+    Config, CordicError, Plan, seed_table,
     lib, lib_path,
     p2r, p2r_const, nco, r2p,
     p2r_host, r2p_host,
@@ -23,7 +23,8 @@ from ._native import (  # noqa: F401
 )
 
 __all__ = [
-    "P2R", "R2P", "SP2R", "SR2P", "Config", "CordicError", "lib", "lib_path",
+    "P2R", "R2P", "SP2R", "SR2P", "Config", "CordicError", "Plan",
+    "seed_table", "lib", "lib_path",
     "p2r", "p2r_const", "nco", "r2p", "p2r_host", "r2p_host",
     "fill_phase_ramp", "fill_iq_ramp", "digest_u32",
 ]

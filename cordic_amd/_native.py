@@ -7,12 +7,15 @@ MAX_STAGES = 64
 FLAG_FORCE_GENERIC = 0x1
 FLAG_LDS_TABLE = 0x2
 FLAG_NO_LJ = 0x4
+FLAG_NO_SEED = 0x8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcordic_amd.so")
+    # CORDIC_AMD_LIB: an alternative build of the same library (A/B work)
+    return os.environ.get("CORDIC_AMD_LIB",
+                          os.path.join(_HERE, "libcordic_amd.so"))
 
 
 class CordicError(RuntimeError):
@@ -73,6 +76,18 @@ ABI = {
                              C.c_void_p, C.c_void_p]),
     "cordic_r2p": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cordic_plan_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
+    "cordic_plan_destroy": (None, [C.c_void_p]),
+    "cordic_plan_config": (_cfgp, [C.c_void_p]),
+    "cordic_plan_seed_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
+    "cordic_plan_p2r_const": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "cordic_plan_nco": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32,
+                                  C.c_uint32, C.c_uint64, C.c_int32,
+                                  C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
     "cordic_p2r_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, C.c_int,
                                   _u32p, _i32p, _i32p]),
     "cordic_r2p_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, _i32p,
@@ -173,6 +188,58 @@ class Config:
     @property
     def ref(self):
         return C.byref(self.c)
+
+
+class Plan:
+    """cordic_plan: a generated core bound to the current device."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(lib().cordic_plan_create(cfg.ref, C.byref(h)),
+               "cordic_plan_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cordic_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def seed_info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().cordic_plan_seed_info(self._h, C.byref(a), C.byref(b),
+                                           C.byref(c)),
+               "cordic_plan_seed_info")
+        return dict(stages=a.value, nleaves=b.value, nbuckets=c.value)
+
+    def p2r_const(self, x0, y0, phase, ox, oy, n=None, stream=None):
+        n = phase.numel() if n is None else n
+        _check(lib().cordic_plan_p2r_const(self._h, n, x0, y0, _ptr(phase),
+                                           _ptr(ox), _ptr(oy),
+                                           _stream(stream)),
+               "cordic_plan_p2r_const")
+
+    def nco(self, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
+        _check(lib().cordic_plan_nco(self._h, n, phase0 & 0xffffffff,
+                                     fcw & 0xffffffff, index0, x0, y0,
+                                     _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_plan_nco")
+
+
+def seed_table(cfg):
+    """Host-side seed table words of a core (numpy uint32) or None."""
+    import numpy as np
+    cap = 4 + 4096 * 6
+    buf = np.zeros(cap, dtype=np.uint32)
+    n = lib().cordic_seed_table(cfg.ref, buf.ctypes.data_as(_u32p), cap)
+    return buf[:n].copy() if n else None
 
 
 def _ptr(t):

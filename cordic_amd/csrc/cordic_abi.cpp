@@ -4,11 +4,120 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
+#include <new>
+#include <vector>
 
 #include "cordic_amd.h"
 #include "cordic_internal.h"
 
 using namespace cordic_amd;
+
+// ------------------------------------------------------------------- plans
+struct cordic_plan {
+	cordic_config cfg;
+	uint32_t *d_table = nullptr;	// device copy of the seed table
+	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
+};
+
+int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
+{
+	if (!cfg || !plan)
+		return CORDIC_ERR_ARGS;
+	if (cfg->mode < CORDIC_P2R || cfg->mode > CORDIC_SR2P)
+		return CORDIC_ERR_MODE;
+	cordic_plan *p = new (std::nothrow) cordic_plan;
+	if (!p)
+		return CORDIC_ERR_ARGS;
+	p->cfg = *cfg;
+	std::vector<uint32_t> words(4 + 4096 * 4 + 4096 * 2);
+	const size_t nw = build_seed_table(*cfg, CORDIC_SEED_STAGES, words.data(), words.size());
+	if (nw) {
+		if (hipMalloc((void **)&p->d_table, nw * 4) != hipSuccess ||
+		    hipMemcpy(p->d_table, words.data(), nw * 4,
+				hipMemcpyHostToDevice) != hipSuccess) {
+			if (p->d_table) (void)hipFree(p->d_table);
+			delete p;
+			return CORDIC_ERR_DEVICE;
+		}
+		p->m = (int)words[0];
+		p->S = (int)words[1];
+		p->nbuckets = (int)words[2];
+		p->nleaves = (int)words[3];
+	}
+	*plan = p;
+	return CORDIC_OK;
+}
+
+void cordic_plan_destroy(cordic_plan *plan)
+{
+	if (!plan)
+		return;
+	if (plan->d_table)
+		(void)hipFree(plan->d_table);
+	delete plan;
+}
+
+const cordic_config *cordic_plan_config(const cordic_plan *plan)
+{
+	return plan ? &plan->cfg : nullptr;
+}
+
+int cordic_plan_seed_info(const cordic_plan *plan, int32_t *stages,
+		int32_t *nleaves, int32_t *nbuckets)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	if (stages) *stages = plan->m;
+	if (nleaves) *nleaves = plan->nleaves;
+	if (nbuckets) *nbuckets = plan->nbuckets;
+	return CORDIC_OK;
+}
+
+static void attach_seed(const cordic_plan *plan, RotatorJob &j)
+{
+	j.seed_table = plan->d_table;
+	j.seed_m = plan->m;
+	j.seed_S = plan->S;
+	j.seed_nbuckets = plan->nbuckets;
+	j.seed_nleaves = plan->nleaves;
+}
+
+int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,
+		int32_t yval, const uint32_t *d_phase, int32_t *d_oxval,
+		int32_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x0 = xval; j.y0 = yval; j.phase = d_phase;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	attach_seed(plan, j);
+	return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+}
+
+int cordic_plan_nco(const cordic_plan *plan, size_t n, uint32_t phase0,
+		uint32_t fcw, uint64_t index0, int32_t xval, int32_t yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
+	j.index0 = index0; j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	attach_seed(plan, j);
+	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+}
+
+size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
+{
+	if (!cfg)
+		return 0;
+	if (!buf || cap_words == 0) {
+		std::vector<uint32_t> tmp(4 + 4096 * 4 + 4096 * 2);
+		return build_seed_table(*cfg, CORDIC_SEED_STAGES, tmp.data(), tmp.size());
+	}
+	return build_seed_table(*cfg, CORDIC_SEED_STAGES, buf, cap_words);
+}
 
 // Host-buffer conveniences.  Every HIP call is checked; buffers are released
 // on all paths.

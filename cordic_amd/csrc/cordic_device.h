@@ -41,6 +41,8 @@ namespace dev {
 constexpr int kBlock = 256;		// 4 waves: one per SIMD
 constexpr int kVec = 4;			// samples per lane per pass (16 B)
 constexpr int kTile = kBlock * kVec;	// samples per block per pass
+constexpr int kSeedBlock = CORDIC_SEED_BLOCK;	// waves of a block share one table
+constexpr int kSeedStages = CORDIC_SEED_STAGES;	// M: stages replaced by the table
 
 // Kernel-argument block: wave-uniform, so hipcc keeps it in SGPRs (s_load).
 struct CoreParams {
@@ -380,6 +382,26 @@ __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &k
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
+// Output stores.  Outputs are written once and never re-read by the engine.
+// Measured on MI355X: the non-temporal form is as good or better for the
+// VALU-bound kernels (full recurrence), while the table-seeded kernel, which
+// runs close to HBM speed, is faster with plain stores (cfg2: 439 vs 406
+// Gsample/s) -- so the choice is per kernel.
+template <bool NT, typename V>
+__device__ __forceinline__ void store_out(V *dst, V v)
+{
+#if defined(CORDIC_FORCE_NT_STORES)
+	__builtin_nontemporal_store(v, dst);
+#elif defined(CORDIC_FORCE_PLAIN_STORES)
+	*dst = v;
+#else
+	if constexpr (NT)
+		__builtin_nontemporal_store(v, dst);
+	else
+		*dst = v;
+#endif
+}
+
 // --------------------------------------------------------- unrolled rotator
 
 // Processes whole 4-sample groups only (nvec of them); the launcher sends the
@@ -521,9 +543,166 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				}
 			}
 		}
-		// outputs are written once and never re-read here: stream them
-		__builtin_nontemporal_store(rx, &ox[g]);
-		__builtin_nontemporal_store(ry, &oy[g]);
+		store_out<true>(&ox[g], rx);
+		store_out<true>(&oy[g], ry);
+	}
+}
+
+// ------------------------------------------ seeded rotator (const vector)
+//
+// Constant i_xval / i_yval: the first M micro-rotations are replaced by a
+// table lookup (see cordic_plan.cpp for the argument and the table layout).
+// Per block: the bucket table is copied to LDS and the (x_M, y_M) seeds of
+// every (octant, leaf) are computed with the exact recurrence -- nothing is
+// cached between launches.  Per sample: one bucket read, two compares, one
+// seed read, then stages M .. NLIVE-1 as in rotator_unrolled.
+struct SeedArgs {
+	const uint32_t *table;	// device copy of build_seed_table()'s words
+	int32_t	S;		// bucket shift
+	int32_t	nbuckets;
+	int32_t	nleaves;
+};
+
+template <typename C, int NLIVE, int M, Feed FEED>
+__global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
+		SeedArgs sa, const u32x4 *__restrict__ phin,
+		i32x4 *__restrict__ ox, i32x4 *__restrict__ oy, size_t nvec)
+{
+	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
+	using U = typename std::make_unsigned<T>::type;
+	using Z = typename std::conditional<C::wide, int64_t, uint32_t>::type;
+	static_assert(FEED != Feed::PhaseArray_XYArray, "constant vector only");
+	static_assert(M <= NLIVE, "seed deeper than the core");
+
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *lds_buckets = lds;				// nbuckets x 4
+	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 4;	// 4L x 8 words
+	const int L = sa.nleaves;
+
+	for (int i = threadIdx.x; i < sa.nbuckets * 4; i += kSeedBlock)
+		lds_buckets[i] = sa.table[4 + i];
+	const uint32_t *leafmeta = sa.table + 4 + (size_t)sa.nbuckets * 4;
+	for (int e = threadIdx.x; e < 4 * L; e += kSeedBlock) {
+		const int q = e / L, j = e - q * L;
+		const uint32_t pattern = leafmeta[2 * j];
+		const T ex = (T)((U)(T)kp.x0 << kp.in_shl);
+		const T ey = (T)((U)(T)kp.y0 << kp.in_shl);
+		T x, y;
+		uint32_t fp;
+		fold_octant<T>(ex, ey, (uint32_t)q << 30, x, y, fp);
+		for (int i = 0; i < M; i++) {		// rtl/cordic.v:262-280
+			const int k = (i + 1 > (int)sizeof(T) * 8 - 1)
+					? (int)sizeof(T) * 8 - 1 : i + 1;
+			const T sy = y >> k, sx = x >> k;
+			if ((pattern >> (M - 1 - i)) & 1u) {	// phase >= 0
+				x = (T)((U)x - (U)sy);
+				y = (T)((U)y + (U)sx);
+			} else {
+				x = (T)((U)x + (U)sy);
+				y = (T)((U)y - (U)sx);
+			}
+		}
+		int64_t sx64 = (int64_t)(Z)x, sy64 = (int64_t)(Z)y;
+		if constexpr (C::lj != 0) {
+			sx64 = (int64_t)((uint64_t)sx64 << C::lj);
+			sy64 = (int64_t)((uint64_t)sy64 << C::lj);
+		}
+		uint32_t *d = lds_seeds + (size_t)e * 8;
+		d[0] = (uint32_t)sx64; d[1] = (uint32_t)((uint64_t)sx64 >> 32);
+		d[2] = (uint32_t)sy64; d[3] = (uint32_t)((uint64_t)sy64 >> 32);
+		d[4] = leafmeta[2 * j + 1];		// off + 2^29
+		d[5] = d[6] = d[7] = 0;
+	}
+	__syncthreads();
+
+	LjRegs ljc{};
+	if constexpr (C::lj != 0) {
+		ljc.mask = vgpr_const(LjConst<C::lj>::mask);
+		ljc.bit = vgpr_const(LjConst<C::lj>::bit);
+		ljc.maskbit = vgpr_const(LjConst<C::lj>::mask | LjConst<C::lj>::bit);
+	}
+	const uint32_t bshift = (uint32_t)sa.S - 4;	// bucket -> byte offset
+	const uint32_t seed_base = (uint32_t)sa.nbuckets * 16u;
+	const uint32_t qstride = (uint32_t)L * 32u;
+	const char *ldsb = reinterpret_cast<const char *>(lds);
+
+	const size_t stride = (size_t)gridDim.x * kSeedBlock;
+	size_t g = (size_t)blockIdx.x * kSeedBlock + threadIdx.x;
+	u32x4 nph{};
+	if constexpr (FEED != Feed::Nco_ConstXY)
+		if (g < nvec)
+			nph = phin[g];
+	for (; g < nvec; g += stride) {
+		const u32x4 tph = nph;
+		if constexpr (FEED != Feed::Nco_ConstXY) {
+			const size_t gn = g + stride;
+			if (gn < nvec)
+				nph = phin[gn];
+		}
+		uint32_t P[kVec];
+		if constexpr (FEED == Feed::Nco_ConstXY) {
+			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
+			P[0] = kp.phase0 + s0 * kp.fcw;
+#pragma unroll
+			for (int v = 1; v < kVec; v++)
+				P[v] = P[v - 1] + kp.fcw;
+		} else {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				P[v] = tph[v] << kp.pw_shl;
+		}
+
+		int64_t x[kVec], y[kVec], p[kVec];
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const uint32_t pb = P[v] + 0x20000000u;
+			const uint32_t q = pb >> 30;
+			const uint32_t r = pb & 0x3fffffffu;	// p0 + 2^29
+			const u32x4 bk = *reinterpret_cast<const u32x4 *>(
+					ldsb + ((r >> bshift) & ~15u));
+			// r >= bound  <=>  (bound-1) - r < 0
+			const uint32_t j32 = (bk[2] + ((bk[0] - r) >> 31)
+						+ ((bk[1] - r) >> 31)) << 5;
+			const char *se = ldsb + seed_base + q * qstride + j32;
+			const u32x4 xy = *reinterpret_cast<const u32x4 *>(se);
+			const uint32_t offr = *reinterpret_cast<const uint32_t *>(se + 16);
+			x[v] = (int64_t)(((uint64_t)xy[1] << 32) | xy[0]);
+			y[v] = (int64_t)(((uint64_t)xy[3] << 32) | xy[2]);
+			const uint32_t pm = r - offr;		// residual after M stages
+			if constexpr (C::lj != 0)
+				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)pm << 31);
+			else
+				p[v] = (int64_t)pm;
+		}
+
+		i32x4 rx, ry;
+		if constexpr (C::lj == 0) {
+			RotChain<C, NLIVE, 0, M>::run(x, y, p, kp);
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				rx[v] = round_to_ow<T>((T)x[v], kp);
+				ry[v] = round_to_ow<T>((T)y[v], kp);
+			}
+		} else {
+			constexpr int LJ = C::lj;
+			static_assert(M >= C::ngen, "seed must cover the general stages");
+			RotChainLJ<LJ, NLIVE, M>::run(x, y, p, kp, ljc);
+			if (kp.r_lj == 32) {
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj32<LJ>(x[v], kp);
+					ry[v] = round_to_ow_lj32<LJ>(y[v], kp);
+				}
+			} else {
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj<LJ>(x[v], kp);
+					ry[v] = round_to_ow_lj<LJ>(y[v], kp);
+				}
+			}
+		}
+		store_out<false>(&ox[g], rx);
+		store_out<false>(&oy[g], ry);
 	}
 }
 
@@ -596,8 +775,8 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			rm[v] = round_to_ow<T>((T)x[v], kp);
 			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
 		}
-		__builtin_nontemporal_store(rm, &omag[g]);
-		__builtin_nontemporal_store(rp, &oph[g]);
+		store_out<true>(&omag[g], rm);
+		store_out<true>(&oph[g], rp);
 	}
 }
 

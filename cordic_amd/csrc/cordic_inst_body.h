@@ -1,6 +1,7 @@
 // cordic_inst_body.h -- one instantiation unit of the unrolled kernels.
 // The including .hip file defines
-//   CORDIC_INST_KIND       1 = rotator (p2r), 2 = converter (r2p)
+//   CORDIC_INST_KIND       1 = rotator (p2r), 2 = converter (r2p),
+//                          3 = seeded rotator (constant vector)
 //   CORDIC_INST_NAME       name of the launcher this unit exports
 //   CORDIC_INST_CONTAINER  dev::Narrow32 or dev::Wide64
 //   CORDIC_INST_NGEN       leading stages in the GENERAL 64-bit form
@@ -47,6 +48,42 @@ bool CORDIC_INST_NAME(Feed feed, int nlive, int grid, hipStream_t st,
 	default:
 		return launch_feed<Feed::Nco_ConstXY>(nlive, grid, st, kp, j);
 	}
+}
+#elif CORDIC_INST_KIND == 3
+namespace {
+template <Feed FEED>
+bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
+		const dev::SeedArgs &sa, const RotatorJob &j, size_t lds_bytes)
+{
+	using namespace dev;
+	switch (nlive) {
+#define X(N) case N: { \
+	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
+	if (lds_bytes > 64 * 1024) \
+		(void)hipFuncSetAttribute((const void *)kern, \
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp, sa, \
+		(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec); \
+	return true; }
+	CORDIC_ROT_STAGES(X)
+#undef X
+	default:
+		return false;
+	}
+}
+} // namespace
+
+bool CORDIC_INST_NAME(Feed feed, int nlive, int grid, hipStream_t st,
+		const dev::CoreParams &kp, const dev::SeedArgs &sa,
+		const RotatorJob &j, size_t lds_bytes)
+{
+	if (feed == Feed::PhaseArray_ConstXY)
+		return launch_seeded<Feed::PhaseArray_ConstXY>(nlive, grid, st, kp,
+				sa, j, lds_bytes);
+	if (feed == Feed::Nco_ConstXY)
+		return launch_seeded<Feed::Nco_ConstXY>(nlive, grid, st, kp, sa, j,
+				lds_bytes);
+	return false;
 }
 #else
 bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,

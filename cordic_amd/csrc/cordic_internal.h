@@ -28,6 +28,19 @@ int	write_header(const cordic_config *c, const char *name, char *buf,
 		size_t cap);
 const char *status_text(int s);
 
+// Seed tables: stages replaced by the lookup and threads per block of the
+// seeded kernels (one table per block).
+#ifndef CORDIC_SEED_STAGES
+#define CORDIC_SEED_STAGES 9
+#endif
+#ifndef CORDIC_SEED_BLOCK
+#define CORDIC_SEED_BLOCK 1024
+#endif
+
+// ---- host: cordic_plan.cpp
+bool	seed_eligible(const cordic_config &c, int m);
+size_t	build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap);
+
 // ---- device launchers: cordic_kernels.hip
 // Where the rotator's phase / vector inputs come from.
 enum class Feed : int {
@@ -44,6 +57,9 @@ struct RotatorJob {
 	uint64_t index0 = 0;				// NCO
 	int32_t  *ox = nullptr, *oy = nullptr;
 	size_t   n = 0;
+	// optional seed table (cordic_plan): device words + their host header
+	const uint32_t *seed_table = nullptr;
+	int seed_m = 0, seed_S = 0, seed_nbuckets = 0, seed_nleaves = 0;
 };
 
 int	launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,

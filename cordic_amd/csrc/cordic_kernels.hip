@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void digest_u32(const uint32_t *w, size_t n
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int grid_for(size_t work_items_per_block, size_t n)
+int grid_for(size_t work_items_per_block, size_t n, int blocks_per_cu = 8)
 {
 	static int cus = 0;
 	if (cus == 0) {
@@ -185,7 +185,7 @@ int grid_for(size_t work_items_per_block, size_t n)
 		cus = prop.multiProcessorCount;
 	}
 	const size_t blocks = (n + work_items_per_block - 1) / work_items_per_block;
-	const size_t cap = (size_t)cus * 8;	// 8 x 256-thread blocks per CU
+	const size_t cap = (size_t)cus * blocks_per_cu;	// resident blocks; the rest is grid-stride
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
@@ -259,7 +259,35 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		if (grid < 0)
 			return CORDIC_ERR_DEVICE;
 		bool done = false;
-		if (j.n >= (size_t)kVec) {
+		// constant-vector feeds with a plan: table-seeded kernel
+		if (FEED != Feed::PhaseArray_XYArray && j.seed_table
+				&& j.seed_m == kSeedStages && j.n >= (size_t)kVec
+				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)) {
+			SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets,
+					j.seed_nleaves};
+			const size_t lds = (size_t)j.seed_nbuckets * 16
+					+ (size_t)j.seed_nleaves * 4 * 32;
+			// blocks per CU: 32 waves and 160 KiB of LDS to share
+			int per_cu = 32 / (kSeedBlock / 64);
+			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+			if (by_lds < per_cu) per_cu = by_lds;
+			const int g2 = grid_for((size_t)kSeedBlock * kVec, j.n,
+					per_cu < 1 ? 1 : per_cu);
+			if (g2 < 0)
+				return CORDIC_ERR_DEVICE;
+			if (per_cu >= 1 && lds <= 160 * 1024) {
+				if (cfg.ww <= 32)
+					done = launch_seed_narrow(FEED, cfg.nlive, g2, st,
+							kp, sa, j, lds);
+				else if (cfg.ww == 35)
+					done = launch_seed_lj29(FEED, cfg.nlive, g2, st, kp,
+							sa, j, lds);
+				else if (cfg.ww < 35)
+					done = launch_seed_lj30(FEED, cfg.nlive, g2, st, kp,
+							sa, j, lds);
+			}
+		}
+		if (!done && j.n >= (size_t)kVec) {
 			const int ngen = general_stages_for(cfg.ww);
 			if (cfg.ww <= 32)
 				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);

@@ -31,6 +31,13 @@ CORDIC_ROT_LAUNCHER(launch_rot_lj30);		// WW == 33, 34
 CORDIC_ROT_LAUNCHER(launch_rot_wide2);		// WW <= 35 (kept for A/B)
 CORDIC_ROT_LAUNCHER(launch_rot_wide8);		// WW <= 41
 CORDIC_ROT_LAUNCHER(launch_rot_wideall);	// WW <= 64
+#define CORDIC_SEED_LAUNCHER(NAME) \
+	bool NAME(Feed feed, int nlive, int grid, hipStream_t st, \
+		const dev::CoreParams &kp, const dev::SeedArgs &sa, \
+		const RotatorJob &j, size_t lds_bytes)
+CORDIC_SEED_LAUNCHER(launch_seed_narrow);	// WW <= 32
+CORDIC_SEED_LAUNCHER(launch_seed_lj29);		// WW == 35
+CORDIC_SEED_LAUNCHER(launch_seed_lj30);		// WW == 33, 34
 CORDIC_POL_LAUNCHER(launch_pol_narrow);
 CORDIC_POL_LAUNCHER(launch_pol_wide8);
 CORDIC_POL_LAUNCHER(launch_pol_wideall);

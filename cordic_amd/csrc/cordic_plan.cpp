@@ -1,0 +1,144 @@
+// cordic_plan.cpp -- "seed tables" for constant-vector rotators (host side).
+//
+// When i_xval / i_yval are held constant (the sin/cos generator use of the
+// core, reference bench/cpp/cordic_tb.cpp:68-69), the state (x, y) after the
+// first M stages depends only on the octant q and on the M rotation
+// directions, and the directions depend only on the folded phase p0:
+//     s_i = +1 if p_i >= 0 else -1,   p_{i+1} = p_i - s_i * a_i
+// (rtl/cordic.v:262-280).  That map is monotone in p0, so [-45deg, +45deg)
+// splits into at most 2^M consecutive intervals ("leaves"), one per reachable
+// direction pattern, whose end points are exact integers (partial sums of
+// +/- a_i).  A kernel can therefore replace the first M micro-rotations by:
+// find the leaf of p0 (bucket table + at most two compares), fetch (x_M, y_M)
+// for (q, leaf) from a table that the kernel itself fills by running the exact
+// recurrence once per entry, and continue with stage M.  Results are
+// bit-identical for every phase; only the per-sample work changes.
+//
+// This file builds the phase-side tables (they depend on the arctan table
+// only) as a flat array of 32-bit words:
+//   [0] M  [1] S (bucket shift)  [2] nbuckets  [3] nleaves
+//   buckets: nbuckets x {b1-1, b2-1, first_leaf, 0}   in the r-domain
+//            r = p0 + 2^29 in [0, 2^30); unused bounds are 0x7fffffff
+//   leaves : nleaves  x {pattern (M bits, stage 0 = MSB), off + 2^29}
+//            where p_M = p0 - off
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "cordic_amd.h"
+#include "cordic_internal.h"
+
+namespace cordic_amd {
+
+namespace {
+struct Leaf { int64_t lo, hi, off; uint32_t pattern; };
+
+void split(const uint32_t *ang, int m, int i, int64_t lo, int64_t hi, int64_t off,
+		uint32_t pat, std::vector<Leaf> &out)
+{
+	if (lo >= hi)
+		return;
+	if (i == m) {
+		out.push_back({lo, hi, off, pat});
+		return;
+	}
+	const int64_t a = ang[i];
+	// p_i = p0 - off.  p_i < 0 (s = -1): p' = p + a;  p_i >= 0 (s = +1): p' = p - a
+	split(ang, m, i + 1, lo, std::min(hi, off), off - a, pat << 1, out);
+	split(ang, m, i + 1, std::max(lo, off), hi, off + a, (pat << 1) | 1u, out);
+}
+} // namespace
+
+bool seed_eligible(const cordic_config &c, int m)
+{
+	if (c.mode != CORDIC_P2R && c.mode != CORDIC_SP2R)
+		return false;
+	if (c.nlive < m || m < 1 || m > 12)
+		return false;
+	if (c.ww > 35)
+		return false;			// no seeded kernel for these
+	if (c.needs_wrap && c.ww != 32 && c.ww != 35)
+		return false;
+	return true;
+}
+
+// Returns the number of words written (0 if the table cannot be built within
+// `cap` words or the bucket constraint cannot be met).
+size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap)
+{
+	if (!seed_eligible(c, m))
+		return 0;
+	const int lsh = 32 - c.pw;
+	uint32_t ang[CORDIC_AMD_MAX_STAGES];
+	for (int i = 0; i < m; i++)
+		ang[i] = c.angle[i] << lsh;	// left-justified, as the kernels use it
+
+	const int64_t LO = -((int64_t)1 << 29), HI = (int64_t)1 << 29;
+	std::vector<Leaf> leaves;
+	split(ang, m, 0, LO, HI, 0, 0u, leaves);
+	std::sort(leaves.begin(), leaves.end(),
+		[](const Leaf &a, const Leaf &b) { return a.lo < b.lo; });
+	const size_t L = leaves.size();
+	if (L == 0 || L > 4096)
+		return 0;
+
+	// largest bucket (2^S phase units) holding at most two leaf boundaries
+	int S = 26;
+	std::vector<int> count;
+	for (; S >= 18; S--) {
+		count.assign((size_t)1 << (30 - S), 0);
+		int worst = 0;
+		for (size_t j = 1; j < L; j++) {
+			const int64_t r = leaves[j].lo - LO;
+			worst = std::max(worst, ++count[(size_t)(r >> S)]);
+		}
+		if (worst <= 2)
+			break;
+	}
+	if (S < 18)
+		return 0;
+	const size_t nb = (size_t)1 << (30 - S);
+	const size_t words = 4 + nb * 4 + L * 2;
+	if (!buf || words > cap)
+		return 0;
+
+	buf[0] = (uint32_t)m;
+	buf[1] = (uint32_t)S;
+	buf[2] = (uint32_t)nb;
+	buf[3] = (uint32_t)L;
+	uint32_t *bk = buf + 4;
+	for (size_t b = 0; b < nb; b++) {
+		bk[4 * b + 0] = 0x7fffffffu;
+		bk[4 * b + 1] = 0x7fffffffu;
+		bk[4 * b + 2] = 0;
+		bk[4 * b + 3] = 0;
+	}
+	// first_leaf[b] = leaf containing the first phase of bucket b
+	size_t j = 0;
+	for (size_t b = 0; b < nb; b++) {
+		const int64_t start = LO + ((int64_t)b << S);
+		while (j + 1 < L && leaves[j + 1].lo <= start)
+			j++;
+		bk[4 * b + 2] = (uint32_t)j;
+	}
+	for (size_t k = 1; k < L; k++) {
+		const int64_t r = leaves[k].lo - LO;		// boundary, r-domain
+		const size_t b = (size_t)(r >> S);
+		if ((r & (((int64_t)1 << S) - 1)) == 0)
+			continue;	// on a bucket edge: already in first_leaf
+		uint32_t *e = bk + 4 * b;
+		if (e[0] == 0x7fffffffu)
+			e[0] = (uint32_t)(r - 1);
+		else
+			e[1] = (uint32_t)(r - 1);
+	}
+	uint32_t *lf = bk + 4 * nb;
+	for (size_t k = 0; k < L; k++) {
+		lf[2 * k + 0] = leaves[k].pattern;
+		lf[2 * k + 1] = (uint32_t)(leaves[k].off - LO);	// off + 2^29
+	}
+	return words;
+}
+
+} // namespace cordic_amd

@@ -77,6 +77,8 @@ enum cordic_status {
 #define CORDIC_FLAG_LDS_TABLE		0x2u	/* arctan table read from LDS   */
 #define CORDIC_FLAG_NO_LJ		0x4u	/* WW 33..35: right-justified
 						   64-bit kernel (for A/B)      */
+#define CORDIC_FLAG_NO_SEED		0x8u	/* plans: full recurrence, no
+						   seed table (for A/B)         */
 
 /*
  * One generated core.  The first block mirrors, field for field, the
@@ -181,6 +183,48 @@ int	cordic_nco(const cordic_config *cfg, size_t n,
 int	cordic_r2p(const cordic_config *cfg, size_t n,
 		const int32_t *d_xval, const int32_t *d_yval,
 		int32_t *d_omag, uint32_t *d_ophase, void *stream);
+
+/*
+ * Plans: a generated core bound to the current HIP device.
+ *
+ * gencordic generates a core once and the bench then streams samples through
+ * it; cordic_plan_create is that generation step for the GPU.  For rotators it
+ * uploads a small "seed table" (cordic_seed_table) that lets the constant-
+ * vector entry points -- the sin/cos generator use of the core, i_xval/i_yval
+ * fixed as in bench/cpp/cordic_tb.cpp:68-69 -- replace the first 9
+ * micro-rotations by an exact table lookup: the (x, y) state after 9 stages
+ * depends only on the octant and on the 9 rotation directions, which are a
+ * monotone step function of the phase with integer break points.  The kernel
+ * fills the (x, y) table itself on every launch with the exact recurrence, so
+ * results are bit-identical for every phase and nothing is cached across
+ * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 9 live
+ * stages) simply run the ordinary kernels.
+ */
+typedef struct cordic_plan cordic_plan;
+
+int	cordic_plan_create(const cordic_config *cfg, cordic_plan **plan);
+void	cordic_plan_destroy(cordic_plan *plan);
+const cordic_config *cordic_plan_config(const cordic_plan *plan);
+/* stages covered by the seed table (0 = none), its leaves and buckets */
+int	cordic_plan_seed_info(const cordic_plan *plan, int32_t *stages,
+		int32_t *nleaves, int32_t *nbuckets);
+
+int	cordic_plan_p2r_const(const cordic_plan *plan, size_t n,
+		int32_t xval, int32_t yval, const uint32_t *d_phase,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+int	cordic_plan_nco(const cordic_plan *plan, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		int32_t xval, int32_t yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* Host only: the phase-side seed table of a core as 32-bit words
+ *   [0] stages M  [1] bucket shift S  [2] nbuckets  [3] nleaves
+ *   nbuckets x {bound1-1, bound2-1, first_leaf, 0}   (r = phase + 2^29 domain)
+ *   nleaves  x {direction pattern, offset + 2^29}
+ * on the left-justified phase (phase << (32-PW)) after the octant fold.
+ * Returns the number of words, or 0 if the core is not eligible / cap is too
+ * small.  buf may be NULL to query eligibility only when cap is 0. */
+size_t	cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words);
 
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,

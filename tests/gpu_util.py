@@ -82,3 +82,22 @@ def gpu_digest(t, index0=0, n=None):
     ca.digest_u32(t, index0, d, n=n)
     torch.cuda.synchronize()
     return int(d.cpu().numpy().view(np.uint64)[0])
+
+
+def gpu_plan_p2r(plan, x0, y0, phase):
+    phase = np.ascontiguousarray(phase, dtype=np.uint32)
+    n = phase.size
+    dph = dev_i32(phase)
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    plan.p2r_const(int(x0), int(y0), dph, ox, oy, n=n)
+    torch.cuda.synchronize()
+    return to_np(ox), to_np(oy)
+
+
+def gpu_plan_nco(plan, n, phase0, fcw, index0, x0, y0):
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    plan.nco(n, phase0, fcw, index0, x0, y0, ox, oy)
+    torch.cuda.synchronize()
+    return to_np(ox), to_np(oy)

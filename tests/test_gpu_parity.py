@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 if torch.cuda.is_available():
     from gpu_util import (DEV, cpu_digest, dev_i32, gpu_digest, gpu_nco,
-                          gpu_p2r, gpu_r2p, to_np)
+                          gpu_p2r, gpu_plan_nco, gpu_plan_p2r, gpu_r2p, to_np)
 
 
 def both(mode, iw=-1, ow=-1, xtra=2, pw=-1, ns=-1):
@@ -350,3 +350,102 @@ def test_fill_kernels_and_digest_twin():
     whole = gpu_digest(x, 0)
     parts = (gpu_digest(x[:40000], 0) + gpu_digest(x[40000:], 40000)) % 2**64
     assert whole == parts
+
+
+# ------------------------------------------------- plans / seeded kernels
+
+SEED_CASES = {
+    "cfg2": (ca.P2R, 32, 32, 2, 32, 16),
+    "cfg4": (ca.P2R, 32, 32, 2, 32, 24),
+    "cfg5_seq": (ca.SP2R, 32, 32, 2, 32, 16),
+    "rtl_cordic": (ca.P2R, 13, 13, 2, -1, -1),
+    "rtl_seqcordic": (ca.SP2R, 13, 13, 2, -1, -1),
+    "cfg1": (ca.P2R, 16, 16, 2, 16, 16),
+    "ww33": (ca.P2R, 30, 30, 2, 32, 16),
+    "ww34": (ca.P2R, 31, 31, 2, 30, 20),
+    "ww32": (ca.P2R, 29, 29, 2, 32, 18),
+    "pw12": (ca.P2R, 12, 12, 2, 12, 12),
+}
+
+
+def breakpoint_phases(cfg):
+    """Every phase within +/-2 LSB of a leaf boundary, in all four octant
+    pairs, as PW-bit phase values."""
+    words = ca.seed_table(cfg)
+    m, S, nb, L = (int(v) for v in words[:4])
+    buckets = words[4:4 + nb * 4].reshape(nb, 4).astype(np.int64)
+    lsb = 1 << (32 - cfg.pw)
+    bounds = np.concatenate([buckets[:, 0], buckets[:, 1]])
+    bounds = bounds[bounds != 0x7fffffff] + 1           # r-domain boundaries
+    starts = (np.arange(nb, dtype=np.int64) << S)        # bucket edges too
+    r = np.concatenate([bounds, starts, [0, (1 << 30) - lsb]])
+    r = np.concatenate([r + d * lsb for d in (-2, -1, 0, 1, 2)])
+    r = r[(r >= 0) & (r < (1 << 30))]
+    out = []
+    for q in range(4):
+        P = (r - (1 << 29) + (q << 30)) & 0xffffffff
+        out.append(P >> (32 - cfg.pw))
+    return np.concatenate(out).astype(np.uint32)
+
+
+@pytest.mark.parametrize("name", sorted(SEED_CASES))
+def test_seeded_plan_is_bit_exact(name):
+    cfg, ocfg = both(*SEED_CASES[name])
+    plan = ca.Plan(cfg)
+    info = plan.seed_info
+    assert info["stages"] == 9 and info["nleaves"] >= 100
+    rng = np.random.RandomState(21)
+    n = (1 << 19) + 5
+    _, _, ph = rand_inputs(rng, cfg.iw, cfg.pw, n)
+    ph = np.concatenate([ph, breakpoint_phases(cfg)])
+    lo, hi = -(1 << (cfg.iw - 1)), (1 << (cfg.iw - 1)) - 1
+    for x0, y0 in [(hi, 0), (lo, lo), (0, hi), (-12345 % (hi + 1), 777 % hi),
+                   (hi, lo), (0, 0), (1, -1)]:
+        gx, gy = gpu_plan_p2r(plan, x0, y0, ph)
+        rx, ry = O.rotate(ocfg, x0, y0, ph)
+        assert np.array_equal(gx, rx) and np.array_equal(gy, ry), (x0, y0)
+    # and it really is the seeded kernel: same results with it switched off
+    plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
+    a = gpu_plan_p2r(plan, hi, 0, ph)
+    b = gpu_plan_p2r(plain, hi, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    plan.close()
+    plain.close()
+
+
+def test_seeded_plan_exhaustive_checked_in_core():
+    """All 2^20 phases of rtl/cordic.v through the seeded kernel."""
+    cfg, ocfg = both(ca.P2R, 13, 13, 2)
+    plan = ca.Plan(cfg)
+    ph, x0, y0 = Q.p2r_bench_inputs(cfg.iw, cfg.pw)
+    gx, gy = gpu_plan_p2r(plan, x0, y0, ph)
+    rx, ry = O.rotate(ocfg, x0, y0, ph)
+    assert np.array_equal(gx, rx) and np.array_equal(gy, ry)
+    assert Q.p2r_quality(cfg, ph, x0, y0, gx, gy)["ok"]
+
+
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 16),
+                                  (ca.SP2R, 32, 32, 2, 32, 16),
+                                  (ca.P2R, 13, 13, 2, -1, -1)])
+def test_seeded_nco(args):
+    cfg, ocfg = both(*args)
+    plan = ca.Plan(cfg)
+    x0 = (1 << (cfg.iw - 1)) - 1
+    for n, phase0, fcw, index0 in [(200003, 0, 0x01234567, 0),
+                                   (4097, 0xdeadbeef, 0x9e3779b9, 12345),
+                                   (65536, 5, 1, (7 << 32) + 99)]:
+        a = gpu_plan_nco(plan, n, phase0, fcw, index0, x0, 0)
+        b = O.nco(ocfg, n, phase0, fcw, index0, x0, 0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_plan_for_ineligible_core_still_works():
+    """r2p / wide cores: the plan carries no table and runs the plain path."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 3, 32, 16)          # WW 36
+    plan = ca.Plan(cfg)
+    assert plan.seed_info["stages"] == 0
+    rng = np.random.RandomState(3)
+    _, _, ph = rand_inputs(rng, 32, 32, 30001)
+    a = gpu_plan_p2r(plan, 2**31 - 1, 0, ph)
+    b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

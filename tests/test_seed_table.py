@@ -1,0 +1,72 @@
+"""Host logic of the seed tables (cordic_plan.cpp) without a GPU: the leaves
+must partition [-45deg, +45deg) and the bucket lookup must return, for any
+folded phase, the leaf whose direction pattern and phase offset are exactly
+what the stage recurrence of rtl/cordic.v:262-280 produces."""
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+
+CASES = [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
+         (ca.SP2R, 32, 32, 2, 32, 16), (ca.P2R, 13, 13, 2, -1, -1),
+         (ca.P2R, 16, 16, 2, 16, 16), (ca.P2R, 12, 12, 2, 12, 12),
+         (ca.P2R, 30, 30, 2, 32, 16), (ca.SP2R, 13, 13, 2, 20, 16)]
+
+
+def parse(words):
+    m, S, nb, L = (int(v) for v in words[:4])
+    buckets = words[4:4 + nb * 4].reshape(nb, 4).astype(np.int64)
+    leaves = words[4 + nb * 4:4 + nb * 4 + L * 2].reshape(L, 2).astype(np.int64)
+    return m, S, nb, L, buckets, leaves
+
+
+def recurrence(p0, ang, m):
+    """directions and residual phase after m stages (exact integers)."""
+    pat = np.zeros(p0.shape, dtype=np.int64)
+    p = p0.astype(np.int64).copy()
+    for i in range(m):
+        pos = p >= 0
+        pat = (pat << 1) | pos
+        p = np.where(pos, p - ang[i], p + ang[i])
+    return pat, p
+
+
+@pytest.mark.parametrize("args", CASES)
+def test_lookup_matches_recurrence(args):
+    cfg = ca.Config.from_cli(*args)
+    words = ca.seed_table(cfg)
+    assert words is not None
+    m, S, nb, L, buckets, leaves = parse(words)
+    assert m == 9 and nb == 1 << (30 - S) and 1 <= L <= 512
+    ang = [a << (32 - cfg.pw) for a in cfg.angles]
+    rng = np.random.RandomState(1)
+    r = rng.randint(0, 1 << 30, 200000).astype(np.int64)
+    # plus every value around every breakpoint the recurrence can produce
+    extra = []
+    for i in range(m + 1):
+        for signs in range(1 << i):
+            off = sum((ang[j] if (signs >> j) & 1 else -ang[j])
+                      for j in range(i))
+            for d in (-2, -1, 0, 1, 2):
+                v = off + d + (1 << 29)
+                if 0 <= v < (1 << 30):
+                    extra.append(v)
+    r = np.concatenate([r, np.array(extra, dtype=np.int64),
+                        np.array([0, 1, (1 << 30) - 1], dtype=np.int64)])
+    b = r >> S
+    t1 = buckets[b, 0] - r
+    t2 = buckets[b, 1] - r
+    j = buckets[b, 2] + (t1 < 0) + (t2 < 0)
+    assert j.max() < L
+    pat, pm = recurrence(r - (1 << 29), ang, m)
+    assert np.array_equal(leaves[j, 0], pat)
+    off = leaves[j, 1] - (1 << 29)
+    assert np.array_equal((r - (1 << 29)) - off, pm)
+    # residual phase stays far inside 32 bits (the kernels rely on it)
+    assert np.abs(pm).max() <= 1 << 29
+
+
+def test_ineligible_cores_have_no_table():
+    assert ca.seed_table(ca.Config.from_cli(ca.R2P, 13, 13, 2)) is None
+    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 3, 32, 16)) is None  # WW 36
+    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 9 stages

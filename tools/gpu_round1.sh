@@ -1,10 +1,18 @@
-# GPU session script (round 1): tests, microbench, bench lines.
+# GPU session script (round 1): parity tests, then one bench line per workload
+# (seeded and full-recurrence, ramp and random inputs).
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 300 ./tools/valu_microbench > gpurun_out/valu_microbench.txt 2>&1
+mkdir -p gpurun_out/bench
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.txt 2>&1
-tail -5 gpurun_out/pytest_gpu.txt
-timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.err
-cat gpurun_out/bench_cfg2.json
-for w in cfg3 cfg4 cfg5 cfg5seq; do timeout 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; cat gpurun_out/bench_$w.json; done
-cat gpurun_out/valu_microbench.txt
+tail -4 gpurun_out/pytest_gpu.txt
+for w in cfg2 cfg3 cfg4 cfg5 cfg5seq; do for s in "" "--no-seed"; do for i in ramp random; do
+if [ "$w" = "cfg3" ] && [ -n "$s" ]; then continue; fi
+tag=${w}${s:+_noseed}_$i
+timeout 300 python bench.py --workload $w $s --input $i --no-cpu-baseline > gpurun_out/bench/$tag.json 2> gpurun_out/bench/$tag.err; python - <<PY
+import json
+try:
+    d=json.load(open("gpurun_out/bench/$tag.json"))
+    print("$tag", round(d["value"]), "Msps", round(d["ms_per_step"],3), "frac", round(d["roofline"]["frac"],3), d["bit_exact_vs_oracle"], d["config"]["kernel"])
+except Exception as e:
+    print("$tag FAILED", e, open("gpurun_out/bench/$tag.err").read()[-500:])
+PY
+done; done; done
