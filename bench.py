@@ -53,62 +53,40 @@ WORKLOADS = {
 MODE = {"p2r": 0, "r2p": 1, "sp2r": 2, "sr2p": 3}
 
 
-def cpu_baseline(workload, seconds_target=12.0):
+def cpu_baseline(workload, seconds=12.0):
     """The oracle (a restatement of the reference RTL, NOT reference code:
     the reference has no CPU compute path) timed on
-    the host cores of this box on a bounded sample of the same workload."""
+    the host cores of this box on a bounded sample of the same workload:
+    oracle/cordic_oracle.c:orc_throughput runs one POSIX thread per hardware
+    thread, each pushing 2^16-sample blocks through the scalar oracle until
+    `seconds` have passed."""
+    import ctypes as C
     import oracle_lib as O
     w = WORKLOADS[workload]
     m, iw, ow, xtra, pw, ns = w["cli"]
     ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    L = O.lib()
     cores = os.cpu_count() or 1
-    per = 1 << 21                       # samples per thread per round
-
-    def work(tid, rounds, out):
-        base = tid * per
-        g = np.arange(per, dtype=np.uint64) + np.uint64(base)
-        t0 = time.perf_counter()
-        for _ in range(rounds):
-            if w["kind"] == "r2p":
-                sh = 32 - iw
-                x = (((((g * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff))
-                       >> np.uint64(8)).astype(np.uint32) << sh)
-                     .astype(np.int32) >> sh)
-                y = (((((g * np.uint64(0x85EBCA77)) & np.uint64(0xffffffff))
-                       >> np.uint64(8)).astype(np.uint32) << sh)
-                     .astype(np.int32) >> sh)
-                O.topolar(ocfg, x, y)
-            else:
-                ph = ((g << np.uint64(w.get("shift", 0)))
-                      & np.uint64(0xffffffff)).astype(np.uint32)
-                O.rotate(ocfg, 2**31 - 1, 0, ph)
-        out[tid] = time.perf_counter() - t0
-
-    # calibrate on one thread, one round
-    o = {}
-    work(0, 1, o)
-    one = o[0]
-    rounds = max(1, min(64, int(seconds_target / max(one, 1e-3))))
-    outs = {}
-    ths = [threading.Thread(target=work, args=(t, rounds, outs))
-           for t in range(cores)]
+    kind = 1 if w["kind"] == "r2p" else 0
+    mul = 0x01234567 if w["kind"] == "nco" else (1 << w.get("shift", 0))
+    x0 = (1 << (iw - 1)) - 1
     t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+    n1 = L.orc_throughput(C.byref(ocfg), kind, 1, 1.0, mul, x0, 0)
+    one = n1 / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    total = L.orc_throughput(C.byref(ocfg), kind, cores, seconds, mul, x0, 0)
     wall = time.perf_counter() - t0
-    total = cores * rounds * per
     return {
         "value": total / wall / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d samples (%d threads x %d rounds x 2^21) of the %s "
-                  "workload through oracle/liboracle.so (gcc -O2 scalar "
-                  "restatement of the reference RTL; the reference itself has "
-                  "no CPU compute path)" % (total, cores, rounds, workload),
-        "value_1thread": per / one / 1e6,
+        "sample": "%d samples of the %s workload (%d threads x 2^16-sample "
+                  "blocks for %.0f s) through oracle/liboracle.so: gcc -O2 "
+                  "scalar restatement of the reference RTL -- the reference "
+                  "itself has no CPU compute path" % (total, workload, cores,
+                                                      seconds),
+        "value_1thread": one / 1e6,
         "cpu": _cpu_model(),
     }
 
@@ -260,6 +238,38 @@ def main():
             ra, rb = O.rotate(ocfg, x0, y0, ph.astype(np.uint32))
         check = bool(np.array_equal(ga, ra) and np.array_equal(gb, rb))
 
+    # ---- constant-vector feeds: also time the full-recurrence kernel (every
+    # sample runs all micro-rotations) so both numbers are on record
+    full = None
+    if (w["kind"] in ("p2r", "nco") and not args.no_seed and not args.generic
+            and plan.seed_info["stages"] > 0):
+        plan2 = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
+        a2 = torch.empty_like(a)
+        b2 = torch.empty_like(b)
+
+        def step2():
+            if w["kind"] == "p2r":
+                plan2.p2r_const(x0, y0, phase, a2, b2)
+            else:
+                plan2.nco(n, 0, 0x01234567, index0, x0, y0, a2, b2)
+        k2 = max(3, min(args.steps, 10))
+        step2()
+        barrier()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k2):
+            step2()
+        e1.record()
+        barrier()
+        ms2 = e0.elapsed_time(e1) / k2
+        same = bool(torch.equal(a, a2) and torch.equal(b, b2))
+        full = {"ms_per_step": ms2, "steps": k2,
+                "value_per_gpu": n / ms2 / 1e3,
+                "hbm_frac": w["bytes"] * n / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "outputs_identical_to_seeded_kernel": same}
+        del a2, b2
+
     gather_ms = None
     if args.gather and dist is not None:
         outs = None
@@ -281,7 +291,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get(
+                key = args.workload + ("_noseed" if args.no_seed else "")
+                traffic = json.load(open(pmc)).get(key, {}).get(
                     "hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
@@ -327,6 +338,8 @@ def main():
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,
         }
+        if full is not None:
+            out["full_recurrence_kernel"] = full
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
         if not args.no_cpu_baseline and world == 1:

@@ -655,3 +655,78 @@ void orc_nco(const orc_config *c, size_t n, uint32_t phase0, uint32_t fcw,
 		orc_rotate(c, 1, &x0, &y0, 0, &ph, &ox[s], &oy[s]);
 	}
 }
+
+/* ------------------------------------------------------------ CPU baseline
+ *
+ * Timing harness for bench.py's cpu_baseline leg: `nthreads` POSIX threads
+ * each push 2^16-sample blocks of the workload through the scalar oracle
+ * until `seconds` have passed; returns the total number of samples done.
+ * kind 0: rotator with constant (x0, y0), phase[i] = (g * phase_mul) mod 2^32
+ * kind 1: converter on the I/Q ramps of SURVEY.md 8d config 3. */
+#include <pthread.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef struct {
+	const orc_config *cfg;
+	int kind, tid;
+	uint32_t phase_mul;
+	int32_t x0, y0;
+	double deadline;
+	uint64_t done;
+} orc_job;
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *orc_worker(void *arg)
+{
+	orc_job *j = (orc_job *)arg;
+	const size_t per = 1u << 16;
+	uint32_t *ph = malloc(per * 4);
+	int32_t *a = malloc(per * 4), *b = malloc(per * 4);
+	int32_t *x = malloc(per * 4), *y = malloc(per * 4);
+	const int sh = 32 - j->cfg->iw;
+	for (size_t i = 0; i < per; i++) {
+		uint32_t g = (uint32_t)((uint64_t)j->tid * per + i);
+		ph[i] = g * j->phase_mul;
+		x[i] = (int32_t)(((g * 0x9E3779B1u) >> 8) << sh) >> sh;
+		y[i] = (int32_t)(((g * 0x85EBCA77u) >> 8) << sh) >> sh;
+	}
+	while (now_s() < j->deadline) {
+		if (j->kind == 1)
+			orc_topolar(j->cfg, per, x, y, a, (uint32_t *)b);
+		else
+			orc_rotate(j->cfg, per, &j->x0, &j->y0, 0, ph, a, b);
+		j->done += per;
+	}
+	free(ph); free(a); free(b); free(x); free(y);
+	return NULL;
+}
+
+uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
+		double seconds, uint32_t phase_mul, int32_t x0, int32_t y0)
+{
+	if (nthreads < 1)
+		nthreads = 1;
+	pthread_t *th = malloc(sizeof(pthread_t) * (size_t)nthreads);
+	orc_job *jobs = calloc((size_t)nthreads, sizeof(orc_job));
+	const double deadline = now_s() + seconds;
+	uint64_t total = 0;
+	for (int t = 0; t < nthreads; t++) {
+		jobs[t].cfg = cfg; jobs[t].kind = kind; jobs[t].tid = t;
+		jobs[t].phase_mul = phase_mul; jobs[t].x0 = x0; jobs[t].y0 = y0;
+		jobs[t].deadline = deadline;
+		pthread_create(&th[t], NULL, orc_worker, &jobs[t]);
+	}
+	for (int t = 0; t < nthreads; t++) {
+		pthread_join(th[t], NULL);
+		total += jobs[t].done;
+	}
+	free(th); free(jobs);
+	return total;
+}

@@ -98,6 +98,10 @@ void	orc_nco(const orc_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
 		uint64_t index0, int32_t x0, int32_t y0,
 		int32_t *ox, int32_t *oy);
 
+/* bench.py cpu_baseline: samples processed by nthreads threads in `seconds` */
+uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
+		double seconds, uint32_t phase_mul, int32_t x0, int32_t y0);
+
 #ifdef __cplusplus
 }
 #endif

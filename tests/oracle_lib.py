@@ -77,6 +77,9 @@ def lib():
             getattr(L, name).argtypes = [C.c_int]
         L.orc_calc_stages2.argtypes = [C.c_int, C.c_int]
         L.orc_nextlg.argtypes = [C.c_uint]
+        L.orc_throughput.restype = C.c_uint64
+        L.orc_throughput.argtypes = [cfgp, C.c_int, C.c_int, C.c_double,
+                                     C.c_uint32, C.c_int32, C.c_int32]
         _lib = L
     return _lib
 

@@ -1,0 +1,79 @@
+"""The C++ host tools that sit on the C ABI: gencordic_amd (the reference's
+command line) and cordic_tb (the reference's acceptance benches)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import quality as Q
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "gencordic_amd")
+TB = os.path.join(ROOT, "tools", "cordic_tb")
+
+
+def test_gencordic_amd_writes_the_reference_header(tmp_path, golden):
+    """sw/Makefile:115-144 command lines, pointed at gencordic_amd."""
+    for name in ("rtl_cordic", "rtl_topolar", "rtl_seqcordic", "rtl_seqpolar",
+                 "cfg2", "cfg3"):
+        e = golden[name]
+        vf = tmp_path / "core.v"
+        r = subprocess.run([GEN] + e["args"].split() + ["-f", str(vf)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        text = (tmp_path / "core.h").read_text()
+        body = re.search(r"#ifndef.*#endif[^\n]*\n", text, re.S).group(0)
+        assert body == e["header"], name
+        os.remove(tmp_path / "core.h")
+
+
+def test_gencordic_amd_errors_like_the_reference():
+    r = subprocess.run([GEN, "-t", "bogus"], capture_output=True, text=True)
+    assert r.returncode != 0 and "ERR" in r.stderr
+    r = subprocess.run([GEN, "-q"], capture_output=True, text=True)
+    assert r.returncode != 0
+    r = subprocess.run([GEN], capture_output=True, text=True)
+    assert r.returncode == 0 and "USAGE" in r.stderr
+    r = subprocess.run([GEN, "-v", "-t", "r2p", "-i", "13", "-o", "13"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "Phase  bits     : 21" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["p2r", "sp2r"])
+def test_cordic_tb_p2r_report(mode):
+    """Same report as bench/cpp/cordic_tb.cpp on the checked-in core."""
+    r = subprocess.run([TB, "-t", mode, "-i", "13", "-o", "13", "-x", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SUCCESS!!" in r.stdout
+    m = dict(avg=float(re.search(r"AVG Err: ([\d.]+)", r.stdout).group(1)),
+             mx=float(re.search(r"MAX Err: ([\d.]+)", r.stdout).group(1)),
+             cnr=float(re.search(r"CNR    : ([\d.]+)", r.stdout).group(1)),
+             sfdr=float(re.search(r"SFDR = +([\d.]+)", r.stdout).group(1)))
+    c = O.config_cli(O.P2R if mode == "p2r" else O.SP2R, 13, 13, 2)
+    ph, x0, y0 = Q.p2r_bench_inputs(c.iw, c.pw)
+    ox, oy = O.rotate(c, x0, y0, ph)
+    q = Q.p2r_quality(c, ph, x0, y0, ox, oy)
+    assert abs(m["avg"] - q["averr"]) < 1e-5 and abs(m["mx"] - q["mxerr"]) < 1e-5
+    assert abs(m["cnr"] - q["cnr"]) < 0.01
+    assert abs(m["sfdr"] - Q.sfdr_dbc(ox, oy)) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["r2p", "sr2p"])
+def test_cordic_tb_r2p_report(mode):
+    r = subprocess.run([TB, "-t", mode, "-i", "13", "-o", "13", "-x", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SUCCESS" in r.stdout
+    mxp = float(re.search(r"Max phase     error: ([\d.]+)", r.stdout).group(1))
+    mxv = float(re.search(r"Max magnitude error:\s+([\d.]+)", r.stdout).group(1))
+    c = O.config_cli(O.R2P if mode == "r2p" else O.SR2P, 13, 13, 2)
+    x, y, mg = Q.r2p_bench_inputs(c.iw, c.pw)
+    mag, p = O.topolar(c, x, y)
+    q = Q.r2p_quality(c, x, y, mg, mag, p)
+    assert abs(mxp - q["mxperr"]) < 0.01 and abs(mxv - q["mxverr"]) < 1e-5
