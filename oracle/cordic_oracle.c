@@ -9,7 +9,9 @@
  *
  * Sample-level parity is UNPINNED BY REFERENCE FIXTURES (none exist, and the
  * reference's only executor is a Verilator build that cannot be made here);
- * table/parameter math is pinned against the real generator's output.
+ * it is cross-checked against tests/vsim.py executing the reference's Verilog
+ * text (see the header).  Table/parameter math is pinned against the real
+ * generator's output.
  */
 #include <math.h>
 #include <string.h>

@@ -11,21 +11,27 @@
  * Verilator build of the emitted Verilog, and Verilator is absent here).
  * Every function cites the reference file:line it follows.
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status:
  *   - table / parameter math (angles, gain, variances, WW/PW/NSTAGES
  *     derivation): PINNED against outputs of the real reference generator
  *     built from /root/reference/sw by oracle/Makefile (oracle/_ref/gencordic)
  *     and against the checked-in rtl/{cordic,topolar,seqcordic,seqpolar}.{v,h}
- *     values, committed as fixtures under tests/golden/.
+ *     values, committed as fixtures under tests/golden/gencordic_golden.json.
  *   - per-sample arithmetic (pre-rotation, stages, rounding): the reference
- *     holds NO per-sample golden vectors and its only executor cannot be
- *     built here, so sample-level parity is UNPINNED BY REFERENCE FIXTURES.
- *     It rests on (a) this restatement being literal, (b) the reference's own
- *     pass criteria (bench/cpp/cordic_tb.cpp:285-337,
- *     bench/cpp/topolar_tb.cpp:303-315) evaluated on this oracle's output at
- *     the checked-in configuration, (c) tests/vsim.py, an independent
- *     evaluator that executes the Verilog text emitted by oracle/_ref/gencordic
- *     and must agree with this file sample for sample.
+ *     ships NO per-sample golden vectors and its only executor (a Verilator
+ *     build) cannot be made here, so sample-level parity is UNPINNED BY
+ *     REFERENCE FIXTURES.  What ties it to the reference:
+ *     (a) tests/vsim.py, this project's own small cycle simulator, EXECUTES
+ *         the reference's Verilog text -- rtl/*.v where they lie and whatever
+ *         oracle/_ref/gencordic emits -- clock by clock, and this oracle must
+ *         agree with it sample for sample (tests/test_rtl_vectors.py; the
+ *         resulting vectors are committed as tests/golden/rtl_vectors.json
+ *         with the script that made them);
+ *     (b) the reference's own pass criteria (bench/cpp/cordic_tb.cpp:285-337,
+ *         bench/cpp/topolar_tb.cpp:303-315) evaluated on this oracle's output
+ *         at the checked-in configuration.
+ *     vsim.py is not Verilator and not a reference build; it is a second,
+ *     independent reading of the same text.
  */
 #ifndef CORDIC_ORACLE_H
 #define CORDIC_ORACLE_H

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/rtl_vectors.json: per-sample input/output vectors
+obtained by EXECUTING the Verilog that the real reference generator emits
+(oracle/_ref/gencordic, built from /root/reference/sw by oracle/Makefile) with
+tests/vsim.py, clock by clock, the way the reference's Verilator benches drive
+the cores.  Only data is stored (parameters, inputs, outputs); no Verilog text.
+
+These are NOT fixtures shipped by the reference (it ships none) and vsim.py is
+this project's own simulator, not Verilator: the vectors pin the oracle and the
+GPU engine to the reference's emitted RTL text as read by vsim.py.
+
+Run:  python tests/golden/make_rtl_vectors.py   (needs oracle/_ref/gencordic)
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vsim  # noqa: E402
+
+GEN = os.path.join(ROOT, "oracle", "_ref", "gencordic")
+
+CORES = {
+    # name: (gencordic args, samples)
+    "rtl_cordic":    ("-a -t p2r -i 13 -o 13 -x 2", 1200),
+    "rtl_topolar":   ("-a -t r2p -i 13 -o 13 -x 2", 1200),
+    "rtl_seqcordic": ("-a -t sp2r -i 13 -o 13 -x 2", 300),
+    "rtl_seqpolar":  ("-a -t sr2p -i 13 -o 13 -x 2", 300),
+    "cfg1":          ("-a -t p2r -i 16 -o 16 -p 16 -n 16", 800),
+    "cfg2":          ("-a -t p2r -i 32 -o 32 -p 32 -n 16", 1200),
+    "cfg3":          ("-a -t r2p -i 24 -o 24 -n 20", 1000),
+    "cfg4":          ("-a -t p2r -i 32 -o 32 -p 32 -n 24", 800),
+    "cfg5_seq":      ("-a -t sp2r -i 32 -o 32 -p 32 -n 16", 300),
+    "trunc_p2r":     ("-a -t p2r -i 12 -o 12 -x 0 -p 16", 600),   # WW == OW+1
+    "ow_gt_iw":      ("-a -t p2r -i 10 -o 14 -x 1 -p 18", 600),
+    "iw_gt_ow":      ("-a -t r2p -i 16 -o 9 -x 1", 600),
+    "tiny_wrap":     ("-a -t p2r -i 2 -o 2 -x 0 -p 8 -n 6", 800),  # WW 3: wraps
+    "tiny_r2p":      ("-a -t r2p -i 3 -o 3 -x 0 -p 7 -n 5", 500),
+    "many_stages":   ("-a -t p2r -i 8 -o 8 -x 1 -p 32 -n 30", 500),  # i >= WW skip
+}
+
+
+def emit(args):
+    with tempfile.TemporaryDirectory() as td:
+        vf = os.path.join(td, "core.v")
+        subprocess.run([GEN] + args.split() + ["-c", "-f", vf], check=True,
+                       capture_output=True)
+        v = open(vf).read()
+        h = open(os.path.join(td, "core.h")).read()
+    # sw/basiccordic.cpp:418-419 prints "// }}}" and the always header of the
+    # WW == OW+1 ("No rounding required") branch on ONE line, which comments
+    # the always header out: that core does not elaborate as emitted.  Restore
+    # the evidently intended line break so the branch can be executed.
+    v = v.replace("// }}}\talways", "// }}}\n\talways")
+    return v, h
+
+
+def inputs(rng, iw, pw, n, need_phase):
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x = rng.randint(lo, hi, n)
+    y = rng.randint(lo, hi, n)
+    ph = rng.randint(0, 1 << pw, n, dtype=np.int64)
+    ext = [lo, hi - 1, 0, -1 if iw > 1 else 0, min(1, hi - 1), lo + 1]
+    k = 0
+    for a in ext:
+        for b in ext:
+            if k < n:
+                x[k], y[k] = a, b
+                k += 1
+    if need_phase:
+        q = 1 << max(pw - 3, 0)
+        edges = [(j * q + d) % (1 << pw) for j in range(9) for d in (-1, 0, 1)]
+        for j, e in enumerate(edges):
+            if 40 + j < n:
+                ph[40 + j] = e
+    return x, y, ph
+
+
+def main():
+    if not os.path.exists(GEN):
+        sys.exit("build oracle/_ref/gencordic first (make -C oracle ref)")
+    out = {}
+    rng = np.random.RandomState(20240917)
+    for name, (args, n) in CORES.items():
+        v, h = emit(args)
+        m = vsim.Module(v)
+        iw, pw = m.params["IW"], m.params["PW"]
+        rot = "i_phase" in m.decl
+        x, y, ph = inputs(rng, iw, pw, n, rot)
+        samples = []
+        for i in range(n):
+            s = dict(i_xval=int(x[i]), i_yval=int(y[i]))
+            if rot:
+                s["i_phase"] = int(ph[i])
+            samples.append(s)
+        seq = "i_stb" in m.decl
+        if seq:
+            import re
+            cpo = int(re.search(r"CLOCKS_PER_OUTPUT\t(\d+)", h).group(1))
+            res = vsim.run_sequential(m, samples, cpo)
+        else:
+            res = vsim.run_pipelined(m, samples)
+        e = {"args": args.replace("-a ", ""), "IW": iw, "OW": m.params["OW"],
+             "WW": m.params["WW"], "PW": pw, "x": [int(v) for v in x],
+             "y": [int(v) for v in y]}
+        if rot:
+            e["phase"] = [int(v) for v in ph]
+            e["o_xval"] = [r["o_xval"] for r in res]
+            e["o_yval"] = [r["o_yval"] for r in res]
+        else:
+            e["o_mag"] = [r["o_mag"] for r in res]
+            e["o_phase"] = [r["o_phase"] & ((1 << pw) - 1) for r in res]
+        out[name] = e
+        print(name, n, "samples")
+    with open(os.path.join(HERE, "rtl_vectors.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+"""The oracle (and, on the GPU, the engine) against the reference's RTL text.
+
+tests/golden/rtl_vectors.json holds per-sample vectors produced by executing
+the Verilog emitted by the real reference generator with tests/vsim.py
+(tests/golden/make_rtl_vectors.py).  The live tests below additionally run
+vsim on the checked-in rtl/*.v (when /root/reference is mounted) and on fresh
+parameter sets emitted by oracle/_ref/gencordic (when it is built)."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vsim
+from test_oracle_golden import MODES, parse_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(O.ORACLE_DIR, "_ref", "gencordic")
+REF_RTL = "/root/reference/rtl"
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    with open(os.path.join(ROOT, "tests", "golden", "rtl_vectors.json")) as f:
+        return json.load(f)
+
+
+def oracle_cfg(args):
+    d = parse_args(args)
+    return O.config_cli(d["mode"], d["iw"], d["ow"], d["xtra"], d["pw"], d["n"])
+
+
+def test_oracle_reproduces_every_rtl_vector(vectors):
+    assert len(vectors) >= 15
+    total = 0
+    for name, e in vectors.items():
+        c = oracle_cfg(e["args"])
+        assert (c.iw, c.ow, c.ww, c.pw) == (e["IW"], e["OW"], e["WW"], e["PW"])
+        x = np.array(e["x"], dtype=np.int32)
+        y = np.array(e["y"], dtype=np.int32)
+        if "phase" in e:
+            ox, oy = O.rotate(c, x, y, np.array(e["phase"], dtype=np.uint32))
+            assert ox.tolist() == e["o_xval"], name
+            assert oy.tolist() == e["o_yval"], name
+        else:
+            mag, ph = O.topolar(c, x, y)
+            assert mag.tolist() == e["o_mag"], name
+            assert ph.tolist() == e["o_phase"], name
+        total += len(e["x"])
+    assert total >= 10000
+
+
+def test_vectors_cover_the_corner_semantics(vectors):
+    """The fixture must really exercise what is hard: WW-bit overflow of a
+    tiny core, the WW == OW+1 truncation branch, stages past WW."""
+    t = vectors["tiny_wrap"]
+    assert t["WW"] == 3 and max(abs(v) for v in t["o_xval"]) <= 2
+    assert vectors["trunc_p2r"]["WW"] == vectors["trunc_p2r"]["OW"] + 1
+    assert vectors["many_stages"]["WW"] < 30
+
+
+def drive(m, x, y, ph, cpo=None):
+    samples = []
+    for i in range(len(x)):
+        s = dict(i_xval=int(x[i]), i_yval=int(y[i]))
+        if ph is not None:
+            s["i_phase"] = int(ph[i])
+        samples.append(s)
+    if cpo:
+        return vsim.run_sequential(m, samples, cpo)
+    return vsim.run_pipelined(m, samples)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_RTL), reason="reference not mounted")
+@pytest.mark.parametrize("core,mode,cpo", [("cordic", O.P2R, None),
+                                           ("topolar", O.R2P, None),
+                                           ("seqcordic", O.SP2R, 17),
+                                           ("seqpolar", O.SR2P, 21)])
+def test_checked_in_rtl_executed_by_vsim_equals_oracle(core, mode, cpo):
+    """rtl/{cordic,topolar,seqcordic,seqpolar}.v, read where they lie."""
+    m = vsim.Module(open(os.path.join(REF_RTL, core + ".v")).read())
+    c = O.config_cli(mode, 13, 13, 2)
+    assert (m.params["IW"], m.params["WW"], m.params["PW"]) == (c.iw, c.ww, c.pw)
+    rng = np.random.RandomState(5)
+    n = 2500 if cpo is None else 400
+    x = rng.randint(-4096, 4096, n)
+    y = rng.randint(-4096, 4096, n)
+    ph = rng.randint(0, 1 << c.pw, n)
+    x[:4], y[:4] = [-4096, 4095, 0, -4096], [-4096, 4095, 0, 4095]
+    rot = mode in (O.P2R, O.SP2R)
+    res = drive(m, x, y, ph if rot else None, cpo)
+    if rot:
+        ox, oy = O.rotate(c, x.astype(np.int32), y.astype(np.int32),
+                          ph.astype(np.uint32))
+        assert [r["o_xval"] for r in res] == ox.tolist()
+        assert [r["o_yval"] for r in res] == oy.tolist()
+    else:
+        mag, p = O.topolar(c, x.astype(np.int32), y.astype(np.int32))
+        assert [r["o_mag"] for r in res] == mag.tolist()
+        assert [r["o_phase"] & ((1 << c.pw) - 1) for r in res] == p.tolist()
+
+
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref not built")
+def test_fresh_generator_output_executed_by_vsim_equals_oracle(tmp_path):
+    """Random parameter sets: emit with the real generator, execute the text,
+    compare with the oracle."""
+    rng = np.random.RandomState(77)
+    done = 0
+    for trial in range(40):
+        mode = ["p2r", "r2p", "sp2r", "sr2p"][rng.randint(4)]
+        iw, ow = int(rng.randint(2, 25)), int(rng.randint(2, 25))
+        xtra = int(rng.randint(0, 4))
+        pw = int(rng.randint(6, 33))
+        ns = int(rng.randint(3, 26))
+        try:
+            c = O.config_cli(MODES[mode], iw, ow, xtra, pw, ns)
+        except ValueError:
+            continue
+        if mode == "p2r" and c.ww == c.ow + 1:
+            continue        # emitted text does not elaborate (see make_rtl_vectors)
+        vf = tmp_path / "core.v"
+        subprocess.run([GEN, "-a", "-c", "-t", mode, "-i", str(iw), "-o",
+                        str(ow), "-x", str(xtra), "-p", str(pw), "-n", str(ns),
+                        "-f", str(vf)], check=True, capture_output=True)
+        m = vsim.Module(vf.read_text())
+        h = (tmp_path / "core.h").read_text()
+        cpo = None
+        if mode in ("sp2r", "sr2p"):
+            cpo = int(re.search(r"CLOCKS_PER_OUTPUT\t(\d+)", h).group(1))
+            assert cpo == c.clocks_per_output
+        n = 250 if cpo is None else 60
+        lo, hi = -(1 << (iw - 1)), 1 << (iw - 1)
+        x = rng.randint(lo, hi, n)
+        y = rng.randint(lo, hi, n)
+        ph = rng.randint(0, 1 << pw, n, dtype=np.int64)
+        x[:3], y[:3] = [lo, hi - 1, lo], [lo, hi - 1, hi - 1]
+        rot = mode in ("p2r", "sp2r")
+        res = drive(m, x, y, ph if rot else None, cpo)
+        if rot:
+            ox, oy = O.rotate(c, x.astype(np.int32), y.astype(np.int32),
+                              ph.astype(np.uint32))
+            assert [r["o_xval"] for r in res] == ox.tolist(), (mode, iw, ow, xtra, pw, ns)
+            assert [r["o_yval"] for r in res] == oy.tolist(), (mode, iw, ow, xtra, pw, ns)
+        else:
+            mag, p = O.topolar(c, x.astype(np.int32), y.astype(np.int32))
+            assert [r["o_mag"] for r in res] == mag.tolist(), (mode, iw, ow, xtra, pw, ns)
+            assert [r["o_phase"] & ((1 << pw) - 1) for r in res] == p.tolist()
+        done += 1
+    assert done >= 20
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_every_rtl_vector(vectors):
+    """The engine against the RTL-derived vectors directly (not via the
+    oracle): every kernel path that these cores select."""
+    import cordic_amd as ca
+    from gpu_util import gpu_p2r, gpu_r2p
+    for name, e in vectors.items():
+        d = parse_args(e["args"])
+        cfg = ca.Config.from_cli(d["mode"], d["iw"], d["ow"], d["xtra"],
+                                 d["pw"], d["n"])
+        x = np.array(e["x"], dtype=np.int32)
+        y = np.array(e["y"], dtype=np.int32)
+        if "phase" in e:
+            gx, gy = gpu_p2r(cfg, x, y, np.array(e["phase"], dtype=np.uint32))
+            assert gx.tolist() == e["o_xval"], name
+            assert gy.tolist() == e["o_yval"], name
+        else:
+            gm, gp = gpu_r2p(cfg, x, y)
+            assert gm.tolist() == e["o_mag"], name
+            assert gp.tolist() == e["o_phase"], name
