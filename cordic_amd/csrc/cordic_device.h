@@ -382,6 +382,17 @@ __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &k
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
+// Input loads: streamed once, never re-read (-DCORDIC_NT_LOADS: non-temporal).
+template <typename V>
+__device__ __forceinline__ V load_in(const V *src)
+{
+#ifdef CORDIC_NT_LOADS
+	return __builtin_nontemporal_load(src);
+#else
+	return *src;
+#endif
+}
+
 // Output stores.  Outputs are written once and never re-read by the engine.
 // Measured on MI355X: the non-temporal form is as good or better for the
 // VALU-bound kernels (full recurrence), while the table-seeded kernel, which
@@ -628,16 +639,18 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 
 	const size_t stride = (size_t)gridDim.x * kSeedBlock;
 	size_t g = (size_t)blockIdx.x * kSeedBlock + threadIdx.x;
+	// software prefetch (see rotator_unrolled); two passes ahead and
+	// non-temporal loads measured no better (profiles/r01 notes)
 	u32x4 nph{};
 	if constexpr (FEED != Feed::Nco_ConstXY)
 		if (g < nvec)
-			nph = phin[g];
+			nph = load_in(&phin[g]);
 	for (; g < nvec; g += stride) {
 		const u32x4 tph = nph;
 		if constexpr (FEED != Feed::Nco_ConstXY) {
 			const size_t gn = g + stride;
 			if (gn < nvec)
-				nph = phin[gn];
+				nph = load_in(&phin[gn]);
 		}
 		uint32_t P[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
