@@ -42,6 +42,9 @@ WORKLOADS = {
                  "sin/cos, phase ramp n<<2, x=2^31-1, y=0"),
     "cfg4": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, 24), bytes=12,
                  shift=0, desc="basiccordic 24-stage, 32-bit, phase ramp n"),
+    "p2rxy": dict(kind="p2rxy", cli=("p2r", 32, 32, 2, 32, 16), bytes=20,
+                  shift=2, desc="basiccordic 16-stage, 32-bit, per-sample x, y "
+                  "and phase vectors (cordic_p2r)"),
     "cfg3": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, 20), bytes=16,
                  desc="topolar 20-stage, 24-bit I/Q ramps -> mag + phase"),
     "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
@@ -164,6 +167,18 @@ def main():
 
         def step():
             plan.p2r_const(x0, y0, phase, a, b)
+    elif w["kind"] == "p2rxy":
+        phase = torch.empty(n, dtype=torch.int32, device=dev)
+        xin = torch.empty(n, dtype=torch.int32, device=dev)
+        yin = torch.empty(n, dtype=torch.int32, device=dev)
+        ca.fill_phase_ramp(phase, index0, w["shift"])
+        ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
+        if args.input == "random":
+            gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+            phase.random_(-2**31, 2**31 - 1, generator=gen)
+
+        def step():
+            ca.p2r(cfg, xin, yin, phase, a, b)
     elif w["kind"] == "r2p":
         xin = torch.empty(n, dtype=torch.int32, device=dev)
         yin = torch.empty(n, dtype=torch.int32, device=dev)
@@ -229,6 +244,10 @@ def main():
             ra, rb = O.topolar(ocfg, xin[ti].cpu().numpy(),
                                yin[ti].cpu().numpy())
             rb = rb.view(np.int32)
+        elif w["kind"] == "p2rxy":
+            ra, rb = O.rotate(ocfg, xin[ti].cpu().numpy(),
+                              yin[ti].cpu().numpy(),
+                              phase[ti].cpu().numpy().view(np.uint32))
         elif w["kind"] == "p2r":
             ra, rb = O.rotate(ocfg, x0, y0,
                               phase[ti].cpu().numpy().view(np.uint32))
@@ -317,7 +336,7 @@ def main():
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
-                    "unrolled" if (args.no_seed or w["kind"] == "r2p")
+                    "unrolled" if (args.no_seed or w["kind"] in ("r2p", "p2rxy"))
                     else "seeded(9)+unrolled"),
                 "input": args.input,
                 "parallelism": "shard%d" % world,

@@ -312,6 +312,10 @@ template <int LJ, int NLIVE, int I> struct RotChainLJ {
 
 // rtl/cordic.v:131-188 on a left-justified phase: q = quadrant of
 // (phase + 45 deg); rotate the vector by q * 90 deg, remove q * 2^(PW-2).
+// Written with sign masks, not selects: v_cndmask_b32 measured ~23 cycles per
+// wave-instruction on MI355X (profiles/valu_microbench_r01.txt), ten times a
+// plain VOP2.
+//   q = 1, 3: swap e_x / e_y;   q = 1, 2: negate x;   q = 2, 3: negate y
 template <typename T>
 __device__ __forceinline__ void fold_octant(T ex, T ey, uint32_t P, T &x, T &y,
 		uint32_t &p)
@@ -319,13 +323,13 @@ __device__ __forceinline__ void fold_octant(T ex, T ey, uint32_t P, T &x, T &y,
 	using U = typename std::make_unsigned<T>::type;
 	const uint32_t q = (P + 0x20000000u) >> 30;
 	p = P - (q << 30);
-	const bool swap = (q & 1u) != 0;
-	const T a = swap ? ey : ex;
-	const T b = swap ? ex : ey;
-	const bool negx = (q == 1u) || (q == 2u);
-	const bool negy = (q >= 2u);
-	x = negx ? (T)((U)0 - (U)a) : a;
-	y = negy ? (T)((U)0 - (U)b) : b;
+	const U ms = (U)(T)(-(int32_t)(q & 1u));		// all ones: swap
+	const U mx = (U)(T)(-(int32_t)(((q + 1u) >> 1) & 1u));	// negate x
+	const U my = (U)(T)(-(int32_t)(q >> 1));		// negate y
+	const U d = ((U)ex ^ (U)ey) & ms;
+	const U a = (U)ex ^ d, b = (U)ey ^ d;
+	x = (T)((a ^ mx) - mx);
+	y = (T)((b ^ my) - my);
 }
 
 // rtl/topolar.v:122-152.  With ax = |e_x|, ay = |e_y| (two's complement

@@ -1,11 +1,13 @@
-// valu_microbench.hip -- throughput of the integer VALU instructions the
-// CORDIC stage can be built from, measured on the machine it runs on.
-// Decides the shape of the 64-bit (WW=35) micro-rotation: native 64-bit
-// shift/add (v_ashrrev_i64, v_lshl_add_u64) versus 32-bit pairs
-// (v_alignbit_b32 + v_ashrrev_i32, v_add_co_u32 + v_addc_co_u32).
+// valu_microbench.hip -- one kernel per instruction, all of the same shape.
+//
+// Throughput of the integer VALU instructions the CORDIC stage can be built
+// from, measured on the machine it runs on.  Every kernel issues 16
+// independent chains of ONE instruction inside a single asm statement (so the
+// compiler adds no s_nop padding between them), 2048 times, from 8 waves per
+// SIMD.  Reported: wave-instructions per second per SIMD expressed as cycles
+// per instruction at the 2.4 GHz peak clock (the chip may clock lower).
 //
 //   hipcc --offload-arch=gfx950 -O3 -o valu_microbench valu_microbench.hip
-//   ./valu_microbench            # prints one line per instruction
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -16,90 +18,487 @@
 
 constexpr int kIters = 2048;
 constexpr int kChains = 16;
-
-// 32-bit ops: 16 independent chains a[i] = op(a[i], b, c)
-#define KERNEL32(NAME, ASM) \
-__global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t b, uint32_t c) { \
-	uint32_t a[kChains]; \
-	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i; \
-	uint32_t vb = b + threadIdx.x, vc = c ^ threadIdx.x; \
-	for (int it = 0; it < kIters; it++) { \
-		_Pragma("unroll") \
-		for (int i = 0; i < kChains; i++) \
-			asm volatile(ASM : "+v"(a[i]) : "v"(vb), "v"(vc) : "vcc", "s10", "s11"); \
-	} \
-	uint32_t s = 0; \
-	for (int i = 0; i < kChains; i++) s ^= a[i]; \
-	out[blockIdx.x * 256 + threadIdx.x] = s; \
+__global__ __launch_bounds__(256) void k_add_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_add_u32 %0, %0, %16\n\tv_add_u32 %1, %1, %16\n\tv_add_u32 %2, %2, %16\n\tv_add_u32 %3, %3, %16\n\tv_add_u32 %4, %4, %16\n\tv_add_u32 %5, %5, %16\n\tv_add_u32 %6, %6, %16\n\tv_add_u32 %7, %7, %16\n\tv_add_u32 %8, %8, %16\n\tv_add_u32 %9, %9, %16\n\tv_add_u32 %10, %10, %16\n\tv_add_u32 %11, %11, %16\n\tv_add_u32 %12, %12, %16\n\tv_add_u32 %13, %13, %16\n\tv_add_u32 %14, %14, %16\n\tv_add_u32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-
-#define KERNEL64(NAME, ASM) \
-__global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t b, uint32_t c) { \
-	uint64_t a[kChains]; \
-	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i; \
-	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x; \
-	uint32_t vc = c ^ threadIdx.x; \
-	for (int it = 0; it < kIters; it++) { \
-		_Pragma("unroll") \
-		for (int i = 0; i < kChains; i++) \
-			asm volatile(ASM : "+v"(a[i]) : "v"(vb), "v"(vc) : "vcc", "s10", "s11"); \
-	} \
-	uint64_t s = 0; \
-	for (int i = 0; i < kChains; i++) s ^= a[i]; \
-	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32)); \
+__global__ __launch_bounds__(256) void k_sub_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_sub_u32 %0, %0, %16\n\tv_sub_u32 %1, %1, %16\n\tv_sub_u32 %2, %2, %16\n\tv_sub_u32 %3, %3, %16\n\tv_sub_u32 %4, %4, %16\n\tv_sub_u32 %5, %5, %16\n\tv_sub_u32 %6, %6, %16\n\tv_sub_u32 %7, %7, %16\n\tv_sub_u32 %8, %8, %16\n\tv_sub_u32 %9, %9, %16\n\tv_sub_u32 %10, %10, %16\n\tv_sub_u32 %11, %11, %16\n\tv_sub_u32 %12, %12, %16\n\tv_sub_u32 %13, %13, %16\n\tv_sub_u32 %14, %14, %16\n\tv_sub_u32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-
-KERNEL32(k_add_u32,     "v_add_u32 %0, %0, %1")
-KERNEL32(k_sub_u32,     "v_sub_u32 %0, %0, %1")
-KERNEL32(k_xor_b32,     "v_xor_b32 %0, %0, %1")
-KERNEL32(k_not_b32,     "v_not_b32 %0, %0")
-KERNEL32(k_ashr_i32,    "v_ashrrev_i32 %0, 3, %0")
-KERNEL32(k_alignbit,    "v_alignbit_b32 %0, %1, %0, 3")
-KERNEL32(k_xad_u32,     "v_xad_u32 %0, %0, %1, %2")
-KERNEL32(k_add3_u32,    "v_add3_u32 %0, %0, %1, %2")
-KERNEL32(k_bfe_i32,     "v_bfe_i32 %0, %0, 1, 30")
-KERNEL32(k_and_or,      "v_and_or_b32 %0, %0, %1, %2")
-KERNEL32(k_lshl_add,    "v_lshl_add_u32 %0, %0, 1, %1")
-KERNEL32(k_mul_lo,      "v_mul_lo_u32 %0, %0, %1")
-KERNEL32(k_mad_u24,     "v_mad_u32_u24 %0, %0, %1, %2")
-KERNEL32(k_cndmask,     "v_cndmask_b32 %0, %0, %1, vcc")
-KERNEL32(k_cmp_gt,      "v_cmp_gt_i32 vcc, %0, %1\n\tv_add_u32 %0, %0, %2")
-KERNEL32(k_pk_add_u16,  "v_pk_add_u16 %0, %0, %1")
-KERNEL32(k_pk_ashr_i16, "v_pk_ashrrev_i16 %0, 3, %0")
-KERNEL32(k_mov_dpp,     "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-KERNEL32(k_fma_f32,     "v_fma_f32 %0, %0, %1, %2")
-KERNEL32(k_or_b32,      "v_or_b32 %0, %0, %1")
-KERNEL32(k_lshlrev_b32, "v_lshlrev_b32 %0, 1, %0")
-KERNEL32(k_min_i32,     "v_min_i32 %0, %0, %1")
-KERNEL32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
-KERNEL32(k_mul_i32_i24, "v_mul_i32_i24 %0, %0, %1")
-KERNEL32(k_bitop3,      "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
-KERNEL32(k_perm_b32,    "v_perm_b32 %0, %0, %1, %2")
-KERNEL32(k_med3_i32,    "v_med3_i32 %0, %0, %1, %2")
-KERNEL32(k_xor_inline,  "v_xor_b32 %0, -2, %0")
-KERNEL32(k_add_e64,     "v_add_u32_e64 %0, %0, %1")
-KERNEL32(k_fmac_f32,    "v_fmac_f32 %0, %1, %2")
-KERNEL32(k_pk_fma_f32x, "v_add_f32 %0, %0, %1")
-// carry chain pair: lo += b (carry to vcc), hi(%2 reused) += 0 + carry.
-// two wait states are owed between the VCC write and the VCC read on gfx940+,
-// filled here with the two ops of the *other* half of the pair pattern.
-KERNEL32(k_addco_pair,  "v_add_co_u32 %0, vcc, %0, %1\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc")
-KERNEL32(k_addco_only,  "v_add_co_u32 %0, vcc, %0, %1")
-KERNEL32(k_addc_only,   "v_addc_co_u32 %0, vcc, %0, %1, vcc")
-KERNEL32(k_subb_e64,    "v_subb_co_u32 %0, s[10:11], %0, %1, s[10:11]")
-
-KERNEL64(k_ashr_i64,    "v_ashrrev_i64 %0, 3, %0")
-KERNEL64(k_lshr_b64,    "v_lshrrev_b64 %0, 3, %0")
-KERNEL64(k_lshl_add_u64,"v_lshl_add_u64 %0, %0, 0, %1")
-KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %2, %2, %0")
-KERNEL64(k_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %2, %2, %0")
-KERNEL64(k_mad_i64_sgpr,"v_mad_i64_i32 %0, s[10:11], %2, %2, %0")
-KERNEL64(k_pk_add_f32,  "v_pk_add_f32 %0, %0, %1")
-KERNEL64(k_mov_b64,     "v_mov_b64 %0, %1")
-KERNEL64(k_add_f64,     "v_add_f64 %0, %0, %1")
-KERNEL64(k_fma_f64,     "v_fma_f64 %0, %0, %1, %1")
-
-struct Case { const char *name; void (*fn)(uint32_t *, uint32_t, uint32_t); int instr; };
+__global__ __launch_bounds__(256) void k_xor_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_xor_b32 %0, %0, %16\n\tv_xor_b32 %1, %1, %16\n\tv_xor_b32 %2, %2, %16\n\tv_xor_b32 %3, %3, %16\n\tv_xor_b32 %4, %4, %16\n\tv_xor_b32 %5, %5, %16\n\tv_xor_b32 %6, %6, %16\n\tv_xor_b32 %7, %7, %16\n\tv_xor_b32 %8, %8, %16\n\tv_xor_b32 %9, %9, %16\n\tv_xor_b32 %10, %10, %16\n\tv_xor_b32 %11, %11, %16\n\tv_xor_b32 %12, %12, %16\n\tv_xor_b32 %13, %13, %16\n\tv_xor_b32 %14, %14, %16\n\tv_xor_b32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_or_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_or_b32 %0, %0, %16\n\tv_or_b32 %1, %1, %16\n\tv_or_b32 %2, %2, %16\n\tv_or_b32 %3, %3, %16\n\tv_or_b32 %4, %4, %16\n\tv_or_b32 %5, %5, %16\n\tv_or_b32 %6, %6, %16\n\tv_or_b32 %7, %7, %16\n\tv_or_b32 %8, %8, %16\n\tv_or_b32 %9, %9, %16\n\tv_or_b32 %10, %10, %16\n\tv_or_b32 %11, %11, %16\n\tv_or_b32 %12, %12, %16\n\tv_or_b32 %13, %13, %16\n\tv_or_b32 %14, %14, %16\n\tv_or_b32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_not_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_not_b32 %0, %0\n\tv_not_b32 %1, %1\n\tv_not_b32 %2, %2\n\tv_not_b32 %3, %3\n\tv_not_b32 %4, %4\n\tv_not_b32 %5, %5\n\tv_not_b32 %6, %6\n\tv_not_b32 %7, %7\n\tv_not_b32 %8, %8\n\tv_not_b32 %9, %9\n\tv_not_b32 %10, %10\n\tv_not_b32 %11, %11\n\tv_not_b32 %12, %12\n\tv_not_b32 %13, %13\n\tv_not_b32 %14, %14\n\tv_not_b32 %15, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_ashrrev_i32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_ashrrev_i32 %0, 3, %0\n\tv_ashrrev_i32 %1, 3, %1\n\tv_ashrrev_i32 %2, 3, %2\n\tv_ashrrev_i32 %3, 3, %3\n\tv_ashrrev_i32 %4, 3, %4\n\tv_ashrrev_i32 %5, 3, %5\n\tv_ashrrev_i32 %6, 3, %6\n\tv_ashrrev_i32 %7, 3, %7\n\tv_ashrrev_i32 %8, 3, %8\n\tv_ashrrev_i32 %9, 3, %9\n\tv_ashrrev_i32 %10, 3, %10\n\tv_ashrrev_i32 %11, 3, %11\n\tv_ashrrev_i32 %12, 3, %12\n\tv_ashrrev_i32 %13, 3, %13\n\tv_ashrrev_i32 %14, 3, %14\n\tv_ashrrev_i32 %15, 3, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_lshrrev_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_lshrrev_b32 %0, 3, %0\n\tv_lshrrev_b32 %1, 3, %1\n\tv_lshrrev_b32 %2, 3, %2\n\tv_lshrrev_b32 %3, 3, %3\n\tv_lshrrev_b32 %4, 3, %4\n\tv_lshrrev_b32 %5, 3, %5\n\tv_lshrrev_b32 %6, 3, %6\n\tv_lshrrev_b32 %7, 3, %7\n\tv_lshrrev_b32 %8, 3, %8\n\tv_lshrrev_b32 %9, 3, %9\n\tv_lshrrev_b32 %10, 3, %10\n\tv_lshrrev_b32 %11, 3, %11\n\tv_lshrrev_b32 %12, 3, %12\n\tv_lshrrev_b32 %13, 3, %13\n\tv_lshrrev_b32 %14, 3, %14\n\tv_lshrrev_b32 %15, 3, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_lshlrev_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_lshlrev_b32 %0, 1, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_lshlrev_b32 %2, 1, %2\n\tv_lshlrev_b32 %3, 1, %3\n\tv_lshlrev_b32 %4, 1, %4\n\tv_lshlrev_b32 %5, 1, %5\n\tv_lshlrev_b32 %6, 1, %6\n\tv_lshlrev_b32 %7, 1, %7\n\tv_lshlrev_b32 %8, 1, %8\n\tv_lshlrev_b32 %9, 1, %9\n\tv_lshlrev_b32 %10, 1, %10\n\tv_lshlrev_b32 %11, 1, %11\n\tv_lshlrev_b32 %12, 1, %12\n\tv_lshlrev_b32 %13, 1, %13\n\tv_lshlrev_b32 %14, 1, %14\n\tv_lshlrev_b32 %15, 1, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_add_u32_e64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_add_u32_e64 %0, %0, %16\n\tv_add_u32_e64 %1, %1, %16\n\tv_add_u32_e64 %2, %2, %16\n\tv_add_u32_e64 %3, %3, %16\n\tv_add_u32_e64 %4, %4, %16\n\tv_add_u32_e64 %5, %5, %16\n\tv_add_u32_e64 %6, %6, %16\n\tv_add_u32_e64 %7, %7, %16\n\tv_add_u32_e64 %8, %8, %16\n\tv_add_u32_e64 %9, %9, %16\n\tv_add_u32_e64 %10, %10, %16\n\tv_add_u32_e64 %11, %11, %16\n\tv_add_u32_e64 %12, %12, %16\n\tv_add_u32_e64 %13, %13, %16\n\tv_add_u32_e64 %14, %14, %16\n\tv_add_u32_e64 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_min_i32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_min_i32 %0, %0, %16\n\tv_min_i32 %1, %1, %16\n\tv_min_i32 %2, %2, %16\n\tv_min_i32 %3, %3, %16\n\tv_min_i32 %4, %4, %16\n\tv_min_i32 %5, %5, %16\n\tv_min_i32 %6, %6, %16\n\tv_min_i32 %7, %7, %16\n\tv_min_i32 %8, %8, %16\n\tv_min_i32 %9, %9, %16\n\tv_min_i32 %10, %10, %16\n\tv_min_i32 %11, %11, %16\n\tv_min_i32 %12, %12, %16\n\tv_min_i32 %13, %13, %16\n\tv_min_i32 %14, %14, %16\n\tv_min_i32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_mul_u32_u24(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mul_u32_u24 %0, %0, %16\n\tv_mul_u32_u24 %1, %1, %16\n\tv_mul_u32_u24 %2, %2, %16\n\tv_mul_u32_u24 %3, %3, %16\n\tv_mul_u32_u24 %4, %4, %16\n\tv_mul_u32_u24 %5, %5, %16\n\tv_mul_u32_u24 %6, %6, %16\n\tv_mul_u32_u24 %7, %7, %16\n\tv_mul_u32_u24 %8, %8, %16\n\tv_mul_u32_u24 %9, %9, %16\n\tv_mul_u32_u24 %10, %10, %16\n\tv_mul_u32_u24 %11, %11, %16\n\tv_mul_u32_u24 %12, %12, %16\n\tv_mul_u32_u24 %13, %13, %16\n\tv_mul_u32_u24 %14, %14, %16\n\tv_mul_u32_u24 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_fma_f32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_fma_f32 %0, %0, %16, %17\n\tv_fma_f32 %1, %1, %16, %17\n\tv_fma_f32 %2, %2, %16, %17\n\tv_fma_f32 %3, %3, %16, %17\n\tv_fma_f32 %4, %4, %16, %17\n\tv_fma_f32 %5, %5, %16, %17\n\tv_fma_f32 %6, %6, %16, %17\n\tv_fma_f32 %7, %7, %16, %17\n\tv_fma_f32 %8, %8, %16, %17\n\tv_fma_f32 %9, %9, %16, %17\n\tv_fma_f32 %10, %10, %16, %17\n\tv_fma_f32 %11, %11, %16, %17\n\tv_fma_f32 %12, %12, %16, %17\n\tv_fma_f32 %13, %13, %16, %17\n\tv_fma_f32 %14, %14, %16, %17\n\tv_fma_f32 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_fmac_f32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_fmac_f32 %0, %16, %17\n\tv_fmac_f32 %1, %16, %17\n\tv_fmac_f32 %2, %16, %17\n\tv_fmac_f32 %3, %16, %17\n\tv_fmac_f32 %4, %16, %17\n\tv_fmac_f32 %5, %16, %17\n\tv_fmac_f32 %6, %16, %17\n\tv_fmac_f32 %7, %16, %17\n\tv_fmac_f32 %8, %16, %17\n\tv_fmac_f32 %9, %16, %17\n\tv_fmac_f32 %10, %16, %17\n\tv_fmac_f32 %11, %16, %17\n\tv_fmac_f32 %12, %16, %17\n\tv_fmac_f32 %13, %16, %17\n\tv_fmac_f32 %14, %16, %17\n\tv_fmac_f32 %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_bitop3_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_bitop3_b32 %0, %0, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %1, %1, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %2, %2, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %3, %3, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %4, %4, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %5, %5, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %6, %6, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %7, %7, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %8, %8, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %9, %9, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %10, %10, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %11, %11, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %12, %12, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %13, %13, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %14, %14, %16, %17 bitop3:0x96\n\tv_bitop3_b32 %15, %15, %16, %17 bitop3:0x96"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_alignbit_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_alignbit_b32 %0, %16, %0, 3\n\tv_alignbit_b32 %1, %16, %1, 3\n\tv_alignbit_b32 %2, %16, %2, 3\n\tv_alignbit_b32 %3, %16, %3, 3\n\tv_alignbit_b32 %4, %16, %4, 3\n\tv_alignbit_b32 %5, %16, %5, 3\n\tv_alignbit_b32 %6, %16, %6, 3\n\tv_alignbit_b32 %7, %16, %7, 3\n\tv_alignbit_b32 %8, %16, %8, 3\n\tv_alignbit_b32 %9, %16, %9, 3\n\tv_alignbit_b32 %10, %16, %10, 3\n\tv_alignbit_b32 %11, %16, %11, 3\n\tv_alignbit_b32 %12, %16, %12, 3\n\tv_alignbit_b32 %13, %16, %13, 3\n\tv_alignbit_b32 %14, %16, %14, 3\n\tv_alignbit_b32 %15, %16, %15, 3"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_xad_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_xad_u32 %0, %0, %16, %17\n\tv_xad_u32 %1, %1, %16, %17\n\tv_xad_u32 %2, %2, %16, %17\n\tv_xad_u32 %3, %3, %16, %17\n\tv_xad_u32 %4, %4, %16, %17\n\tv_xad_u32 %5, %5, %16, %17\n\tv_xad_u32 %6, %6, %16, %17\n\tv_xad_u32 %7, %7, %16, %17\n\tv_xad_u32 %8, %8, %16, %17\n\tv_xad_u32 %9, %9, %16, %17\n\tv_xad_u32 %10, %10, %16, %17\n\tv_xad_u32 %11, %11, %16, %17\n\tv_xad_u32 %12, %12, %16, %17\n\tv_xad_u32 %13, %13, %16, %17\n\tv_xad_u32 %14, %14, %16, %17\n\tv_xad_u32 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_add3_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_add3_u32 %0, %0, %16, %17\n\tv_add3_u32 %1, %1, %16, %17\n\tv_add3_u32 %2, %2, %16, %17\n\tv_add3_u32 %3, %3, %16, %17\n\tv_add3_u32 %4, %4, %16, %17\n\tv_add3_u32 %5, %5, %16, %17\n\tv_add3_u32 %6, %6, %16, %17\n\tv_add3_u32 %7, %7, %16, %17\n\tv_add3_u32 %8, %8, %16, %17\n\tv_add3_u32 %9, %9, %16, %17\n\tv_add3_u32 %10, %10, %16, %17\n\tv_add3_u32 %11, %11, %16, %17\n\tv_add3_u32 %12, %12, %16, %17\n\tv_add3_u32 %13, %13, %16, %17\n\tv_add3_u32 %14, %14, %16, %17\n\tv_add3_u32 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_bfe_i32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_bfe_i32 %0, %0, 1, 30\n\tv_bfe_i32 %1, %1, 1, 30\n\tv_bfe_i32 %2, %2, 1, 30\n\tv_bfe_i32 %3, %3, 1, 30\n\tv_bfe_i32 %4, %4, 1, 30\n\tv_bfe_i32 %5, %5, 1, 30\n\tv_bfe_i32 %6, %6, 1, 30\n\tv_bfe_i32 %7, %7, 1, 30\n\tv_bfe_i32 %8, %8, 1, 30\n\tv_bfe_i32 %9, %9, 1, 30\n\tv_bfe_i32 %10, %10, 1, 30\n\tv_bfe_i32 %11, %11, 1, 30\n\tv_bfe_i32 %12, %12, 1, 30\n\tv_bfe_i32 %13, %13, 1, 30\n\tv_bfe_i32 %14, %14, 1, 30\n\tv_bfe_i32 %15, %15, 1, 30"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_and_or_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_and_or_b32 %0, %0, %16, %17\n\tv_and_or_b32 %1, %1, %16, %17\n\tv_and_or_b32 %2, %2, %16, %17\n\tv_and_or_b32 %3, %3, %16, %17\n\tv_and_or_b32 %4, %4, %16, %17\n\tv_and_or_b32 %5, %5, %16, %17\n\tv_and_or_b32 %6, %6, %16, %17\n\tv_and_or_b32 %7, %7, %16, %17\n\tv_and_or_b32 %8, %8, %16, %17\n\tv_and_or_b32 %9, %9, %16, %17\n\tv_and_or_b32 %10, %10, %16, %17\n\tv_and_or_b32 %11, %11, %16, %17\n\tv_and_or_b32 %12, %12, %16, %17\n\tv_and_or_b32 %13, %13, %16, %17\n\tv_and_or_b32 %14, %14, %16, %17\n\tv_and_or_b32 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_lshl_add_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_lshl_add_u32 %0, %0, 1, %16\n\tv_lshl_add_u32 %1, %1, 1, %16\n\tv_lshl_add_u32 %2, %2, 1, %16\n\tv_lshl_add_u32 %3, %3, 1, %16\n\tv_lshl_add_u32 %4, %4, 1, %16\n\tv_lshl_add_u32 %5, %5, 1, %16\n\tv_lshl_add_u32 %6, %6, 1, %16\n\tv_lshl_add_u32 %7, %7, 1, %16\n\tv_lshl_add_u32 %8, %8, 1, %16\n\tv_lshl_add_u32 %9, %9, 1, %16\n\tv_lshl_add_u32 %10, %10, 1, %16\n\tv_lshl_add_u32 %11, %11, 1, %16\n\tv_lshl_add_u32 %12, %12, 1, %16\n\tv_lshl_add_u32 %13, %13, 1, %16\n\tv_lshl_add_u32 %14, %14, 1, %16\n\tv_lshl_add_u32 %15, %15, 1, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_perm_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_perm_b32 %0, %0, %16, %17\n\tv_perm_b32 %1, %1, %16, %17\n\tv_perm_b32 %2, %2, %16, %17\n\tv_perm_b32 %3, %3, %16, %17\n\tv_perm_b32 %4, %4, %16, %17\n\tv_perm_b32 %5, %5, %16, %17\n\tv_perm_b32 %6, %6, %16, %17\n\tv_perm_b32 %7, %7, %16, %17\n\tv_perm_b32 %8, %8, %16, %17\n\tv_perm_b32 %9, %9, %16, %17\n\tv_perm_b32 %10, %10, %16, %17\n\tv_perm_b32 %11, %11, %16, %17\n\tv_perm_b32 %12, %12, %16, %17\n\tv_perm_b32 %13, %13, %16, %17\n\tv_perm_b32 %14, %14, %16, %17\n\tv_perm_b32 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_mul_lo_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mul_lo_u32 %0, %0, %16\n\tv_mul_lo_u32 %1, %1, %16\n\tv_mul_lo_u32 %2, %2, %16\n\tv_mul_lo_u32 %3, %3, %16\n\tv_mul_lo_u32 %4, %4, %16\n\tv_mul_lo_u32 %5, %5, %16\n\tv_mul_lo_u32 %6, %6, %16\n\tv_mul_lo_u32 %7, %7, %16\n\tv_mul_lo_u32 %8, %8, %16\n\tv_mul_lo_u32 %9, %9, %16\n\tv_mul_lo_u32 %10, %10, %16\n\tv_mul_lo_u32 %11, %11, %16\n\tv_mul_lo_u32 %12, %12, %16\n\tv_mul_lo_u32 %13, %13, %16\n\tv_mul_lo_u32 %14, %14, %16\n\tv_mul_lo_u32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_mad_u32_u24(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_u32_u24 %0, %0, %16, %17\n\tv_mad_u32_u24 %1, %1, %16, %17\n\tv_mad_u32_u24 %2, %2, %16, %17\n\tv_mad_u32_u24 %3, %3, %16, %17\n\tv_mad_u32_u24 %4, %4, %16, %17\n\tv_mad_u32_u24 %5, %5, %16, %17\n\tv_mad_u32_u24 %6, %6, %16, %17\n\tv_mad_u32_u24 %7, %7, %16, %17\n\tv_mad_u32_u24 %8, %8, %16, %17\n\tv_mad_u32_u24 %9, %9, %16, %17\n\tv_mad_u32_u24 %10, %10, %16, %17\n\tv_mad_u32_u24 %11, %11, %16, %17\n\tv_mad_u32_u24 %12, %12, %16, %17\n\tv_mad_u32_u24 %13, %13, %16, %17\n\tv_mad_u32_u24 %14, %14, %16, %17\n\tv_mad_u32_u24 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cndmask_b32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_cndmask_b32 %0, %0, %16, vcc\n\tv_cndmask_b32 %1, %1, %16, vcc\n\tv_cndmask_b32 %2, %2, %16, vcc\n\tv_cndmask_b32 %3, %3, %16, vcc\n\tv_cndmask_b32 %4, %4, %16, vcc\n\tv_cndmask_b32 %5, %5, %16, vcc\n\tv_cndmask_b32 %6, %6, %16, vcc\n\tv_cndmask_b32 %7, %7, %16, vcc\n\tv_cndmask_b32 %8, %8, %16, vcc\n\tv_cndmask_b32 %9, %9, %16, vcc\n\tv_cndmask_b32 %10, %10, %16, vcc\n\tv_cndmask_b32 %11, %11, %16, vcc\n\tv_cndmask_b32 %12, %12, %16, vcc\n\tv_cndmask_b32 %13, %13, %16, vcc\n\tv_cndmask_b32 %14, %14, %16, vcc\n\tv_cndmask_b32 %15, %15, %16, vcc"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cndmask_e64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_cndmask_b32 %0, %0, %16, s[10:11]\n\tv_cndmask_b32 %1, %1, %16, s[10:11]\n\tv_cndmask_b32 %2, %2, %16, s[10:11]\n\tv_cndmask_b32 %3, %3, %16, s[10:11]\n\tv_cndmask_b32 %4, %4, %16, s[10:11]\n\tv_cndmask_b32 %5, %5, %16, s[10:11]\n\tv_cndmask_b32 %6, %6, %16, s[10:11]\n\tv_cndmask_b32 %7, %7, %16, s[10:11]\n\tv_cndmask_b32 %8, %8, %16, s[10:11]\n\tv_cndmask_b32 %9, %9, %16, s[10:11]\n\tv_cndmask_b32 %10, %10, %16, s[10:11]\n\tv_cndmask_b32 %11, %11, %16, s[10:11]\n\tv_cndmask_b32 %12, %12, %16, s[10:11]\n\tv_cndmask_b32 %13, %13, %16, s[10:11]\n\tv_cndmask_b32 %14, %14, %16, s[10:11]\n\tv_cndmask_b32 %15, %15, %16, s[10:11]"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc", "s10", "s11");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_add_co_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_add_co_u32 %0, vcc, %0, %16\n\tv_add_co_u32 %1, vcc, %1, %16\n\tv_add_co_u32 %2, vcc, %2, %16\n\tv_add_co_u32 %3, vcc, %3, %16\n\tv_add_co_u32 %4, vcc, %4, %16\n\tv_add_co_u32 %5, vcc, %5, %16\n\tv_add_co_u32 %6, vcc, %6, %16\n\tv_add_co_u32 %7, vcc, %7, %16\n\tv_add_co_u32 %8, vcc, %8, %16\n\tv_add_co_u32 %9, vcc, %9, %16\n\tv_add_co_u32 %10, vcc, %10, %16\n\tv_add_co_u32 %11, vcc, %11, %16\n\tv_add_co_u32 %12, vcc, %12, %16\n\tv_add_co_u32 %13, vcc, %13, %16\n\tv_add_co_u32 %14, vcc, %14, %16\n\tv_add_co_u32 %15, vcc, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_addc_co_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_addc_co_u32 %0, vcc, %0, %16, vcc\n\tv_addc_co_u32 %1, vcc, %1, %16, vcc\n\tv_addc_co_u32 %2, vcc, %2, %16, vcc\n\tv_addc_co_u32 %3, vcc, %3, %16, vcc\n\tv_addc_co_u32 %4, vcc, %4, %16, vcc\n\tv_addc_co_u32 %5, vcc, %5, %16, vcc\n\tv_addc_co_u32 %6, vcc, %6, %16, vcc\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\tv_addc_co_u32 %8, vcc, %8, %16, vcc\n\tv_addc_co_u32 %9, vcc, %9, %16, vcc\n\tv_addc_co_u32 %10, vcc, %10, %16, vcc\n\tv_addc_co_u32 %11, vcc, %11, %16, vcc\n\tv_addc_co_u32 %12, vcc, %12, %16, vcc\n\tv_addc_co_u32 %13, vcc, %13, %16, vcc\n\tv_addc_co_u32 %14, vcc, %14, %16, vcc\n\tv_addc_co_u32 %15, vcc, %15, %16, vcc"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cmp_gt_i32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_cmp_gt_i32 vcc, %0, %16\n\tv_cmp_gt_i32 vcc, %1, %16\n\tv_cmp_gt_i32 vcc, %2, %16\n\tv_cmp_gt_i32 vcc, %3, %16\n\tv_cmp_gt_i32 vcc, %4, %16\n\tv_cmp_gt_i32 vcc, %5, %16\n\tv_cmp_gt_i32 vcc, %6, %16\n\tv_cmp_gt_i32 vcc, %7, %16\n\tv_cmp_gt_i32 vcc, %8, %16\n\tv_cmp_gt_i32 vcc, %9, %16\n\tv_cmp_gt_i32 vcc, %10, %16\n\tv_cmp_gt_i32 vcc, %11, %16\n\tv_cmp_gt_i32 vcc, %12, %16\n\tv_cmp_gt_i32 vcc, %13, %16\n\tv_cmp_gt_i32 vcc, %14, %16\n\tv_cmp_gt_i32 vcc, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_pk_add_u16(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_pk_add_u16 %0, %0, %16\n\tv_pk_add_u16 %1, %1, %16\n\tv_pk_add_u16 %2, %2, %16\n\tv_pk_add_u16 %3, %3, %16\n\tv_pk_add_u16 %4, %4, %16\n\tv_pk_add_u16 %5, %5, %16\n\tv_pk_add_u16 %6, %6, %16\n\tv_pk_add_u16 %7, %7, %16\n\tv_pk_add_u16 %8, %8, %16\n\tv_pk_add_u16 %9, %9, %16\n\tv_pk_add_u16 %10, %10, %16\n\tv_pk_add_u16 %11, %11, %16\n\tv_pk_add_u16 %12, %12, %16\n\tv_pk_add_u16 %13, %13, %16\n\tv_pk_add_u16 %14, %14, %16\n\tv_pk_add_u16 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_pk_mad_i16(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_pk_mad_i16 %0, %0, %16, %17\n\tv_pk_mad_i16 %1, %1, %16, %17\n\tv_pk_mad_i16 %2, %2, %16, %17\n\tv_pk_mad_i16 %3, %3, %16, %17\n\tv_pk_mad_i16 %4, %4, %16, %17\n\tv_pk_mad_i16 %5, %5, %16, %17\n\tv_pk_mad_i16 %6, %6, %16, %17\n\tv_pk_mad_i16 %7, %7, %16, %17\n\tv_pk_mad_i16 %8, %8, %16, %17\n\tv_pk_mad_i16 %9, %9, %16, %17\n\tv_pk_mad_i16 %10, %10, %16, %17\n\tv_pk_mad_i16 %11, %11, %16, %17\n\tv_pk_mad_i16 %12, %12, %16, %17\n\tv_pk_mad_i16 %13, %13, %16, %17\n\tv_pk_mad_i16 %14, %14, %16, %17\n\tv_pk_mad_i16 %15, %15, %16, %17"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_mov_dpp(uint32_t *out, uint32_t b, uint32_t c) {
+	uint32_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = threadIdx.x * 31 + i;
+	uint32_t vb = b + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint32_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_ashrrev_i64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_ashrrev_i64 %0, 3, %0\n\tv_ashrrev_i64 %1, 3, %1\n\tv_ashrrev_i64 %2, 3, %2\n\tv_ashrrev_i64 %3, 3, %3\n\tv_ashrrev_i64 %4, 3, %4\n\tv_ashrrev_i64 %5, 3, %5\n\tv_ashrrev_i64 %6, 3, %6\n\tv_ashrrev_i64 %7, 3, %7\n\tv_ashrrev_i64 %8, 3, %8\n\tv_ashrrev_i64 %9, 3, %9\n\tv_ashrrev_i64 %10, 3, %10\n\tv_ashrrev_i64 %11, 3, %11\n\tv_ashrrev_i64 %12, 3, %12\n\tv_ashrrev_i64 %13, 3, %13\n\tv_ashrrev_i64 %14, 3, %14\n\tv_ashrrev_i64 %15, 3, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_lshlrev_b64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_lshlrev_b64 %0, 3, %0\n\tv_lshlrev_b64 %1, 3, %1\n\tv_lshlrev_b64 %2, 3, %2\n\tv_lshlrev_b64 %3, 3, %3\n\tv_lshlrev_b64 %4, 3, %4\n\tv_lshlrev_b64 %5, 3, %5\n\tv_lshlrev_b64 %6, 3, %6\n\tv_lshlrev_b64 %7, 3, %7\n\tv_lshlrev_b64 %8, 3, %8\n\tv_lshlrev_b64 %9, 3, %9\n\tv_lshlrev_b64 %10, 3, %10\n\tv_lshlrev_b64 %11, 3, %11\n\tv_lshlrev_b64 %12, 3, %12\n\tv_lshlrev_b64 %13, 3, %13\n\tv_lshlrev_b64 %14, 3, %14\n\tv_lshlrev_b64 %15, 3, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_lshl_add_u64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_lshl_add_u64 %0, %0, 0, %16\n\tv_lshl_add_u64 %1, %1, 0, %16\n\tv_lshl_add_u64 %2, %2, 0, %16\n\tv_lshl_add_u64 %3, %3, 0, %16\n\tv_lshl_add_u64 %4, %4, 0, %16\n\tv_lshl_add_u64 %5, %5, 0, %16\n\tv_lshl_add_u64 %6, %6, 0, %16\n\tv_lshl_add_u64 %7, %7, 0, %16\n\tv_lshl_add_u64 %8, %8, 0, %16\n\tv_lshl_add_u64 %9, %9, 0, %16\n\tv_lshl_add_u64 %10, %10, 0, %16\n\tv_lshl_add_u64 %11, %11, 0, %16\n\tv_lshl_add_u64 %12, %12, 0, %16\n\tv_lshl_add_u64 %13, %13, 0, %16\n\tv_lshl_add_u64 %14, %14, 0, %16\n\tv_lshl_add_u64 %15, %15, 0, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_mad_u64_u32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_u64_u32 %0, vcc, %17, %17, %0\n\tv_mad_u64_u32 %1, vcc, %17, %17, %1\n\tv_mad_u64_u32 %2, vcc, %17, %17, %2\n\tv_mad_u64_u32 %3, vcc, %17, %17, %3\n\tv_mad_u64_u32 %4, vcc, %17, %17, %4\n\tv_mad_u64_u32 %5, vcc, %17, %17, %5\n\tv_mad_u64_u32 %6, vcc, %17, %17, %6\n\tv_mad_u64_u32 %7, vcc, %17, %17, %7\n\tv_mad_u64_u32 %8, vcc, %17, %17, %8\n\tv_mad_u64_u32 %9, vcc, %17, %17, %9\n\tv_mad_u64_u32 %10, vcc, %17, %17, %10\n\tv_mad_u64_u32 %11, vcc, %17, %17, %11\n\tv_mad_u64_u32 %12, vcc, %17, %17, %12\n\tv_mad_u64_u32 %13, vcc, %17, %17, %13\n\tv_mad_u64_u32 %14, vcc, %17, %17, %14\n\tv_mad_u64_u32 %15, vcc, %17, %17, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_mad_i64_i32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_i64_i32 %0, vcc, %17, %17, %0\n\tv_mad_i64_i32 %1, vcc, %17, %17, %1\n\tv_mad_i64_i32 %2, vcc, %17, %17, %2\n\tv_mad_i64_i32 %3, vcc, %17, %17, %3\n\tv_mad_i64_i32 %4, vcc, %17, %17, %4\n\tv_mad_i64_i32 %5, vcc, %17, %17, %5\n\tv_mad_i64_i32 %6, vcc, %17, %17, %6\n\tv_mad_i64_i32 %7, vcc, %17, %17, %7\n\tv_mad_i64_i32 %8, vcc, %17, %17, %8\n\tv_mad_i64_i32 %9, vcc, %17, %17, %9\n\tv_mad_i64_i32 %10, vcc, %17, %17, %10\n\tv_mad_i64_i32 %11, vcc, %17, %17, %11\n\tv_mad_i64_i32 %12, vcc, %17, %17, %12\n\tv_mad_i64_i32 %13, vcc, %17, %17, %13\n\tv_mad_i64_i32 %14, vcc, %17, %17, %14\n\tv_mad_i64_i32 %15, vcc, %17, %17, %15"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_add_f64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_add_f64 %0, %0, %16\n\tv_add_f64 %1, %1, %16\n\tv_add_f64 %2, %2, %16\n\tv_add_f64 %3, %3, %16\n\tv_add_f64 %4, %4, %16\n\tv_add_f64 %5, %5, %16\n\tv_add_f64 %6, %6, %16\n\tv_add_f64 %7, %7, %16\n\tv_add_f64 %8, %8, %16\n\tv_add_f64 %9, %9, %16\n\tv_add_f64 %10, %10, %16\n\tv_add_f64 %11, %11, %16\n\tv_add_f64 %12, %12, %16\n\tv_add_f64 %13, %13, %16\n\tv_add_f64 %14, %14, %16\n\tv_add_f64 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_fma_f64(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_fma_f64 %0, %0, %16, %16\n\tv_fma_f64 %1, %1, %16, %16\n\tv_fma_f64 %2, %2, %16, %16\n\tv_fma_f64 %3, %3, %16, %16\n\tv_fma_f64 %4, %4, %16, %16\n\tv_fma_f64 %5, %5, %16, %16\n\tv_fma_f64 %6, %6, %16, %16\n\tv_fma_f64 %7, %7, %16, %16\n\tv_fma_f64 %8, %8, %16, %16\n\tv_fma_f64 %9, %9, %16, %16\n\tv_fma_f64 %10, %10, %16, %16\n\tv_fma_f64 %11, %11, %16, %16\n\tv_fma_f64 %12, %12, %16, %16\n\tv_fma_f64 %13, %13, %16, %16\n\tv_fma_f64 %14, %14, %16, %16\n\tv_fma_f64 %15, %15, %16, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_pk_add_f32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_pk_add_f32 %0, %0, %16\n\tv_pk_add_f32 %1, %1, %16\n\tv_pk_add_f32 %2, %2, %16\n\tv_pk_add_f32 %3, %3, %16\n\tv_pk_add_f32 %4, %4, %16\n\tv_pk_add_f32 %5, %5, %16\n\tv_pk_add_f32 %6, %6, %16\n\tv_pk_add_f32 %7, %7, %16\n\tv_pk_add_f32 %8, %8, %16\n\tv_pk_add_f32 %9, %9, %16\n\tv_pk_add_f32 %10, %10, %16\n\tv_pk_add_f32 %11, %11, %16\n\tv_pk_add_f32 %12, %12, %16\n\tv_pk_add_f32 %13, %13, %16\n\tv_pk_add_f32 %14, %14, %16\n\tv_pk_add_f32 %15, %15, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+__global__ __launch_bounds__(256) void k_pk_fma_f32(uint32_t *out, uint32_t b, uint32_t c) {
+	uint64_t a[kChains];
+	for (int i = 0; i < kChains; i++) a[i] = ((uint64_t)threadIdx.x << 33) + i;
+	uint64_t vb = ((uint64_t)b << 20) + threadIdx.x;
+	uint32_t vc = c ^ threadIdx.x;
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_pk_fma_f32 %0, %0, %16, %16\n\tv_pk_fma_f32 %1, %1, %16, %16\n\tv_pk_fma_f32 %2, %2, %16, %16\n\tv_pk_fma_f32 %3, %3, %16, %16\n\tv_pk_fma_f32 %4, %4, %16, %16\n\tv_pk_fma_f32 %5, %5, %16, %16\n\tv_pk_fma_f32 %6, %6, %16, %16\n\tv_pk_fma_f32 %7, %7, %16, %16\n\tv_pk_fma_f32 %8, %8, %16, %16\n\tv_pk_fma_f32 %9, %9, %16, %16\n\tv_pk_fma_f32 %10, %10, %16, %16\n\tv_pk_fma_f32 %11, %11, %16, %16\n\tv_pk_fma_f32 %12, %12, %16, %16\n\tv_pk_fma_f32 %13, %13, %16, %16\n\tv_pk_fma_f32 %14, %14, %16, %16\n\tv_pk_fma_f32 %15, %15, %16, %16"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(vb), "v"(vc) : "vcc");
+	uint64_t s = 0;
+	for (int i = 0; i < kChains; i++) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+}
+struct Case { const char *name; void (*fn)(uint32_t *, uint32_t, uint32_t); };
 
 int main()
 {
@@ -109,17 +508,48 @@ int main()
 	const int blocks = cus * 8;		// 8 x 256 threads per CU: 8 waves/SIMD
 	uint32_t *out;
 	CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
-	printf("device %s, %d CUs, clock %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+	printf("device %s, %d CUs, clockRate %d MHz\n", prop.gcnArchName, cus, prop.clockRate / 1000);
 	std::vector<Case> cases = {
-#define C(n, i) { #n, n, i }
-		C(k_add_u32, 1), C(k_sub_u32, 1), C(k_xor_b32, 1), C(k_not_b32, 1),
-		C(k_ashr_i32, 1), C(k_alignbit, 1), C(k_xad_u32, 1), C(k_add3_u32, 1),
-		C(k_bfe_i32, 1), C(k_and_or, 1), C(k_lshl_add, 1), C(k_mul_lo, 1),
-		C(k_mad_u24, 1), C(k_cndmask, 1), C(k_cmp_gt, 2), C(k_pk_add_u16, 1),
-		C(k_pk_ashr_i16, 1), C(k_mov_dpp, 1), C(k_fma_f32, 1), C(k_or_b32, 1), C(k_lshlrev_b32, 1), C(k_min_i32, 1), C(k_mul_u32_u24, 1), C(k_mul_i32_i24, 1), C(k_bitop3, 1), C(k_perm_b32, 1), C(k_med3_i32, 1), C(k_xor_inline, 1), C(k_add_e64, 1), C(k_fmac_f32, 1), C(k_pk_fma_f32x, 1),
-		C(k_addco_pair, 2), C(k_addco_only, 1), C(k_addc_only, 1), C(k_subb_e64, 1),
-		C(k_ashr_i64, 1), C(k_lshr_b64, 1), C(k_lshl_add_u64, 1),
-		C(k_mad_u64_u32, 1), C(k_mad_i64_i32, 1), C(k_mad_i64_sgpr, 1), C(k_pk_add_f32, 1), C(k_mov_b64, 1), C(k_add_f64, 1), C(k_fma_f64, 1),
+		{ "add_u32", k_add_u32 },
+		{ "sub_u32", k_sub_u32 },
+		{ "xor_b32", k_xor_b32 },
+		{ "or_b32", k_or_b32 },
+		{ "not_b32", k_not_b32 },
+		{ "ashrrev_i32", k_ashrrev_i32 },
+		{ "lshrrev_b32", k_lshrrev_b32 },
+		{ "lshlrev_b32", k_lshlrev_b32 },
+		{ "add_u32_e64", k_add_u32_e64 },
+		{ "min_i32", k_min_i32 },
+		{ "mul_u32_u24", k_mul_u32_u24 },
+		{ "fma_f32", k_fma_f32 },
+		{ "fmac_f32", k_fmac_f32 },
+		{ "bitop3_b32", k_bitop3_b32 },
+		{ "alignbit_b32", k_alignbit_b32 },
+		{ "xad_u32", k_xad_u32 },
+		{ "add3_u32", k_add3_u32 },
+		{ "bfe_i32", k_bfe_i32 },
+		{ "and_or_b32", k_and_or_b32 },
+		{ "lshl_add_u32", k_lshl_add_u32 },
+		{ "perm_b32", k_perm_b32 },
+		{ "mul_lo_u32", k_mul_lo_u32 },
+		{ "mad_u32_u24", k_mad_u32_u24 },
+		{ "cndmask_b32", k_cndmask_b32 },
+		{ "cndmask_e64", k_cndmask_e64 },
+		{ "add_co_u32", k_add_co_u32 },
+		{ "addc_co_u32", k_addc_co_u32 },
+		{ "cmp_gt_i32", k_cmp_gt_i32 },
+		{ "pk_add_u16", k_pk_add_u16 },
+		{ "pk_mad_i16", k_pk_mad_i16 },
+		{ "mov_dpp", k_mov_dpp },
+		{ "ashrrev_i64", k_ashrrev_i64 },
+		{ "lshlrev_b64", k_lshlrev_b64 },
+		{ "lshl_add_u64", k_lshl_add_u64 },
+		{ "mad_u64_u32", k_mad_u64_u32 },
+		{ "mad_i64_i32", k_mad_i64_i32 },
+		{ "add_f64", k_add_f64 },
+		{ "fma_f64", k_fma_f64 },
+		{ "pk_add_f32", k_pk_add_f32 },
+		{ "pk_fma_f32", k_pk_fma_f32 },
 	};
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
@@ -139,11 +569,10 @@ int main()
 		}
 		const double lane_ops = (double)blocks * 256 * kIters * kChains;
 		const double tops = lane_ops / (best * 1e-3) / 1e12;
-		// cycles per wave-statement per SIMD at 2.4 GHz: waves*stmts / (SIMDs*time*clk)
-		const double stmts = (double)blocks * 4 * kIters * kChains;
-		const double cyc = (best * 1e-3) * 2.4e9 * (cus * 4.0) / stmts;
-		printf("%-16s %8.3f ms  %7.2f Tstmt/s (lane)  %5.2f cyc/wave-stmt/SIMD @2.4GHz (%d instr/stmt)\n",
-			c.name, best, tops, cyc, c.instr);
+		const double instr = (double)blocks * 4 * kIters * kChains;
+		const double cyc = (best * 1e-3) * 2.4e9 * (cus * 4.0) / instr;
+		printf("%-16s %8.3f ms  %7.2f T lane-ops/s  %5.2f cyc/wave-instr/SIMD @2.4GHz\n",
+			c.name, best, tops, cyc);
 	}
 	return 0;
 }
