@@ -32,7 +32,16 @@ bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 	CORDIC_ROT_STAGES(X)
 #undef X
 	default:
-		return false;
+		// any other count up to kDynStages: the dynamic-exit instance
+		if (nlive < 1 || nlive > kDynStages)
+			return false;
+		hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER,
+				kDynStages, (G > kDynStages ? kDynStages : G), FEED,
+				true>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i32x4 *)j.x, (const i32x4 *)j.y,
+			(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
+			j.n / kVec);
+		return true;
 	}
 }
 } // namespace
@@ -67,8 +76,20 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	return true; }
 	CORDIC_ROT_STAGES(X)
 #undef X
-	default:
-		return false;
+	default: {
+		if (nlive < kSeedStages || nlive > kDynStages)
+			return false;
+		auto kern = rotator_seeded<CORDIC_INST_CONTAINER, kDynStages,
+				kSeedStages, FEED, true>;
+		if (lds_bytes > 64 * 1024)
+			(void)hipFuncSetAttribute((const void *)kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)lds_bytes);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st,
+			kp, sa, (const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
+			j.n / kVec);
+		return true;
+	}
 	}
 }
 } // namespace
@@ -102,7 +123,13 @@ bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,
 	CORDIC_POL_STAGES(X)
 #undef X
 	default:
-		return false;
+		if (nlive < 1 || nlive > kDynStages)
+			return false;
+		hipLaunchKernelGGL((topolar_unrolled<CORDIC_INST_CONTAINER, kDynStages,
+				(G > kDynStages ? kDynStages : G), true>), dim3(grid),
+			dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y,
+			(i32x4 *)mag, (u32x4 *)ph, n / kVec);
+		return true;
 	}
 }
 #endif

@@ -14,6 +14,10 @@
 
 namespace cordic_amd {
 
+// stage counts without a static instance run on one instance unrolled to
+// kDynStages with a scalar early exit (cordic_device.h: DYN)
+constexpr int kDynStages = 40;
+
 // every stage in the GENERAL form
 constexpr int kAllGeneral = 1 << 20;
 

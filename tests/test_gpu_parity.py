@@ -181,6 +181,44 @@ def test_parameter_sweep_all_kernel_paths():
     assert seen["wrap"] >= 2 and seen["wide"] >= 10 and seen["narrow"] >= 10
 
 
+@pytest.mark.parametrize("kind", ["lj29", "lj30", "narrow", "wide", "r2p",
+                                  "r2p_wide", "seq"])
+def test_every_stage_count(kind):
+    """Stage counts 1..40: static instances where they exist, the dynamic-exit
+    instance elsewhere (plain and seeded), the generic kernel beyond."""
+    rng = np.random.RandomState(31)
+    for ns in list(range(1, 41)) + [47, 64]:
+        if kind == "lj29":
+            args = (ca.P2R, 32, 32, 2, 32, ns)
+        elif kind == "lj30":
+            args = (ca.P2R, 31, 30, 2, 32, ns)
+        elif kind == "narrow":
+            args = (ca.P2R, 24, 24, 2, 32, ns)
+        elif kind == "wide":
+            args = (ca.P2R, 32, 32, 7, 32, ns)
+        elif kind == "r2p":
+            args = (ca.R2P, 24, 24, 2, 32, ns)
+        elif kind == "r2p_wide":
+            args = (ca.R2P, 32, 32, 2, 32, ns)
+        else:
+            args = (ca.SP2R, 32, 32, 2, 32, ns)
+        try:
+            cfg, ocfg = both(*args)
+        except ca.CordicError:
+            continue
+        x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, 3001)
+        if args[0] in (ca.P2R, ca.SP2R):
+            assert_p2r(cfg, ocfg, x, y, ph)
+            plan = ca.Plan(cfg)
+            x0 = (1 << (cfg.iw - 1)) - 1
+            gx, gy = gpu_plan_p2r(plan, x0, -5, ph)
+            rx, ry = O.rotate(ocfg, x0, -5, ph)
+            assert np.array_equal(gx, rx) and np.array_equal(gy, ry), ns
+            plan.close()
+        else:
+            assert_r2p(cfg, ocfg, x, y)
+
+
 def test_tiny_cores_wrap_like_the_registers():
     """WW of a few bits: truncation noise reaches full scale and the WW-bit
     registers really overflow; the kernel must wrap exactly as they do."""
