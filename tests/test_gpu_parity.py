@@ -487,3 +487,124 @@ def test_plan_for_ineligible_core_still_works():
     a = gpu_plan_p2r(plan, 2**31 - 1, 0, ph)
     b = O.rotate(ocfg, 2**31 - 1, 0, ph)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------ BASELINE sizes, properties
+
+def _digest2(a, b, index0=0):
+    return (gpu_digest(a, index0) + gpu_digest(b, index0 + (1 << 40))) % 2**64
+
+
+def test_full_size_cfg2_checksum_of_checksums_and_spot_check():
+    """2^30 samples (BASELINE config 2): one launch vs 64 launches of 2^24
+    with the shard's global index -- digests must add up -- plus a strided
+    subset and both ends against the oracle."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n = 1 << 30
+    x0 = 2**31 - 1
+    phase = torch.empty(n, dtype=torch.int32, device=DEV)
+    a = torch.empty(n, dtype=torch.int32, device=DEV)
+    b = torch.empty(n, dtype=torch.int32, device=DEV)
+    ca.fill_phase_ramp(phase, 0, 2)
+    plan = ca.Plan(cfg)
+    plan.p2r_const(x0, 0, phase, a, b)
+    torch.cuda.synchronize()
+    whole = _digest2(a, b)
+    # same work as 64 shards through the full-recurrence kernel
+    plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
+    a2 = torch.empty(1 << 24, dtype=torch.int32, device=DEV)
+    b2 = torch.empty(1 << 24, dtype=torch.int32, device=DEV)
+    parts = 0
+    for s in range(64):
+        lo = s << 24
+        plain.p2r_const(x0, 0, phase[lo:lo + (1 << 24)], a2, b2)
+        torch.cuda.synchronize()
+        parts = (parts + _digest2(a2, b2, lo)) % 2**64
+    assert whole == parts
+    idx = np.unique(np.concatenate([np.arange(4096), np.arange(n - 4096, n),
+                                    np.arange(0, n, 65521)])).astype(np.int64)
+    ti = torch.from_numpy(idx).to(DEV)
+    rx, ry = O.rotate(ocfg, x0, 0, ((idx << 2) & 0xffffffff).astype(np.uint32))
+    assert np.array_equal(a[ti].cpu().numpy(), rx)
+    assert np.array_equal(b[ti].cpu().numpy(), ry)
+    # linearity in the index: the NCO with fcw = 4 regenerates the same ramp
+    a.zero_(); b.zero_()
+    plan.nco(n, 0, 4, 0, x0, 0, a, b)
+    torch.cuda.synchronize()
+    assert _digest2(a, b) == whole
+
+
+def test_full_size_cfg5_nco_4g_samples():
+    """2^32 samples (BASELINE config 5), store only: the fused NCO against the
+    phase-array path in four 2^30 quarters, and oracle spot checks across the
+    32-bit index wrap."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n = 1 << 32
+    x0, fcw = 2**31 - 1, 0x01234567
+    a = torch.empty(n, dtype=torch.int32, device=DEV)
+    b = torch.empty(n, dtype=torch.int32, device=DEV)
+    plan = ca.Plan(cfg)
+    plan.nco(n, 0, fcw, 0, x0, 0, a, b)
+    torch.cuda.synchronize()
+    q = 1 << 30
+    a2 = torch.empty(q, dtype=torch.int32, device=DEV)
+    b2 = torch.empty(q, dtype=torch.int32, device=DEV)
+    for s in range(4):
+        ca.nco(cfg.with_flags(ca.FLAG_NO_SEED), q, 0, fcw, s * q, x0, 0, a2, b2)
+        torch.cuda.synchronize()
+        assert _digest2(a2, b2, s * q) == _digest2(a[s * q:(s + 1) * q],
+                                                   b[s * q:(s + 1) * q], s * q)
+    idx = np.unique(np.concatenate([np.arange(2048), np.arange(n - 2048, n),
+                                    np.arange(0, n, 1048573)])).astype(np.int64)
+    ti = torch.from_numpy(idx).to(DEV)
+    ph = ((idx.astype(np.uint64) * np.uint64(fcw)) & np.uint64(0xffffffff))
+    rx, ry = O.rotate(ocfg, x0, 0, ph.astype(np.uint32))
+    assert np.array_equal(a[ti].cpu().numpy(), rx)
+    assert np.array_equal(b[ti].cpu().numpy(), ry)
+
+
+def test_full_size_cfg3_r2p_round_trip_and_spot_check():
+    """2^30 I/Q pairs (BASELINE config 3): oracle spot check and the
+    polar -> rect round trip of the result (phase in, angle out)."""
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    n = 1 << 30
+    x = torch.empty(n, dtype=torch.int32, device=DEV)
+    y = torch.empty(n, dtype=torch.int32, device=DEV)
+    mag = torch.empty(n, dtype=torch.int32, device=DEV)
+    ph = torch.empty(n, dtype=torch.int32, device=DEV)
+    ca.fill_iq_ramp(x, y, 0, 0x9E3779B1, 0x85EBCA77, 24)
+    ca.r2p(cfg, x, y, mag, ph)
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(4096), np.arange(n - 4096, n),
+                                    np.arange(0, n, 65521)])).astype(np.int64)
+    ti = torch.from_numpy(idx).to(DEV)
+    rm, rp = O.topolar(ocfg, x[ti].cpu().numpy(), y[ti].cpu().numpy())
+    assert np.array_equal(mag[ti].cpu().numpy(), rm)
+    assert np.array_equal(ph[ti].cpu().numpy().view(np.uint32), rp)
+    # launch-geometry independence: 16 shards of 2^26 give the same digests
+    whole = _digest2(mag, ph)
+    m2 = torch.empty(1 << 26, dtype=torch.int32, device=DEV)
+    p2 = torch.empty(1 << 26, dtype=torch.int32, device=DEV)
+    parts = 0
+    for s in range(16):
+        lo = s << 26
+        ca.r2p(cfg, x[lo:lo + (1 << 26)], y[lo:lo + (1 << 26)], m2, p2)
+        torch.cuda.synchronize()
+        parts = (parts + _digest2(m2, p2, lo)) % 2**64
+    assert whole == parts
+    # round trip: rotating (mag, 0) by the measured angle points back at (x, y)
+    rot = ca.Config.from_cli(ca.P2R, 24, 24, 2, 32, 20)
+    ox = torch.empty(1 << 20, dtype=torch.int32, device=DEV)
+    oy = torch.empty(1 << 20, dtype=torch.int32, device=DEV)
+    zero = torch.zeros(1 << 20, dtype=torch.int32, device=DEV)
+    ca.p2r(rot, mag[:1 << 20].contiguous(), zero, ph[:1 << 20].contiguous(),
+           ox, oy)
+    torch.cuda.synchronize()
+    xs = x[:1 << 20].cpu().numpy().astype(np.float64)
+    ys = y[:1 << 20].cpu().numpy().astype(np.float64)
+    # gains: r2p 0.8234 * 2^(OW-IW-1), p2r 1.1644 * 2^(OW-IW-1)
+    g = cfg.gain * 0.5 * rot.gain * 0.5
+    err = np.hypot(ox.cpu().numpy() - xs * g, oy.cpu().numpy() - ys * g)
+    # statistical property, not a parity check: two quantised conversions in
+    # a row stay within a few output LSBs of the ideal (values are ~2^21)
+    assert err.max() < 16.0
