@@ -337,7 +337,7 @@ def main():
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
                     "unrolled" if (args.no_seed or w["kind"] in ("r2p", "p2rxy"))
-                    else "seeded(9)+unrolled"),
+                    else "seeded(%d)+unrolled" % plan.seed_info["stages"]),
                 "input": args.input,
                 "parallelism": "shard%d" % world,
             },

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *lds_buckets = lds;				// nbuckets x 4
-	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 4;	// 4L x 8 words
+	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 4;	// 4L x 4 words
 	const int L = sa.nleaves;
 
 	for (int i = threadIdx.x; i < sa.nbuckets * 4; i += kSeedBlock)
@@ -627,16 +627,24 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				y = (T)((U)y - (U)sx);
 			}
 		}
-		int64_t sx64 = (int64_t)(Z)x, sy64 = (int64_t)(Z)y;
+		// 16-byte seed entry {x word, y word, off + 2^29, low bits}:
+		//  Narrow32: the words are x and y themselves;
+		//  WideLJ  : the words are the HIGH words of x << LJ, y << LJ; their
+		//            low words only carry 32-LJ (<= 3) bits at the top,
+		//            packed as x_lo | (y_lo >> 3) into the fourth word.
+		uint32_t *d = lds_seeds + (size_t)e * 4;
 		if constexpr (C::lj != 0) {
-			sx64 = (int64_t)((uint64_t)sx64 << C::lj);
-			sy64 = (int64_t)((uint64_t)sy64 << C::lj);
+			const uint64_t xs = (uint64_t)(int64_t)x << C::lj;
+			const uint64_t ys = (uint64_t)(int64_t)y << C::lj;
+			d[0] = (uint32_t)(xs >> 32);
+			d[1] = (uint32_t)(ys >> 32);
+			d[3] = (uint32_t)xs | ((uint32_t)ys >> 3);
+		} else {
+			d[0] = (uint32_t)x;
+			d[1] = (uint32_t)y;
+			d[3] = 0;
 		}
-		uint32_t *d = lds_seeds + (size_t)e * 8;
-		d[0] = (uint32_t)sx64; d[1] = (uint32_t)((uint64_t)sx64 >> 32);
-		d[2] = (uint32_t)sy64; d[3] = (uint32_t)((uint64_t)sy64 >> 32);
-		d[4] = leafmeta[2 * j + 1];		// off + 2^29
-		d[5] = d[6] = d[7] = 0;
+		d[2] = leafmeta[2 * j + 1];		// off + 2^29
 	}
 	__syncthreads();
 
@@ -648,22 +656,37 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	}
 	const uint32_t bshift = (uint32_t)sa.S - 4;	// bucket -> byte offset
 	const uint32_t seed_base = (uint32_t)sa.nbuckets * 16u;
-	const uint32_t qstride = (uint32_t)L * 32u;
+	const uint32_t qstride = (uint32_t)L * 16u;
 	const char *ldsb = reinterpret_cast<const char *>(lds);
 
+	// Work distribution: every (persistent) block sweeps its own contiguous
+	// chunk.  This kernel runs at HBM speed, and an arithmetic-free kernel
+	// with the same 4 B in / 8 B out traffic measured 2.47 ms per 2^30
+	// samples this way against 2.67 ms with a grid-stride interleave
+	// (tools/hbm_pattern_bench.hip, profiles/r01/hbm_pattern.txt).
+#ifdef CORDIC_SEED_GRIDSTRIDE
 	const size_t stride = (size_t)gridDim.x * kSeedBlock;
+	const size_t hi = nvec;
 	size_t g = (size_t)blockIdx.x * kSeedBlock + threadIdx.x;
+#else
+	const size_t stride = kSeedBlock;
+	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + kSeedBlock - 1) / kSeedBlock * kSeedBlock;
+	const size_t lo = (size_t)blockIdx.x * chunk;
+	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	size_t g = lo + threadIdx.x;
+#endif
 	// software prefetch (see rotator_unrolled); two passes ahead and
-	// non-temporal loads measured no better (profiles/r01 notes)
+	// non-temporal loads measured no better
 	u32x4 nph{};
 	if constexpr (FEED != Feed::Nco_ConstXY)
-		if (g < nvec)
+		if (g < hi)
 			nph = load_in(&phin[g]);
-	for (; g < nvec; g += stride) {
+	for (; g < hi; g += stride) {
 		const u32x4 tph = nph;
 		if constexpr (FEED != Feed::Nco_ConstXY) {
 			const size_t gn = g + stride;
-			if (gn < nvec)
+			if (gn < hi)
 				nph = load_in(&phin[gn]);
 		}
 		uint32_t P[kVec];
@@ -679,23 +702,39 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				P[v] = tph[v] << kp.pw_shl;
 		}
 
+		// three passes so that the four bucket reads, then the four seed
+		// reads, are in flight together (one s_waitcnt each, not eight)
 		int64_t x[kVec], y[kVec], p[kVec];
+		uint32_t r[kVec], qoff[kVec];
+		u32x4 bk[kVec], se[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			const uint32_t pb = P[v] + 0x20000000u;
-			const uint32_t q = pb >> 30;
-			const uint32_t r = pb & 0x3fffffffu;	// p0 + 2^29
-			const u32x4 bk = *reinterpret_cast<const u32x4 *>(
-					ldsb + ((r >> bshift) & ~15u));
+			qoff[v] = (pb >> 30) * qstride + seed_base;
+			r[v] = pb & 0x3fffffffu;		// p0 + 2^29
+			bk[v] = *reinterpret_cast<const u32x4 *>(
+					ldsb + ((r[v] >> bshift) & ~15u));
+		}
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
 			// r >= bound  <=>  (bound-1) - r < 0
-			const uint32_t j32 = (bk[2] + ((bk[0] - r) >> 31)
-						+ ((bk[1] - r) >> 31)) << 5;
-			const char *se = ldsb + seed_base + q * qstride + j32;
-			const u32x4 xy = *reinterpret_cast<const u32x4 *>(se);
-			const uint32_t offr = *reinterpret_cast<const uint32_t *>(se + 16);
-			x[v] = (int64_t)(((uint64_t)xy[1] << 32) | xy[0]);
-			y[v] = (int64_t)(((uint64_t)xy[3] << 32) | xy[2]);
-			const uint32_t pm = r - offr;		// residual after M stages
+			const uint32_t j16 = (bk[v][2] + ((bk[v][0] - r[v]) >> 31)
+						+ ((bk[v][1] - r[v]) >> 31)) << 4;
+			se[v] = *reinterpret_cast<const u32x4 *>(ldsb + qoff[v] + j16);
+		}
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			if constexpr (C::lj != 0) {
+				constexpr uint32_t lowmask = ~((1u << C::lj) - 1u);
+				x[v] = (int64_t)(((uint64_t)se[v][0] << 32)
+						| (se[v][3] & lowmask));
+				y[v] = (int64_t)(((uint64_t)se[v][1] << 32)
+						| (se[v][3] << 3));
+			} else {
+				x[v] = (int64_t)se[v][0];
+				y[v] = (int64_t)se[v][1];
+			}
+			const uint32_t pm = r[v] - se[v][2];	// residual after M stages
 			if constexpr (C::lj != 0)
 				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)pm << 31);
 			else

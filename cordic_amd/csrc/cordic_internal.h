@@ -31,7 +31,7 @@ const char *status_text(int s);
 // Seed tables: stages replaced by the lookup and threads per block of the
 // seeded kernels (one table per block).
 #ifndef CORDIC_SEED_STAGES
-#define CORDIC_SEED_STAGES 9
+#define CORDIC_SEED_STAGES 10
 #endif
 #ifndef CORDIC_SEED_BLOCK
 #define CORDIC_SEED_BLOCK 1024

@@ -402,7 +402,7 @@ SEED_CASES = {
     "ww33": (ca.P2R, 30, 30, 2, 32, 16),
     "ww34": (ca.P2R, 31, 31, 2, 30, 20),
     "ww32": (ca.P2R, 29, 29, 2, 32, 18),
-    "pw12": (ca.P2R, 12, 12, 2, 12, 12),
+    "pw14": (ca.P2R, 12, 12, 2, 14, 14),
 }
 
 
@@ -431,7 +431,7 @@ def test_seeded_plan_is_bit_exact(name):
     cfg, ocfg = both(*SEED_CASES[name])
     plan = ca.Plan(cfg)
     info = plan.seed_info
-    assert info["stages"] == 9 and info["nleaves"] >= 100
+    assert info["stages"] == 10 and info["nleaves"] >= 100
     rng = np.random.RandomState(21)
     n = (1 << 19) + 5
     _, _, ph = rand_inputs(rng, cfg.iw, cfg.pw, n)

@@ -9,7 +9,7 @@ import cordic_amd as ca
 
 CASES = [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
          (ca.SP2R, 32, 32, 2, 32, 16), (ca.P2R, 13, 13, 2, -1, -1),
-         (ca.P2R, 16, 16, 2, 16, 16), (ca.P2R, 12, 12, 2, 12, 12),
+         (ca.P2R, 16, 16, 2, 16, 16), (ca.P2R, 12, 12, 2, 14, 14),
          (ca.P2R, 30, 30, 2, 32, 16), (ca.SP2R, 13, 13, 2, 20, 16)]
 
 
@@ -37,7 +37,7 @@ def test_lookup_matches_recurrence(args):
     words = ca.seed_table(cfg)
     assert words is not None
     m, S, nb, L, buckets, leaves = parse(words)
-    assert m == 9 and nb == 1 << (30 - S) and 1 <= L <= 512
+    assert m == 10 and nb == 1 << (30 - S) and 1 <= L <= 1024
     ang = [a << (32 - cfg.pw) for a in cfg.angles]
     rng = np.random.RandomState(1)
     r = rng.randint(0, 1 << 30, 200000).astype(np.int64)
@@ -69,4 +69,4 @@ def test_lookup_matches_recurrence(args):
 def test_ineligible_cores_have_no_table():
     assert ca.seed_table(ca.Config.from_cli(ca.R2P, 13, 13, 2)) is None
     assert ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 3, 32, 16)) is None  # WW 36
-    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 9 stages
+    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 10 stages
