@@ -45,6 +45,11 @@ WORKLOADS = {
     "p2rxy": dict(kind="p2rxy", cli=("p2r", 32, 32, 2, 32, 16), bytes=20,
                   shift=2, desc="basiccordic 16-stage, 32-bit, per-sample x, y "
                   "and phase vectors (cordic_p2r)"),
+    "sintbl": dict(kind="tbl", table=(4, -1, 13, 17), bytes=8, shift=0,
+                   desc="sintable PW=17 OW=13 (rtl/sintable.v), phase ramp n"),
+    "qtrtbl": dict(kind="tbl", table=(5, -1, 24, 18), bytes=8, shift=0,
+                   desc="quarterwav PW=18 OW=24 (rtl/quarterwav.v), phase "
+                   "ramp n"),
     "cfg3": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, 20), bytes=16,
                  desc="topolar 20-stage, 24-bit I/Q ramps -> mag + phase"),
     "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
@@ -66,6 +71,8 @@ def cpu_baseline(workload, seconds=12.0):
     import ctypes as C
     import oracle_lib as O
     w = WORKLOADS[workload]
+    if w["kind"] == "tbl":
+        return None
     m, iw, ow, xtra, pw, ns = w["cli"]
     ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
     L = O.lib()
@@ -103,6 +110,74 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def bench_table(args, w, ca, dist, dev, world, rank):
+    """Table cores (row F4): same timing discipline, gather kernel."""
+    import oracle_lib as O
+    kind, iw, ow, pw = w["table"]
+    tab = ca.Table(kind, iw, ow, pw)
+    n = 1 << args.log2_samples
+    index0 = rank * n
+    phase = torch.empty(n, dtype=torch.int32, device=dev)
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    ca.fill_phase_ramp(phase, index0, w["shift"])
+    if args.input == "random":
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        phase.random_(-2**31, 2**31 - 1, generator=gen)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tab.lookup(phase, out)
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(args.steps):
+        tab.lookup(phase, out)
+        ev[k + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    if rank == 0:
+        idx = np.unique(np.concatenate([
+            np.arange(0, min(n, 4096)), np.arange(max(0, n - 4096), n),
+            np.arange(0, n, 65521)])).astype(np.int64)
+        ti = torch.from_numpy(idx).to(dev)
+        tv = O.table_values(kind, tab.pw, tab.ow)
+        exp = O.table_lookup(kind, tab.pw, tab.ow, tv,
+                             phase[ti].cpu().numpy().view(np.uint32))
+        ok = bool(np.array_equal(out[ti].cpu().numpy(), exp))
+        avg = float(np.mean(kern_ms)) / 1e3
+        achieved = w["bytes"] * n / avg / 1e9
+        print(json.dumps({
+            "metric": "Msamples/sec (%s)" % args.workload,
+            "value": float(world) * n * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, w["desc"]),
+                       "samples_per_gpu": n, "pw": tab.pw, "ow": tab.ow,
+                       "entries": tab.entries, "kernel": "table_lookup",
+                       "input": args.input, "parallelism": "shard%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_sample": w["bytes"],
+                         "kernel_ms_avg": avg * 1e3},
+            "bit_exact_vs_oracle": ok}))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -143,6 +218,8 @@ def main():
     dev = torch.device("cuda", local)
 
     w = WORKLOADS[args.workload]
+    if w["kind"] == "tbl":
+        return bench_table(args, w, ca, dist, dev, world, rank)
     m, iw, ow, xtra, pw, ns = w["cli"]
     cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
     if args.generic:

@@ -88,6 +88,12 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_table_config_init": (C.c_int, [C.c_void_p] + [C.c_int] * 4),
+    "cordic_table_values": (C.c_int, [C.c_void_p, _i32p, C.c_size_t]),
+    "cordic_table_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cordic_table_destroy": (None, [C.c_void_p]),
+    "cordic_table_lookup": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "cordic_p2r_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, C.c_int,
                                   _u32p, _i32p, _i32p]),
     "cordic_r2p_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, _i32p,
@@ -231,6 +237,58 @@ class Plan:
                                      fcw & 0xffffffff, index0, x0, y0,
                                      _ptr(ox), _ptr(oy), _stream(stream)),
                "cordic_plan_nco")
+
+
+TBL, QTR = 4, 5
+
+
+class _CTableConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pw", C.c_int32), ("ow", C.c_int32),
+                ("entries", C.c_int32)]
+
+
+class Table:
+    """A -t tbl / -t qtr core: cordic_table_config + its device table."""
+
+    def __init__(self, kind, iw=-1, ow=-1, pw=-1, device=True):
+        self.c = _CTableConfig()
+        _check(lib().cordic_table_config_init(C.byref(self.c), kind, iw, ow,
+                                              pw), "cordic_table_config_init")
+        self._h = None
+        if device:
+            h = C.c_void_p()
+            _check(lib().cordic_table_create(C.byref(self.c), C.byref(h)),
+                   "cordic_table_create")
+            self._h = h
+
+    pw = property(lambda self: self.c.pw)
+    ow = property(lambda self: self.c.ow)
+    entries = property(lambda self: self.c.entries)
+
+    def values(self):
+        import numpy as np
+        out = np.empty(self.c.entries, dtype=np.int32)
+        _check(lib().cordic_table_values(C.byref(self.c),
+                                         out.ctypes.data_as(_i32p), out.size),
+               "cordic_table_values")
+        return out
+
+    def lookup(self, phase, val, n=None, stream=None):
+        n = phase.numel() if n is None else n
+        _check(lib().cordic_table_lookup(self._h, n, _ptr(phase), _ptr(val),
+                                         _stream(stream)),
+               "cordic_table_lookup")
+
+    def close(self):
+        if self._h:
+            lib().cordic_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def seed_table(cfg):

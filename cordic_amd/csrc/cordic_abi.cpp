@@ -108,6 +108,65 @@ int cordic_plan_nco(const cordic_plan *plan, size_t n, uint32_t phase0,
 	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
 }
 
+// ------------------------------------------------------------- table cores
+struct cordic_table {
+	cordic_table_config cfg;
+	int32_t *d_tbl = nullptr;
+};
+
+int cordic_table_config_init(cordic_table_config *cfg, int kind, int iw, int ow,
+		int phase_bits)
+{
+	return table_derive(cfg, kind, iw, ow, phase_bits);
+}
+
+int cordic_table_values(const cordic_table_config *cfg, int32_t *out, size_t cap)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	return table_fill(*cfg, out, cap);
+}
+
+int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
+{
+	if (!cfg || !tbl || cfg->entries <= 0)
+		return CORDIC_ERR_ARGS;
+	std::vector<int32_t> host((size_t)cfg->entries);
+	int rc = table_fill(*cfg, host.data(), host.size());
+	if (rc != CORDIC_OK)
+		return rc;
+	cordic_table *t = new (std::nothrow) cordic_table;
+	if (!t)
+		return CORDIC_ERR_ARGS;
+	t->cfg = *cfg;
+	if (hipMalloc((void **)&t->d_tbl, host.size() * 4) != hipSuccess ||
+	    hipMemcpy(t->d_tbl, host.data(), host.size() * 4,
+			hipMemcpyHostToDevice) != hipSuccess) {
+		if (t->d_tbl) (void)hipFree(t->d_tbl);
+		delete t;
+		return CORDIC_ERR_DEVICE;
+	}
+	*tbl = t;
+	return CORDIC_OK;
+}
+
+void cordic_table_destroy(cordic_table *tbl)
+{
+	if (!tbl)
+		return;
+	if (tbl->d_tbl)
+		(void)hipFree(tbl->d_tbl);
+	delete tbl;
+}
+
+int cordic_table_lookup(const cordic_table *tbl, size_t n,
+		const uint32_t *d_phase, int32_t *d_val, void *stream)
+{
+	if (!tbl)
+		return CORDIC_ERR_ARGS;
+	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream);
+}
+
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
 {
 	if (!cfg)

@@ -422,6 +422,59 @@ int write_header(const cordic_config *c, const char *name, char *buf, size_t cap
 	return (int)o.len;
 }
 
+// ---------------------------------------------------------------------------
+// Table cores (sw/sintable.cpp), row F4
+// ---------------------------------------------------------------------------
+int table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw)
+{
+	if (!t)
+		return CORDIC_ERR_ARGS;
+	std::memset(t, 0, sizeof(*t));
+	if (kind != CORDIC_TBL && kind != CORDIC_QTR)
+		return CORDIC_ERR_MODE;
+	// sw/main.cpp:332-335 (tbl tests pw <= 0) vs :371-374 (qtr tests pw < 0)
+	const bool pw_absent = (kind == CORDIC_TBL) ? (pw <= 0) : (pw < 0);
+	if (iw >= 0 && pw_absent)
+		pw = iw;
+	if (pw > 3 && ow <= 0) {
+		for (int k = pw - 2; k < pw + 3; k++)
+			if (k >= 1 && k <= 62 && phase_bits_for(k) == pw) {
+				ow = k;
+				break;
+			}
+	}
+	if (ow <= 0)
+		ow = 24;
+	if (pw <= 0)
+		pw = phase_bits_for(ow);
+	// sw/hexfile.cpp:52-59 (ow < 31, >= 4 entries); sw/sintable.cpp:186-194
+	// refuses tables above 2^25 entries
+	if (ow >= 31 || ow < 2)
+		return CORDIC_ERR_WIDTH;
+	if (pw <= 2 || pw >= 26)
+		return CORDIC_ERR_PHASE_BITS;
+	t->kind = kind;
+	t->pw = pw;
+	t->ow = ow;
+	t->entries = (kind == CORDIC_TBL) ? (1 << pw) : (1 << (pw - 2));
+	return CORDIC_OK;
+}
+
+int table_fill(const cordic_table_config &t, int32_t *out, size_t cap)
+{
+	if (!out || cap < (size_t)t.entries)
+		return CORDIC_ERR_ARGS;
+	const int n = 1 << t.pw;
+	const long maxv = (1l << (t.ow - 1)) - 1l;
+	for (int k = 0; k < t.entries; k++) {
+		double ph = 2.0 * M_PI * (double)k / (double)n;
+		if (t.kind == CORDIC_QTR)
+			ph += M_PI / (double)n;	// half a step: sw/sintable.cpp:330
+		out[k] = (int32_t)(long)((double)maxv * std::sin(ph));
+	}
+	return CORDIC_OK;
+}
+
 const char *status_text(int s)
 {
 	switch (s) {

@@ -27,6 +27,8 @@ int	parse_args(cordic_config *cfg, int argc, const char *const *argv,
 int	write_header(const cordic_config *c, const char *name, char *buf,
 		size_t cap);
 const char *status_text(int s);
+int	table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw);
+int	table_fill(const cordic_table_config &t, int32_t *out, size_t cap);
 
 // Seed tables: stages replaced by the lookup and threads per block of the
 // seeded kernels (one table per block).
@@ -70,6 +72,8 @@ int	launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 		void *stream);
 int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 		uint32_t mulx, uint32_t muly, int bits, void *stream);
+int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
+		size_t n, const uint32_t *phase, int32_t *val, void *stream);
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream);
 

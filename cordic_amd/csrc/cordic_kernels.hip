@@ -137,6 +137,52 @@ __global__ __launch_bounds__(kBlock) void fill_iq_ramp(int32_t *x, int32_t *y,
 	}
 }
 
+// rtl/sintable.v:72-77 / rtl/quarterwav.v:86-108: one gather per sample from
+// a table that lives in L2 / Infinity Cache (at most 2^25 entries).
+template <bool QUARTER>
+__device__ __forceinline__ int32_t table_sample(const int32_t *__restrict__ tbl,
+		uint32_t ph, int pw, int ow)
+{
+	const int sh = 32 - ow;
+	if constexpr (!QUARTER) {
+		return tbl[ph & ((1u << pw) - 1u)];
+	} else {
+		const uint32_t qm = (1u << (pw - 2)) - 1u;
+		const uint32_t idx = ((ph >> (pw - 2)) & 1u) ? (~ph & qm) : (ph & qm);
+		int32_t v = tbl[idx];
+		if ((ph >> (pw - 1)) & 1u)
+			v = -v;
+		return (int32_t)((uint32_t)v << sh) >> sh;	// OW-bit wrap
+	}
+}
+
+template <bool QUARTER>
+__global__ __launch_bounds__(kBlock) void table_lookup(
+		const int32_t *__restrict__ tbl, const uint32_t *__restrict__ phase,
+		int32_t *__restrict__ val, size_t n, int pw, int ow)
+{
+	const size_t nvec = n / kVec;
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	const bool vec_ok = ((reinterpret_cast<uintptr_t>(phase)
+			| reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
+	size_t done = 0;
+	if (vec_ok) {
+		for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
+				g += stride) {
+			const u32x4 p = reinterpret_cast<const u32x4 *>(phase)[g];
+			i32x4 o;
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				o[v] = table_sample<QUARTER>(tbl, p[v], pw, ow);
+			reinterpret_cast<i32x4 *>(val)[g] = o;
+		}
+		done = nvec * kVec;
+	}
+	for (size_t i = done + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+			i += stride)
+		val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
+}
+
 // mix(): a 64-bit finaliser over (global index, word) so that the digest is
 // sensitive to both value and position, yet shards simply add.
 __device__ __forceinline__ uint64_t digest_mix(uint64_t idx, uint32_t w)
@@ -425,6 +471,23 @@ int launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 	hipLaunchKernelGGL(fill_iq_ramp, dim3(grid), dim3(kBlock), 0,
 			static_cast<hipStream_t>(stream), x, y, n, index0, mulx,
 			muly, bits);
+	return check_launch();
+}
+
+int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
+		size_t n, const uint32_t *phase, int32_t *val, void *stream)
+{
+	if (n == 0) return CORDIC_OK;
+	if (!d_tbl || !phase || !val) return CORDIC_ERR_ARGS;
+	const int grid = grid_for(kTile, n);
+	if (grid < 0) return CORDIC_ERR_DEVICE;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (t.kind == CORDIC_QTR)
+		hipLaunchKernelGGL(table_lookup<true>, dim3(grid), dim3(kBlock), 0,
+				st, d_tbl, phase, val, n, t.pw, t.ow);
+	else
+		hipLaunchKernelGGL(table_lookup<false>, dim3(grid), dim3(kBlock), 0,
+				st, d_tbl, phase, val, n, t.pw, t.ow);
 	return check_launch();
 }
 

@@ -226,6 +226,40 @@ int	cordic_plan_nco(const cordic_plan *plan, size_t n,
  * small.  buf may be NULL to query eligibility only when cap is 0. */
 size_t	cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words);
 
+/*
+ * Table cores (row F4): the reference's plain and quarter-wave sine tables,
+ * gencordic -t tbl / -t qtr (sw/sintable.cpp; rtl/sintable.v:72-77,
+ * rtl/quarterwav.v:86-108).  Not CORDIC -- a gather -- offered so that the
+ * reference's other sine generators can be compared on the same device.
+ */
+enum cordic_table_kind {
+	CORDIC_TBL = 4,		/* -t tbl : 2^PW-entry sine table            */
+	CORDIC_QTR = 5		/* -t qtr : 2^(PW-2)-entry quarter-wave table */
+};
+
+typedef struct cordic_table_config {
+	int32_t	kind;		/* enum cordic_table_kind                    */
+	int32_t	pw;		/* PW: phase bits                            */
+	int32_t	ow;		/* OW: output bits                           */
+	int32_t	entries;	/* table length                              */
+} cordic_table_config;
+
+typedef struct cordic_table cordic_table;	/* table resident on the device */
+
+/* gencordic's defaulting for -t tbl / -t qtr (sw/main.cpp:330-405): iw is the
+ * -i value (taken as the phase width when -p is absent), <= 0 / < 0 = absent. */
+int	cordic_table_config_init(cordic_table_config *cfg, int kind, int iw,
+		int ow, int phase_bits);
+/* The table exactly as the generator writes it to <name>.hex
+ * (sw/sintable.cpp:155-166,322-333), as sign-extended OW-bit values. */
+int	cordic_table_values(const cordic_table_config *cfg, int32_t *out,
+		size_t cap);
+int	cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl);
+void	cordic_table_destroy(cordic_table *tbl);
+/* d_val[i] = o_val of the core for i_phase = d_phase[i] (low PW bits) */
+int	cordic_table_lookup(const cordic_table *tbl, size_t n,
+		const uint32_t *d_phase, int32_t *d_val, void *stream);
+
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,

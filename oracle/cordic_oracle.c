@@ -732,3 +732,82 @@ uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
 	free(th); free(jobs);
 	return total;
 }
+
+/* ------------------------------------------------------------ table cores
+ *
+ * sintable / quarterwav (sw/sintable.cpp): plain table lookups, outside the
+ * CORDIC hot path.  kind 4 = -t tbl, 5 = -t qtr. */
+
+/* sw/main.cpp:330-368 (tbl) and :369-405 (qtr): PW / OW defaulting */
+int orc_table_config(int kind, int iw, int ow, int phase_bits, int *pw_out,
+		int *ow_out)
+{
+	if (kind != 4 && kind != 5)
+		return -1;
+	if (kind == 4) {
+		if ((iw >= 0) && (phase_bits <= 0)) { phase_bits = iw; iw = -1; }
+	} else {
+		if ((iw >= 0) && (phase_bits < 0)) { phase_bits = iw; iw = -1; }
+	}
+	if ((phase_bits > 3) && (ow <= 0)) {
+		for (int k = phase_bits - 2; k < phase_bits + 3; k++) {
+			if (k < 1 || k > 62)
+				continue;
+			if (orc_calc_phase_bits(k) == phase_bits) { ow = k; break; }
+		}
+	}
+	if (ow <= 0)
+		ow = 24;
+	if (phase_bits <= 0)
+		phase_bits = orc_calc_phase_bits(ow);
+	/* sw/hexfile.cpp:52-59, sw/sintable.cpp:58-66,186-194 */
+	if (ow >= 31 || ow < 2 || phase_bits <= 2 || phase_bits >= 26)
+		return -2;
+	*pw_out = phase_bits;
+	*ow_out = ow;
+	return 0;
+}
+
+/* sw/sintable.cpp:155-166 (full wave) and :322-333 (quarter wave, half a
+ * step of phase offset); entries as signed values */
+void orc_table_values(int kind, int pw, int ow, int32_t *out)
+{
+	const int tbl_entries = (1 << pw);
+	const long maxv = (1l << (ow - 1)) - 1l;
+	if (kind == 4) {
+		for (int k = 0; k < tbl_entries; k++) {
+			double ph = 2.0 * M_PI * (double)k / (double)tbl_entries;
+			long v = (long)((double)(long)maxv * sin(ph));
+			out[k] = (int32_t)v;
+		}
+	} else {
+		for (int k = 0; k < tbl_entries / 4; k++) {
+			double ph = 2.0 * M_PI * (double)k / (double)tbl_entries;
+			ph += M_PI / (double)tbl_entries;
+			long v = (long)((double)maxv * sin(ph));
+			out[k] = (int32_t)v;
+		}
+	}
+}
+
+/* rtl/sintable.v:72-77 and rtl/quarterwav.v:86-108 per sample */
+void orc_table_lookup(int kind, int pw, int ow, const int32_t *tbl, size_t n,
+		const uint32_t *phase, int32_t *out)
+{
+	const uint32_t pm = pmask(pw);
+	for (size_t s = 0; s < n; s++) {
+		const uint32_t ph = phase[s] & pm;
+		if (kind == 4) {
+			out[s] = (int32_t)sx(tbl[ph], ow);
+		} else {
+			const uint32_t qm = (1u << (pw - 2)) - 1u;
+			uint32_t idx = ph & qm;
+			if ((ph >> (pw - 2)) & 1)
+				idx = (~ph) & qm;
+			int64_t v = sx(tbl[idx], ow);
+			if ((ph >> (pw - 1)) & 1)
+				v = -v;
+			out[s] = (int32_t)sx(v, ow);
+		}
+	}
+}

@@ -22,7 +22,7 @@
  *     build) cannot be made here, so sample-level parity is UNPINNED BY
  *     REFERENCE FIXTURES.  What ties it to the reference:
  *     (a) tests/vsim.py, this project's own small cycle simulator, EXECUTES
- *         the reference's Verilog text -- rtl/*.v where they lie and whatever
+ *         the reference's Verilog text -- the rtl/ .v files where they lie and whatever
  *         oracle/_ref/gencordic emits -- clock by clock, and this oracle must
  *         agree with it sample for sample (tests/test_rtl_vectors.py; the
  *         resulting vectors are committed as tests/golden/rtl_vectors.json
@@ -103,6 +103,13 @@ void	orc_topolar(const orc_config *cfg, size_t n, const int32_t *x,
 void	orc_nco(const orc_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
 		uint64_t index0, int32_t x0, int32_t y0,
 		int32_t *ox, int32_t *oy);
+
+/* table cores (sw/sintable.cpp; kind 4 = -t tbl, 5 = -t qtr) */
+int	orc_table_config(int kind, int iw, int ow, int phase_bits, int *pw_out,
+		int *ow_out);
+void	orc_table_values(int kind, int pw, int ow, int32_t *out);
+void	orc_table_lookup(int kind, int pw, int ow, const int32_t *tbl, size_t n,
+		const uint32_t *phase, int32_t *out);
 
 /* bench.py cpu_baseline: samples processed by nthreads threads in `seconds` */
 uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,

@@ -77,6 +77,12 @@ def lib():
             getattr(L, name).argtypes = [C.c_int]
         L.orc_calc_stages2.argtypes = [C.c_int, C.c_int]
         L.orc_nextlg.argtypes = [C.c_uint]
+        L.orc_table_config.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2
+        L.orc_table_values.argtypes = [C.c_int, C.c_int, C.c_int, i32p]
+        L.orc_table_values.restype = None
+        L.orc_table_lookup.argtypes = [C.c_int, C.c_int, C.c_int, i32p,
+                                       C.c_size_t, u32p, i32p]
+        L.orc_table_lookup.restype = None
         L.orc_throughput.restype = C.c_uint64
         L.orc_throughput.argtypes = [cfgp, C.c_int, C.c_int, C.c_double,
                                      C.c_uint32, C.c_int32, C.c_int32]
@@ -159,3 +165,29 @@ def seq_r2p_cycle(cfg, x, y):
     m, p = C.c_int32(), C.c_uint32()
     t = lib().orc_seq_r2p_cycle(C.byref(cfg), x, y, C.byref(m), C.byref(p))
     return t, m.value, p.value
+
+
+TBL, QTR = 4, 5
+
+
+def table_config(kind, iw=-1, ow=-1, pw=-1):
+    a, b = C.c_int(), C.c_int()
+    rc = lib().orc_table_config(kind, iw, ow, pw, C.byref(a), C.byref(b))
+    if rc:
+        raise ValueError("orc_table_config rc=%d" % rc)
+    return a.value, b.value
+
+
+def table_values(kind, pw, ow):
+    n = (1 << pw) if kind == TBL else (1 << (pw - 2))
+    out = np.empty(n, dtype=np.int32)
+    lib().orc_table_values(kind, pw, ow, _i32(out))
+    return out
+
+
+def table_lookup(kind, pw, ow, tbl, phase):
+    phase = np.ascontiguousarray(phase, dtype=np.uint32)
+    out = np.empty(phase.size, dtype=np.int32)
+    lib().orc_table_lookup(kind, pw, ow, _i32(np.ascontiguousarray(tbl)),
+                           phase.size, _u32(phase), _i32(out))
+    return out

@@ -27,6 +27,7 @@ import re
 
 TOKEN = re.compile(r"""
     (?P<ws>\s+|//[^\n]*|`[^\n]*)
+  | (?P<str>"[^"\n]*")
   | (?P<num>\d*'[sS]?[bBhHdD][0-9a-fA-F_xXzZ]+|\d+)
   | (?P<id>\$?[A-Za-z_][A-Za-z0-9_$]*)
   | (?P<op>>>>|<<<|<=|>=|==|!=|&&|\|\||>>|<<|[-+*/%!~&|^<>=?:;,.#@(){}\[\]])
@@ -206,7 +207,8 @@ def parse_literal(s):
 class Module:
     """Parsed module + simulator state."""
 
-    def __init__(self, text):
+    def __init__(self, text, readmem_dir=None):
+        self.readmem_dir = readmem_dir
         self.params = {}
         self.decl = {}          # name -> (width, signed, array_len or None)
         self.assigns = {}       # wire name -> expr
@@ -318,7 +320,15 @@ class Module:
                 _ = (name, idx)
         elif v == "initial":
             p.next()
-            self.initials.append((p.stmt(), dict(env)))
+            if p.peek() == "begin" and p.peek(1) == "$readmemh":
+                p.next()
+                while p.peek() == "$readmemh":
+                    self._readmem(p)
+                p.expect("end")
+            elif p.peek() == "$readmemh":
+                self._readmem(p)
+            else:
+                self.initials.append((p.stmt(), dict(env)))
         elif v == "always":
             p.next()
             p.expect("@")
@@ -358,6 +368,29 @@ class Module:
         else:
             raise SyntaxError("module item %r" % v)
 
+    def _readmem(self, p):
+        p.expect("$readmemh")
+        p.expect("(")
+        fname = p.next().strip('"')
+        p.expect(",")
+        mem = p.next()
+        p.expect(")")
+        p.expect(";")
+        self.readmems = getattr(self, "readmems", []) + [(fname, mem)]
+
+    def _load_hex(self, fname, mem):
+        """$readmemh: whitespace separated hex words, @addr sets the cursor
+        (the format sw/hexfile.cpp:76-88 writes)."""
+        import os
+        path = os.path.join(self.readmem_dir or ".", fname)
+        addr = 0
+        for tok in open(path).read().split():
+            if tok.startswith("@"):
+                addr = int(tok[1:], 16)
+            else:
+                self.state[mem][addr] = int(tok, 16)
+                addr += 1
+
     # ---- evaluation
     def reset_state(self):
         self.state = {}
@@ -366,6 +399,8 @@ class Module:
         for st, env in self.initials:
             ups = []
             self.exec(st, env, ups, blocking=True)
+        for fname, mem in getattr(self, "readmems", []):
+            self._load_hex(fname, mem)
 
     def sig(self, node, env):
         """self-determined (width, signed) of an expression."""
@@ -518,21 +553,43 @@ class Module:
                     break
         else:
             lhs, rhs = st.args
+            now = blocking or k == "ba"
+            if lhs.kind == "cat":          # { a, b } <= value
+                widths = [self.decl[i.args[0]][0] for i in lhs.args[0]]
+                v = self.val(rhs, env) & ((1 << sum(widths)) - 1)
+                for item, w in zip(reversed(lhs.args[0]), reversed(widths)):
+                    part = v & ((1 << w) - 1)
+                    v >>= w
+                    if now:
+                        self._store(item.args[0], None, part)
+                    else:
+                        ups.append((item.args[0], None, part))
+                return
             if lhs.kind == "idx":
                 name = lhs.args[0].args[0]
                 idx = self.val(lhs.args[1], env)
+                if self.decl[name][2] is None:     # bit select of a vector
+                    bit = self.val(rhs, env) & 1
+                    if now:
+                        self._store(name, ("bit", idx), bit)
+                    else:
+                        ups.append((name, ("bit", idx), bit))
+                    return
             else:
                 name, idx = lhs.args[0], None
             w = self.decl[name][0]
             # the RHS is evaluated in its own signedness, then truncated
             v = self.val(rhs, env) & ((1 << w) - 1)
-            if blocking or k == "ba":
+            if now:
                 self._store(name, idx, v)
             else:
                 ups.append((name, idx, v))
 
     def _store(self, name, idx, v):
-        if idx is None:
+        if isinstance(idx, tuple):             # ("bit", k)
+            k = idx[1]
+            self.state[name] = (self.state[name] & ~(1 << k)) | (v << k)
+        elif idx is None:
             self.state[name] = v
         else:
             self.state[name][idx] = v
