@@ -77,3 +77,28 @@ def test_cordic_tb_r2p_report(mode):
     mag, p = O.topolar(c, x, y)
     q = Q.r2p_quality(c, x, y, mg, mag, p)
     assert abs(mxp - q["mxperr"]) < 0.01 and abs(mxv - q["mxverr"]) < 1e-5
+
+
+def test_gencordic_amd_writes_the_reference_hex_tables(tmp_path):
+    """-t tbl / -t qtr: <fname>.hex byte for byte what the real generator
+    writes (when it is available), and always what the golden hash says."""
+    import hashlib
+    import json
+    gen = os.path.join(O.ORACLE_DIR, "_ref", "gencordic")
+    with open(os.path.join(ROOT, "tests", "golden", "table_golden.json")) as f:
+        golden = json.load(f)
+    for args, e in golden.items():
+        mine = tmp_path / "mine.v"
+        r = subprocess.run([GEN] + args.split() + ["-f", str(mine)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        text = (tmp_path / "mine.hex").read_text()
+        words = [int(t, 16) for t in text.split() if not t.startswith("@")]
+        h = hashlib.sha256(b"".join(w.to_bytes(4, "little")
+                                    for w in words)).hexdigest()
+        assert h == e["sha256"], args
+        if os.path.exists(gen):
+            ref = tmp_path / "ref.v"
+            subprocess.run([gen] + args.split() + ["-f", str(ref)], check=True,
+                           capture_output=True)
+            assert text == (tmp_path / "ref.hex").read_text(), args

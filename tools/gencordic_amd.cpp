@@ -73,6 +73,85 @@ int main(int argc, char **argv)
 		args.push_back(argv[k]);
 	}
 
+	// -t tbl / -t qtr: the table cores.  Derive PW / OW as gencordic does and
+	// write the same <fname>.hex the reference writes (sw/hexfile.cpp:76-88:
+	// "@%08x " every 8 entries, (OW+3)/4 hex digits per entry).
+	{
+		int kind = 0, iw = -1, ow = -1, pw = -1;
+		std::string f;
+		for (size_t k = 1; k + 1 < args.size() + 1; k++) {
+			const char *a = args[k];
+			const char *v = (k + 1 < args.size()) ? args[k + 1] : nullptr;
+			if (!strcmp(a, "-t") && v) {
+				if (!strcmp(v, "tbl")) kind = CORDIC_TBL;
+				else if (!strcmp(v, "qtr")) kind = CORDIC_QTR;
+			} else if (!strcmp(a, "-i") && v) iw = atoi(v);
+			else if (!strcmp(a, "-o") && v) ow = atoi(v);
+			else if (!strcmp(a, "-p") && v) pw = atoi(v);
+			else if (!strcmp(a, "-f") && v) f = v;
+		}
+		if (kind) {
+			cordic_table_config tc;
+			const int trc = cordic_table_config_init(&tc, kind, iw, ow, pw);
+			if (trc != CORDIC_OK) {
+				fprintf(stderr, "ERR: %s\n", cordic_strerror(trc));
+				return EXIT_FAILURE;
+			}
+			if (f.empty())
+				f = (kind == CORDIC_TBL) ? "sintable.v" : "quarterwav.v";
+			if (verbose)
+				printf("Generated a %s table core: PW %d, OW %d, %d entries\n",
+					kind == CORDIC_TBL ? "sine" : "quarter-wave", tc.pw,
+					tc.ow, tc.entries);
+			std::vector<int32_t> tv((size_t)tc.entries);
+			cordic_table_values(&tc, tv.data(), tv.size());
+			std::string hexname = f;
+			if (hexname.size() > 4 && hexname[hexname.size() - 2] == '.')
+				hexname = hexname.substr(0, hexname.size() - 2);
+			hexname += ".hex";
+			FILE *hf = fopen(hexname.c_str(), "w");
+			if (!hf) {
+				fprintf(stderr, "ERR: Cannot open %s for writing\n", hexname.c_str());
+				return EXIT_FAILURE;
+			}
+			const int nc = (tc.ow + 3) / 4;
+			const long msk = (1l << tc.ow) - 1l;
+			for (int k = 0; k < tc.entries; k++) {
+				if (0 == (k % 8))
+					fprintf(hf, "%s@%08x ", (k != 0) ? "\n" : "", k);
+				fprintf(hf, "%0*lx ", nc, (long)tv[k] & msk);
+			}
+			fprintf(hf, "\n");
+			fclose(hf);
+			if (run_lg >= 0) {
+				if (run_lg > 31) run_lg = 31;
+				const size_t n = (size_t)1 << run_lg;
+				uint32_t *ph; int32_t *o;
+				cordic_table *tb = nullptr;
+				if (hipMalloc((void **)&ph, n * 4) != hipSuccess ||
+				    hipMalloc((void **)&o, n * 4) != hipSuccess ||
+				    cordic_table_create(&tc, &tb) != CORDIC_OK) {
+					fprintf(stderr, "ERR: %s\n", cordic_strerror(CORDIC_ERR_DEVICE));
+					return EXIT_FAILURE;
+				}
+				cordic_fill_phase_ramp(ph, n, 0, 0, nullptr);
+				cordic_table_lookup(tb, n, ph, o, nullptr);
+				(void)hipDeviceSynchronize();
+				const auto t0 = std::chrono::steady_clock::now();
+				for (int k = 0; k < 10; k++)
+					cordic_table_lookup(tb, n, ph, o, nullptr);
+				(void)hipDeviceSynchronize();
+				const double dt = std::chrono::duration<double>(
+						std::chrono::steady_clock::now() - t0).count();
+				printf("streamed 10 x 2^%d samples: %.1f Msamples/s\n",
+					run_lg, (double)n * 10 / dt / 1e6);
+				cordic_table_destroy(tb);
+				(void)hipFree(ph); (void)hipFree(o);
+			}
+			return EXIT_SUCCESS;
+		}
+	}
+
 	cordic_config cfg;
 	char fname[512];
 	int want_header = 0;
