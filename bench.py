@@ -428,8 +428,14 @@ def main():
                 "bytes_per_sample": w["bytes"],
                 "kernel_ms_avg": kern_avg_s * 1e3,
                 "kernel_ms_min": float(np.min(kern_ms)),
-                "note": "the path is integer-VALU bound, not HBM bound: see "
-                        "DESIGN.md (roofline) for the VALU ceiling",
+                "note": ("table-seeded kernel: within ~5 % of an arithmetic-"
+                         "free kernel with the same 4 B in / 8 B out traffic "
+                         "(tools/hbm_pattern_bench.hip reaches 0.62-0.66 of "
+                         "peak for this pattern); the full-recurrence kernel "
+                         "is integer-VALU bound (DESIGN.md 4.5)"
+                         if (w["kind"] in ("p2r", "nco") and not args.no_seed
+                             and not args.generic) else
+                         "integer-VALU bound, not HBM bound: DESIGN.md 4.5"),
             },
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,

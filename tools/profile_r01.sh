@@ -9,7 +9,7 @@ TAG=$W$(echo "$EXTRA" | tr -d ' -')
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --workload $W $EXTRA --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --workload $W $EXTRA --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 BENCH3="python $R/bench.py --workload $W $EXTRA --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH3 > $OUT/pmc_fetch.log 2>&1

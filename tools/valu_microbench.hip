@@ -498,6 +498,39 @@ __global__ __launch_bounds__(256) void k_pk_fma_f32(uint32_t *out, uint32_t b, u
 	for (int i = 0; i < kChains; i++) s ^= a[i];
 	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
 }
+__global__ __launch_bounds__(256) void k_mad_bank_free(uint32_t *out, uint32_t b, uint32_t c) {
+	// explicit registers: probes VGPR bank conflicts (bank = register % 4)
+	asm volatile("v_mov_b32 v2, %0\n\tv_mov_b32 v3, %1\n\tv_mov_b32 v4, %0\n\tv_mov_b32 v5, %1\n\t"
+		"v_mov_b32 v6, %0\n\tv_mov_b32 v7, %1\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %1"
+		:: "v"(b + threadIdx.x), "v"(c ^ threadIdx.x) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_i64_i32 v[16:17], vcc, v2, v3, v[16:17]\n\tv_mad_i64_i32 v[18:19], vcc, v4, v5, v[18:19]\n\tv_mad_i64_i32 v[20:21], vcc, v2, v3, v[20:21]\n\tv_mad_i64_i32 v[22:23], vcc, v4, v5, v[22:23]\n\tv_mad_i64_i32 v[24:25], vcc, v2, v3, v[24:25]\n\tv_mad_i64_i32 v[26:27], vcc, v4, v5, v[26:27]\n\tv_mad_i64_i32 v[28:29], vcc, v2, v3, v[28:29]\n\tv_mad_i64_i32 v[30:31], vcc, v4, v5, v[30:31]\n\tv_mad_i64_i32 v[32:33], vcc, v2, v3, v[32:33]\n\tv_mad_i64_i32 v[34:35], vcc, v4, v5, v[34:35]\n\tv_mad_i64_i32 v[36:37], vcc, v2, v3, v[36:37]\n\tv_mad_i64_i32 v[38:39], vcc, v4, v5, v[38:39]\n\tv_mad_i64_i32 v[40:41], vcc, v2, v3, v[40:41]\n\tv_mad_i64_i32 v[42:43], vcc, v4, v5, v[42:43]\n\tv_mad_i64_i32 v[44:45], vcc, v2, v3, v[44:45]\n\tv_mad_i64_i32 v[46:47], vcc, v4, v5, v[46:47]" ::: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	uint32_t r;
+	asm volatile("v_xor_b32 %0, v16, v47" : "=v"(r) :: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+	out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void k_mad_bank_2x2(uint32_t *out, uint32_t b, uint32_t c) {
+	// explicit registers: probes VGPR bank conflicts (bank = register % 4)
+	asm volatile("v_mov_b32 v2, %0\n\tv_mov_b32 v3, %1\n\tv_mov_b32 v4, %0\n\tv_mov_b32 v5, %1\n\t"
+		"v_mov_b32 v6, %0\n\tv_mov_b32 v7, %1\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %1"
+		:: "v"(b + threadIdx.x), "v"(c ^ threadIdx.x) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_i64_i32 v[16:17], vcc, v4, v5, v[16:17]\n\tv_mad_i64_i32 v[18:19], vcc, v2, v3, v[18:19]\n\tv_mad_i64_i32 v[20:21], vcc, v4, v5, v[20:21]\n\tv_mad_i64_i32 v[22:23], vcc, v2, v3, v[22:23]\n\tv_mad_i64_i32 v[24:25], vcc, v4, v5, v[24:25]\n\tv_mad_i64_i32 v[26:27], vcc, v2, v3, v[26:27]\n\tv_mad_i64_i32 v[28:29], vcc, v4, v5, v[28:29]\n\tv_mad_i64_i32 v[30:31], vcc, v2, v3, v[30:31]\n\tv_mad_i64_i32 v[32:33], vcc, v4, v5, v[32:33]\n\tv_mad_i64_i32 v[34:35], vcc, v2, v3, v[34:35]\n\tv_mad_i64_i32 v[36:37], vcc, v4, v5, v[36:37]\n\tv_mad_i64_i32 v[38:39], vcc, v2, v3, v[38:39]\n\tv_mad_i64_i32 v[40:41], vcc, v4, v5, v[40:41]\n\tv_mad_i64_i32 v[42:43], vcc, v2, v3, v[42:43]\n\tv_mad_i64_i32 v[44:45], vcc, v4, v5, v[44:45]\n\tv_mad_i64_i32 v[46:47], vcc, v2, v3, v[46:47]" ::: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	uint32_t r;
+	asm volatile("v_xor_b32 %0, v16, v47" : "=v"(r) :: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+	out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void k_mad_bank_3same(uint32_t *out, uint32_t b, uint32_t c) {
+	// explicit registers: probes VGPR bank conflicts (bank = register % 4)
+	asm volatile("v_mov_b32 v2, %0\n\tv_mov_b32 v3, %1\n\tv_mov_b32 v4, %0\n\tv_mov_b32 v5, %1\n\t"
+		"v_mov_b32 v6, %0\n\tv_mov_b32 v7, %1\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %1"
+		:: "v"(b + threadIdx.x), "v"(c ^ threadIdx.x) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	for (int it = 0; it < kIters; it++)
+		asm volatile("v_mad_i64_i32 v[16:17], vcc, v4, v8, v[16:17]\n\tv_mad_i64_i32 v[18:19], vcc, v2, v6, v[18:19]\n\tv_mad_i64_i32 v[20:21], vcc, v4, v8, v[20:21]\n\tv_mad_i64_i32 v[22:23], vcc, v2, v6, v[22:23]\n\tv_mad_i64_i32 v[24:25], vcc, v4, v8, v[24:25]\n\tv_mad_i64_i32 v[26:27], vcc, v2, v6, v[26:27]\n\tv_mad_i64_i32 v[28:29], vcc, v4, v8, v[28:29]\n\tv_mad_i64_i32 v[30:31], vcc, v2, v6, v[30:31]\n\tv_mad_i64_i32 v[32:33], vcc, v4, v8, v[32:33]\n\tv_mad_i64_i32 v[34:35], vcc, v2, v6, v[34:35]\n\tv_mad_i64_i32 v[36:37], vcc, v4, v8, v[36:37]\n\tv_mad_i64_i32 v[38:39], vcc, v2, v6, v[38:39]\n\tv_mad_i64_i32 v[40:41], vcc, v4, v8, v[40:41]\n\tv_mad_i64_i32 v[42:43], vcc, v2, v6, v[42:43]\n\tv_mad_i64_i32 v[44:45], vcc, v4, v8, v[44:45]\n\tv_mad_i64_i32 v[46:47], vcc, v2, v6, v[46:47]" ::: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc");
+	uint32_t r;
+	asm volatile("v_xor_b32 %0, v16, v47" : "=v"(r) :: "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+	out[blockIdx.x * 256 + threadIdx.x] = r;
+}
 struct Case { const char *name; void (*fn)(uint32_t *, uint32_t, uint32_t); };
 
 int main()
@@ -546,6 +579,9 @@ int main()
 		{ "lshl_add_u64", k_lshl_add_u64 },
 		{ "mad_u64_u32", k_mad_u64_u32 },
 		{ "mad_i64_i32", k_mad_i64_i32 },
+		{ "mad_bank_free", k_mad_bank_free },
+		{ "mad_bank_2x2", k_mad_bank_2x2 },
+		{ "mad_bank_3same", k_mad_bank_3same },
 		{ "add_f64", k_add_f64 },
 		{ "fma_f64", k_fma_f64 },
 		{ "pk_add_f32", k_pk_add_f32 },
