@@ -5,7 +5,6 @@ import os
 P2R, R2P, SP2R, SR2P = 0, 1, 2, 3
 MAX_STAGES = 64
 FLAG_FORCE_GENERIC = 0x1
-FLAG_LDS_TABLE = 0x2
 FLAG_NO_LJ = 0x4
 FLAG_NO_SEED = 0x8
 

@@ -74,7 +74,6 @@ enum cordic_status {
 
 /* flags (cordic_config.flags) -- implementation selectors for A/B work */
 #define CORDIC_FLAG_FORCE_GENERIC	0x1u	/* never use an unrolled kernel */
-#define CORDIC_FLAG_LDS_TABLE		0x2u	/* arctan table read from LDS   */
 #define CORDIC_FLAG_NO_LJ		0x4u	/* WW 33..35: right-justified
 						   64-bit kernel (for A/B)      */
 #define CORDIC_FLAG_NO_SEED		0x8u	/* plans: full recurrence, no

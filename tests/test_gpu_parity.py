@@ -608,3 +608,37 @@ def test_full_size_cfg3_r2p_round_trip_and_spot_check():
     # statistical property, not a parity check: two quantised conversions in
     # a row stay within a few output LSBs of the ideal (values are ~2^21)
     assert err.max() < 16.0
+
+
+def test_entry_points_are_stream_ordered_and_graph_capturable():
+    """The device entry points only enqueue on the given stream: they can be
+    captured into a HIP graph and replayed on new data."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    rcfg, rocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    plan = ca.Plan(cfg)
+    n = 1 << 18
+    rng = np.random.RandomState(4)
+    phase = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    mag = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ang = torch.zeros(n, dtype=torch.int32, device=DEV)
+    x0 = 2**31 - 1
+    # warm up outside the capture (first call queries the device once)
+    plan.p2r_const(x0, 0, phase, ox, oy)
+    ca.r2p(rcfg, ox, oy, mag, ang)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.p2r_const(x0, 0, phase, ox, oy)     # sin/cos ...
+        ca.r2p(rcfg, ox, oy, mag, ang)           # ... and back to polar
+    for trial in range(3):
+        ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        phase.copy_(dev_i32(ph))
+        g.replay()
+        torch.cuda.synchronize()
+        rx, ry = O.rotate(ocfg, x0, 0, ph)
+        assert np.array_equal(to_np(ox), rx) and np.array_equal(to_np(oy), ry)
+        rm, rp = O.topolar(rocfg, rx, ry)
+        assert np.array_equal(to_np(mag), rm)
+        assert np.array_equal(to_np(ang, np.uint32), rp)
