@@ -210,7 +210,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: RCCL process group (also for a
+        # single rank, so that the collective path can be exercised on 1 GPU)
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
@@ -368,6 +370,8 @@ def main():
 
     gather_ms = None
     if args.gather and dist is not None:
+        # collect the output shards on rank 0 (RCCL gather over xGMI); timed
+        # separately, never folded into `value`
         outs = None
         if rank == 0:
             outs = [torch.empty(2 * n, dtype=torch.int32, device=dev)
