@@ -111,6 +111,16 @@ def lib():
     """Load libcordic_amd.so; raise (never fall back) if it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; whichever copy is loaded
+        # first serves the whole process.  Tensors handed to this library are
+        # allocated by torch, so torch's runtime must be the one in use: load
+        # it before libcordic_amd.so pulls in /opt/rocm's copy (two runtimes
+        # in one process make every launch fail).  Pure C++ callers never see
+        # this file and simply use the system runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = lib_path()
         if not os.path.exists(path):
             raise ImportError(

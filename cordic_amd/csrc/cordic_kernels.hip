@@ -235,6 +235,11 @@ int grid_for(size_t work_items_per_block, size_t n, int blocks_per_cu = 8)
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a
+// probing call inside another library) must not be blamed on our launch, so
+// every launcher clears it first and checks it right after its own launch.
+void clear_stale_error() { (void)hipGetLastError(); }
+
 int check_launch()
 {
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
@@ -381,6 +386,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		void *stream)
 {
+	clear_stale_error();
 	if (cfg.mode != CORDIC_P2R && cfg.mode != CORDIC_SP2R)
 		return CORDIC_ERR_MODE;
 	if (job.n == 0)
@@ -402,6 +408,7 @@ int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream)
 {
+	clear_stale_error();
 	if (cfg.mode != CORDIC_R2P && cfg.mode != CORDIC_SR2P)
 		return CORDIC_ERR_MODE;
 	if (n == 0)
@@ -452,6 +459,7 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 int launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 		void *stream)
 {
+	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!p || shift < 0 || shift > 31) return CORDIC_ERR_ARGS;
 	const int grid = grid_for(kBlock * 4, n);
@@ -464,6 +472,7 @@ int launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 int launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 		uint32_t mulx, uint32_t muly, int bits, void *stream)
 {
+	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!x || !y || bits < 1 || bits > 32) return CORDIC_ERR_ARGS;
 	const int grid = grid_for(kBlock * 4, n);
@@ -477,6 +486,7 @@ int launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream)
 {
+	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!d_tbl || !phase || !val) return CORDIC_ERR_ARGS;
 	const int grid = grid_for(kTile, n);
@@ -494,6 +504,7 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 int launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream)
 {
+	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!w || !digest) return CORDIC_ERR_ARGS;
 	const int grid = grid_for(kBlock * 8, n);
