@@ -40,6 +40,10 @@ WORKLOADS = {
     "cfg2": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, 16), bytes=12,
                  shift=2, desc="basiccordic 16-stage, 32-bit phase -> 32-bit "
                  "sin/cos, phase ramp n<<2, x=2^31-1, y=0"),
+    "cfg1": dict(kind="p2r", cli=("p2r", 16, 16, 2, 16, 16), bytes=6,
+                 shift=0, io16=True, desc="basiccordic 16-bit (WW19 PW16, 13 "
+                 "live stages), int16/uint16 sample arrays, phase ramp "
+                 "n mod 2^16, x=32767, y=0"),
     "cfg4": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, 24), bytes=12,
                  shift=0, desc="basiccordic 24-stage, 32-bit, phase ramp n"),
     "p2rxy": dict(kind="p2rxy", cli=("p2r", 32, 32, 2, 32, 16), bytes=20,
@@ -233,14 +237,18 @@ def main():
     x0, y0 = (1 << (iw - 1)) - 1, 0
 
     # ---- resident inputs / outputs
-    a = torch.empty(n, dtype=torch.int32, device=dev)
-    b = torch.empty(n, dtype=torch.int32, device=dev)
+    io16 = bool(w.get("io16"))
+    sdt = torch.int16 if io16 else torch.int32
+    a = torch.empty(n, dtype=sdt, device=dev)
+    b = torch.empty(n, dtype=sdt, device=dev)
     if w["kind"] == "p2r":
         phase = torch.empty(n, dtype=torch.int32, device=dev)
         ca.fill_phase_ramp(phase, index0, w["shift"])
         if args.input == "random":
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
             phase.random_(-2**31, 2**31 - 1, generator=gen)
+        if io16:
+            phase = phase.to(torch.int16)   # the low 16 bits: n mod 2^16
 
         plan = ca.Plan(cfg)
 
@@ -303,8 +311,9 @@ def main():
 
     # ---- after the timed region: correctness of what was just computed
     d = torch.zeros(1, dtype=torch.int64, device=dev)
-    ca.digest_u32(a, index0, d)
-    ca.digest_u32(b, index0 + (1 << 40), d)
+    ca.digest_u32(a.view(torch.int32), index0 // (2 if io16 else 1), d)
+    ca.digest_u32(b.view(torch.int32),
+                  index0 // (2 if io16 else 1) + (1 << 40), d)
     if dist is not None:
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
     torch.cuda.synchronize()
@@ -327,6 +336,10 @@ def main():
             ra, rb = O.rotate(ocfg, xin[ti].cpu().numpy(),
                               yin[ti].cpu().numpy(),
                               phase[ti].cpu().numpy().view(np.uint32))
+        elif w["kind"] == "p2r" and io16:
+            ra, rb = O.rotate(ocfg, x0, y0, phase[ti].cpu().numpy()
+                              .view(np.uint16).astype(np.uint32))
+            ra, rb = ra.astype(np.int16), rb.astype(np.int16)
         elif w["kind"] == "p2r":
             ra, rb = O.rotate(ocfg, x0, y0,
                               phase[ti].cpu().numpy().view(np.uint32))
@@ -374,7 +387,7 @@ def main():
         # separately, never folded into `value`
         outs = None
         if rank == 0:
-            outs = [torch.empty(2 * n, dtype=torch.int32, device=dev)
+            outs = [torch.empty(2 * n, dtype=sdt, device=dev)
                     for _ in range(world)]
         ab = torch.cat([a, b])
         barrier()

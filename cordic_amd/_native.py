@@ -7,6 +7,8 @@ MAX_STAGES = 64
 FLAG_FORCE_GENERIC = 0x1
 FLAG_NO_LJ = 0x4
 FLAG_NO_SEED = 0x8
+# enum cordic_status (the codes tests assert on)
+ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -75,6 +77,24 @@ ABI = {
                              C.c_void_p, C.c_void_p]),
     "cordic_r2p": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cordic_p2r16": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    "cordic_p2r16_const": (C.c_int, [_cfgp, C.c_size_t, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "cordic_nco16": (C.c_int, [_cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
+                               C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "cordic_r2p16": (C.c_int, [_cfgp, C.c_size_t, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cordic_plan_p2r16_const": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "cordic_plan_nco16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32,
+                                    C.c_uint32, C.c_uint64, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "cordic_plan_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
     "cordic_plan_destroy": (None, [C.c_void_p]),
     "cordic_plan_config": (_cfgp, [C.c_void_p]),
@@ -236,12 +256,25 @@ class Plan:
 
     def p2r_const(self, x0, y0, phase, ox, oy, n=None, stream=None):
         n = phase.numel() if n is None else n
+        if _is16(ox):
+            _same16("cordic_plan_p2r16_const", phase, ox, oy)
+            _check(lib().cordic_plan_p2r16_const(
+                self._h, n, x0, y0, _ptr(phase), _ptr(ox), _ptr(oy),
+                _stream(stream)), "cordic_plan_p2r16_const")
+            return
         _check(lib().cordic_plan_p2r_const(self._h, n, x0, y0, _ptr(phase),
                                            _ptr(ox), _ptr(oy),
                                            _stream(stream)),
                "cordic_plan_p2r_const")
 
     def nco(self, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
+        if _is16(ox):
+            _same16("cordic_plan_nco16", ox, oy)
+            _check(lib().cordic_plan_nco16(
+                self._h, n, phase0 & 0xffffffff, fcw & 0xffffffff, index0,
+                x0, y0, _ptr(ox), _ptr(oy), _stream(stream)),
+                "cordic_plan_nco16")
+            return
         _check(lib().cordic_plan_nco(self._h, n, phase0 & 0xffffffff,
                                      fcw & 0xffffffff, index0, x0, y0,
                                      _ptr(ox), _ptr(oy), _stream(stream)),
@@ -327,20 +360,49 @@ def _stream(stream):
     return stream.cuda_stream
 
 
+def _is16(t):
+    """int16 / uint16 sample tensors select the 16-bit-container entry points
+    (include/cordic_amd.h: cordic_*16)."""
+    return t.element_size() == 2
+
+
+def _same16(what, *tensors):
+    if any(t.element_size() != 2 for t in tensors):
+        raise TypeError("%s: every sample array must be 16-bit" % what)
+
+
 def p2r(cfg, x, y, phase, ox, oy, n=None, stream=None):
     n = phase.numel() if n is None else n
+    if _is16(ox):
+        _same16("cordic_p2r16", x, y, phase, ox, oy)
+        _check(lib().cordic_p2r16(cfg.ref, n, _ptr(x), _ptr(y), _ptr(phase),
+                                  _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_p2r16")
+        return
     _check(lib().cordic_p2r(cfg.ref, n, _ptr(x), _ptr(y), _ptr(phase),
                             _ptr(ox), _ptr(oy), _stream(stream)), "cordic_p2r")
 
 
 def p2r_const(cfg, x0, y0, phase, ox, oy, n=None, stream=None):
     n = phase.numel() if n is None else n
+    if _is16(ox):
+        _same16("cordic_p2r16_const", phase, ox, oy)
+        _check(lib().cordic_p2r16_const(cfg.ref, n, x0, y0, _ptr(phase),
+                                        _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_p2r16_const")
+        return
     _check(lib().cordic_p2r_const(cfg.ref, n, x0, y0, _ptr(phase), _ptr(ox),
                                   _ptr(oy), _stream(stream)),
            "cordic_p2r_const")
 
 
 def nco(cfg, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
+    if _is16(ox):
+        _same16("cordic_nco16", ox, oy)
+        _check(lib().cordic_nco16(cfg.ref, n, phase0 & 0xffffffff,
+                                  fcw & 0xffffffff, index0, x0, y0, _ptr(ox),
+                                  _ptr(oy), _stream(stream)), "cordic_nco16")
+        return
     _check(lib().cordic_nco(cfg.ref, n, phase0 & 0xffffffff, fcw & 0xffffffff,
                             index0, x0, y0, _ptr(ox), _ptr(oy),
                             _stream(stream)), "cordic_nco")
@@ -348,6 +410,12 @@ def nco(cfg, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
 
 def r2p(cfg, x, y, mag, ophase, n=None, stream=None):
     n = x.numel() if n is None else n
+    if _is16(mag):
+        _same16("cordic_r2p16", x, y, mag, ophase)
+        _check(lib().cordic_r2p16(cfg.ref, n, _ptr(x), _ptr(y), _ptr(mag),
+                                  _ptr(ophase), _stream(stream)),
+               "cordic_r2p16")
+        return
     _check(lib().cordic_r2p(cfg.ref, n, _ptr(x), _ptr(y), _ptr(mag),
                             _ptr(ophase), _stream(stream)), "cordic_r2p")
 

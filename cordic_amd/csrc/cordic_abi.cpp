@@ -108,6 +108,117 @@ int cordic_plan_nco(const cordic_plan *plan, size_t n, uint32_t phase0,
 	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
 }
 
+// 16-bit containers: the job carries the int16 / uint16 arrays behind its
+// int32 pointers (cordic_internal.h: RotatorJob::io16)
+namespace {
+int fits16(const cordic_config &c, bool phase_array)
+{
+	if (c.iw > 16 || c.ow > 16 || (phase_array && c.pw > 16))
+		return CORDIC_ERR_CONTAINER;
+	return CORDIC_OK;
+}
+template <typename T> const int32_t *as_i32(const T *p)
+{
+	return reinterpret_cast<const int32_t *>(p);
+}
+template <typename T> int32_t *as_i32(T *p)
+{
+	return reinterpret_cast<int32_t *>(p);
+}
+RotatorJob job16(const int16_t *x, const int16_t *y, const uint16_t *phase,
+		int16_t *ox, int16_t *oy, size_t n)
+{
+	RotatorJob j;
+	j.x = as_i32(x); j.y = as_i32(y);
+	j.phase = reinterpret_cast<const uint32_t *>(phase);
+	j.ox = as_i32(ox); j.oy = as_i32(oy);
+	j.n = n;
+	j.io16 = true;
+	return j;
+}
+} // namespace
+
+int cordic_p2r16(const cordic_config *cfg, size_t n, const int16_t *d_xval,
+		const int16_t *d_yval, const uint16_t *d_phase, int16_t *d_oxval,
+		int16_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(*cfg, true))
+		return rc;
+	RotatorJob j = job16(d_xval, d_yval, d_phase, d_oxval, d_oyval, n);
+	return launch_rotator(*cfg, Feed::PhaseArray_XYArray, j, stream);
+}
+
+int cordic_p2r16_const(const cordic_config *cfg, size_t n, int32_t xval,
+		int32_t yval, const uint16_t *d_phase, int16_t *d_oxval,
+		int16_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(*cfg, true))
+		return rc;
+	RotatorJob j = job16(nullptr, nullptr, d_phase, d_oxval, d_oyval, n);
+	j.x0 = xval; j.y0 = yval;
+	return launch_rotator(*cfg, Feed::PhaseArray_ConstXY, j, stream);
+}
+
+int cordic_nco16(const cordic_config *cfg, size_t n, uint32_t phase0,
+		uint32_t fcw, uint64_t index0, int32_t xval, int32_t yval,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(*cfg, false))
+		return rc;
+	RotatorJob j = job16(nullptr, nullptr, nullptr, d_oxval, d_oyval, n);
+	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
+	j.index0 = index0;
+	return launch_rotator(*cfg, Feed::Nco_ConstXY, j, stream);
+}
+
+int cordic_r2p16(const cordic_config *cfg, size_t n, const int16_t *d_xval,
+		const int16_t *d_yval, int16_t *d_omag, uint16_t *d_ophase,
+		void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(*cfg, true))
+		return rc;
+	return launch_topolar(*cfg, n, as_i32(d_xval), as_i32(d_yval),
+			as_i32(d_omag), reinterpret_cast<uint32_t *>(d_ophase),
+			stream, true);
+}
+
+int cordic_plan_p2r16_const(const cordic_plan *plan, size_t n, int32_t xval,
+		int32_t yval, const uint16_t *d_phase, int16_t *d_oxval,
+		int16_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(plan->cfg, true))
+		return rc;
+	RotatorJob j = job16(nullptr, nullptr, d_phase, d_oxval, d_oyval, n);
+	j.x0 = xval; j.y0 = yval;
+	attach_seed(plan, j);
+	return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+}
+
+int cordic_plan_nco16(const cordic_plan *plan, size_t n, uint32_t phase0,
+		uint32_t fcw, uint64_t index0, int32_t xval, int32_t yval,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	if (int rc = fits16(plan->cfg, false))
+		return rc;
+	RotatorJob j = job16(nullptr, nullptr, nullptr, d_oxval, d_oyval, n);
+	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
+	j.index0 = index0;
+	attach_seed(plan, j);
+	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+}
+
 // ------------------------------------------------------------- table cores
 struct cordic_table {
 	cordic_table_config cfg;

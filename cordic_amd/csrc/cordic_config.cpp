@@ -487,6 +487,7 @@ const char *status_text(int s)
 	case CORDIC_ERR_UNSUPPORTED:	return "the reference core for these parameters cannot be built or never completes";
 	case CORDIC_ERR_ARGS:		return "bad argument";
 	case CORDIC_ERR_DEVICE:		return "HIP runtime error";
+	case CORDIC_ERR_CONTAINER:	return "port wider than the 16-bit sample container";
 	default:			return "unknown status";
 	}
 }

@@ -395,6 +395,46 @@ __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &k
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+typedef int16_t i16x4 __attribute__((ext_vector_type(4)));
+
+// Memory containers of the sample arrays.  Io32: int32 / uint32 per value
+// (any port width).  Io16: int16 / uint16 per value for cores whose ports are
+// at most 16 bits wide (the 16-bit benches of the reference keep their
+// samples in shorts) -- half the HBM bytes per sample; a lane then moves
+// 8 bytes per array per pass.  In registers both are 32-bit.
+struct Io32 {
+	typedef u32x4 uvec;
+	typedef i32x4 ivec;
+	typedef uint32_t uelem;
+	typedef int32_t ielem;
+	static __device__ __forceinline__ u32x4 widen(u32x4 v) { return v; }
+	static __device__ __forceinline__ i32x4 widen(i32x4 v) { return v; }
+	static __device__ __forceinline__ u32x4 narrow(u32x4 v) { return v; }
+	static __device__ __forceinline__ i32x4 narrow(i32x4 v) { return v; }
+};
+struct Io16 {
+	typedef u16x4 uvec;
+	typedef i16x4 ivec;
+	typedef uint16_t uelem;
+	typedef int16_t ielem;
+	static __device__ __forceinline__ u32x4 widen(u16x4 v)
+	{
+		return __builtin_convertvector(v, u32x4);
+	}
+	static __device__ __forceinline__ i32x4 widen(i16x4 v)
+	{
+		return __builtin_convertvector(v, i32x4);
+	}
+	static __device__ __forceinline__ u16x4 narrow(u32x4 v)
+	{
+		return __builtin_convertvector(v, u16x4);
+	}
+	static __device__ __forceinline__ i16x4 narrow(i32x4 v)
+	{
+		return __builtin_convertvector(v, i16x4);
+	}
+};
 
 // Input loads: streamed once, never re-read (-DCORDIC_NT_LOADS: non-temporal).
 template <typename V>
@@ -432,11 +472,14 @@ __device__ __forceinline__ void store_out(V *dst, V v)
 // Processes whole 4-sample groups only (nvec of them); the launcher sends the
 // 0..3 trailing samples to the generic kernel.  Keeping the tail out of this
 // kernel is what lets hipcc emit global_load_dwordx4 / global_store_dwordx4.
-template <typename C, int NLIVE, int NGEN, Feed FEED, bool DYN = false>
+template <typename C, int NLIVE, int NGEN, Feed FEED, bool DYN = false,
+		typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
-		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
-		const u32x4 *__restrict__ phin, i32x4 *__restrict__ ox,
-		i32x4 *__restrict__ oy, size_t nvec)
+		const typename IO::ivec *__restrict__ xin,
+		const typename IO::ivec *__restrict__ yin,
+		const typename IO::uvec *__restrict__ phin,
+		typename IO::ivec *__restrict__ ox,
+		typename IO::ivec *__restrict__ oy, size_t nvec)
 {
 	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
 	using U = typename std::make_unsigned<T>::type;
@@ -472,8 +515,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	// software prefetch: the loads of pass i+1 are issued before the ~750
 	// VALU instructions of pass i, so no wave ever parks on HBM latency
-	u32x4 nph{};
-	i32x4 nx{}, ny{};
+	typename IO::uvec nph{};
+	typename IO::ivec nx{}, ny{};
 	if (g < nvec) {
 		if constexpr (FEED != Feed::Nco_ConstXY)
 			nph = phin[g];
@@ -483,8 +526,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		}
 	}
 	for (; g < nvec; g += stride) {
-		const u32x4 tph = nph;
-		const i32x4 tx = nx, ty = ny;
+		const u32x4 tph = IO::widen(nph);
+		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
 			if constexpr (FEED != Feed::Nco_ConstXY)
@@ -568,8 +611,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				}
 			}
 		}
-		store_out<true>(&ox[g], rx);
-		store_out<true>(&oy[g], ry);
+		store_out<true>(&ox[g], IO::narrow(rx));
+		store_out<true>(&oy[g], IO::narrow(ry));
 	}
 }
 
@@ -588,14 +631,15 @@ struct SeedArgs {
 	int32_t	nleaves;
 };
 
-template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false>
+template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
+		typename IO = Io32>
 __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
-		SeedArgs sa, const u32x4 *__restrict__ phin,
-		i32x4 *__restrict__ ox, i32x4 *__restrict__ oy, size_t nvec)
+		SeedArgs sa, const typename IO::uvec *__restrict__ phin,
+		typename IO::ivec *__restrict__ ox,
+		typename IO::ivec *__restrict__ oy, size_t nvec)
 {
 	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
 	using U = typename std::make_unsigned<T>::type;
-	using Z = typename std::conditional<C::wide, int64_t, uint32_t>::type;
 	static_assert(FEED != Feed::PhaseArray_XYArray, "constant vector only");
 	static_assert(M <= NLIVE, "seed deeper than the core");
 
@@ -678,12 +722,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 #endif
 	// software prefetch (see rotator_unrolled); two passes ahead and
 	// non-temporal loads measured no better
-	u32x4 nph{};
+	typename IO::uvec nph{};
 	if constexpr (FEED != Feed::Nco_ConstXY)
 		if (g < hi)
 			nph = load_in(&phin[g]);
 	for (; g < hi; g += stride) {
-		const u32x4 tph = nph;
+		const u32x4 tph = IO::widen(nph);
 		if constexpr (FEED != Feed::Nco_ConstXY) {
 			const size_t gn = g + stride;
 			if (gn < hi)
@@ -767,8 +811,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				}
 			}
 		}
-		store_out<false>(&ox[g], rx);
-		store_out<false>(&oy[g], ry);
+		store_out<false>(&ox[g], IO::narrow(rx));
+		store_out<false>(&oy[g], IO::narrow(ry));
 	}
 }
 
@@ -794,10 +838,13 @@ __device__ __forceinline__ void fold_quadrant_masks(T ex, T ey, int32_t ix,
 		| 0x20000000u;
 }
 
-template <typename C, int NLIVE, int NGEN, bool DYN = false>
+template <typename C, int NLIVE, int NGEN, bool DYN = false,
+		typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
-		const i32x4 *__restrict__ xin, const i32x4 *__restrict__ yin,
-		i32x4 *__restrict__ omag, u32x4 *__restrict__ oph, size_t nvec)
+		const typename IO::ivec *__restrict__ xin,
+		const typename IO::ivec *__restrict__ yin,
+		typename IO::ivec *__restrict__ omag,
+		typename IO::uvec *__restrict__ oph, size_t nvec)
 {
 	using T = typename std::conditional<C::wide, int64_t, int32_t>::type;
 	using U = typename std::make_unsigned<T>::type;
@@ -805,13 +852,13 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	// software prefetch (see rotator_unrolled)
-	i32x4 nx{}, ny{};
+	typename IO::ivec nx{}, ny{};
 	if (g < nvec) {
 		nx = xin[g];
 		ny = yin[g];
 	}
 	for (; g < nvec; g += stride) {
-		const i32x4 tx = nx, ty = ny;
+		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
 			nx = xin[gn];
@@ -841,8 +888,8 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			rm[v] = round_to_ow<T>((T)x[v], kp);
 			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
 		}
-		store_out<true>(&omag[g], rm);
-		store_out<true>(&oph[g], rp);
+		store_out<true>(&omag[g], IO::narrow(rm));
+		store_out<true>(&oph[g], IO::narrow(rp));
 	}
 }
 

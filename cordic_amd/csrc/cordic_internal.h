@@ -59,6 +59,10 @@ struct RotatorJob {
 	uint64_t index0 = 0;				// NCO
 	int32_t  *ox = nullptr, *oy = nullptr;
 	size_t   n = 0;
+	// sample arrays hold int16 / uint16 values (the pointers above are then
+	// really int16_t* / uint16_t*); needs IW, OW <= 16 and, with a phase
+	// array, PW <= 16
+	bool	 io16 = false;
 	// optional seed table (cordic_plan): device words + their host header
 	const uint32_t *seed_table = nullptr;
 	int seed_m = 0, seed_S = 0, seed_nbuckets = 0, seed_nleaves = 0;
@@ -67,7 +71,8 @@ struct RotatorJob {
 int	launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		void *stream);
 int	launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
-		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream);
+		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream,
+		bool io16 = false);
 int	launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 		void *stream);
 int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,

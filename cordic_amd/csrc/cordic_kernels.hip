@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "cordic_device.h"
 #include "cordic_internal.h"
@@ -35,11 +36,13 @@ __device__ __forceinline__ int32_t round_generic(int64_t v, const CoreParams &kp
 	return kp.wrap ? sext32(o, kp.ow) : o;
 }
 
-template <Feed FEED>
+template <Feed FEED, typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
-		const int32_t *__restrict__ xin, const int32_t *__restrict__ yin,
-		const uint32_t *__restrict__ phin, int32_t *__restrict__ ox,
-		int32_t *__restrict__ oy, size_t n)
+		const typename IO::ielem *__restrict__ xin,
+		const typename IO::ielem *__restrict__ yin,
+		const typename IO::uelem *__restrict__ phin,
+		typename IO::ielem *__restrict__ ox,
+		typename IO::ielem *__restrict__ oy, size_t n)
 {
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 		if constexpr (FEED == Feed::Nco_ConstXY)
 			P = kp.phase0 + (uint32_t)(kp.index0 + i) * kp.fcw;
 		else
-			P = phin[i] << kp.pw_shl;
+			P = (uint32_t)phin[i] << kp.pw_shl;
 		if constexpr (FEED == Feed::PhaseArray_XYArray) {
 			ix = sext32(xin[i], kp.iw);
 			iy = sext32(yin[i], kp.iw);
@@ -76,14 +79,17 @@ __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 			x = wrap_ww(x, kp);
 			y = wrap_ww(y, kp);
 		}
-		ox[i] = round_generic(x, kp);
-		oy[i] = round_generic(y, kp);
+		ox[i] = (typename IO::ielem)round_generic(x, kp);
+		oy[i] = (typename IO::ielem)round_generic(y, kp);
 	}
 }
 
+template <typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void topolar_generic(CoreParams kp,
-		const int32_t *__restrict__ xin, const int32_t *__restrict__ yin,
-		int32_t *__restrict__ omag, uint32_t *__restrict__ oph, size_t n)
+		const typename IO::ielem *__restrict__ xin,
+		const typename IO::ielem *__restrict__ yin,
+		typename IO::ielem *__restrict__ omag,
+		typename IO::uelem *__restrict__ oph, size_t n)
 {
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -109,8 +115,8 @@ __global__ __launch_bounds__(kBlock) void topolar_generic(CoreParams kp,
 			x = wrap_ww(x, kp);
 			y = wrap_ww(y, kp);
 		}
-		omag[i] = round_generic(x, kp);
-		oph[i] = p >> kp.pw_shl;
+		omag[i] = (typename IO::ielem)round_generic(x, kp);
+		oph[i] = (typename IO::uelem)(p >> kp.pw_shl);
 	}
 }
 
@@ -218,6 +224,44 @@ __global__ __launch_bounds__(kBlock) void digest_u32(const uint32_t *w, size_t n
 // ------------------------------------------------------------ host helpers
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// sample arrays are int32 or (io16) int16 underneath the int32_t* of the job
+template <typename P> P *advance(P *p, size_t samples, bool io16)
+{
+	if (!p) return p;
+	typedef typename std::conditional<std::is_const<P>::value, const char,
+			char>::type B;
+	return reinterpret_cast<P *>(reinterpret_cast<B *>(p)
+			+ samples * (io16 ? 2 : 4));
+}
+
+template <Feed FEED>
+void launch_rot_generic(int grid, hipStream_t st, const CoreParams &kp,
+		const RotatorJob &t)
+{
+	if (t.io16)
+		hipLaunchKernelGGL((rotator_generic<FEED, Io16>), dim3(grid),
+			dim3(kBlock), 0, st, kp, (const int16_t *)t.x,
+			(const int16_t *)t.y, (const uint16_t *)t.phase,
+			(int16_t *)t.ox, (int16_t *)t.oy, t.n);
+	else
+		hipLaunchKernelGGL((rotator_generic<FEED, Io32>), dim3(grid),
+			dim3(kBlock), 0, st, kp, t.x, t.y, t.phase, t.ox, t.oy, t.n);
+}
+
+void launch_pol_generic(int grid, hipStream_t st, const CoreParams &kp,
+		const int32_t *x, const int32_t *y, int32_t *mag, uint32_t *ph,
+		size_t n, bool io16)
+{
+	if (io16)
+		hipLaunchKernelGGL((topolar_generic<Io16>), dim3(grid), dim3(kBlock),
+			0, st, kp, (const int16_t *)x, (const int16_t *)y,
+			(int16_t *)mag, (uint16_t *)ph, n);
+	else
+		hipLaunchKernelGGL((topolar_generic<Io32>), dim3(grid), dim3(kBlock),
+			0, st, kp, x, y, mag, ph, n);
+}
 
 int grid_for(size_t work_items_per_block, size_t n, int blocks_per_cu = 8)
 {
@@ -297,13 +341,16 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 	kp.fcw = j.fcw << kp.pw_shl;
 	kp.index0 = j.index0;
 
-	bool vec_ok = aligned16(j.ox) && aligned16(j.oy);
+	// a lane moves kVec samples per array per pass: 16 bytes, or 8 (io16)
+	bool (*const vec_aligned)(const void *) = j.io16 ? aligned8 : aligned16;
+	bool vec_ok = vec_aligned(j.ox) && vec_aligned(j.oy);
 	if (FEED != Feed::Nco_ConstXY)
-		vec_ok = vec_ok && aligned16(j.phase);
+		vec_ok = vec_ok && vec_aligned(j.phase);
 	if (FEED == Feed::PhaseArray_XYArray)
-		vec_ok = vec_ok && aligned16(j.x) && aligned16(j.y);
+		vec_ok = vec_ok && vec_aligned(j.x) && vec_aligned(j.y);
 	const bool fast_ok = vec_ok && !(cfg.flags & CORDIC_FLAG_FORCE_GENERIC)
-		&& (!cfg.needs_wrap || cfg.ww == 32 || cfg.ww == 64);
+		&& (!cfg.needs_wrap || cfg.ww == 32 || cfg.ww == 64)
+		&& (!j.io16 || cfg.ww <= 32);
 
 	if (fast_ok) {
 		const int grid = grid_for(kTile, j.n);
@@ -327,7 +374,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
 			if (per_cu >= 1 && lds <= 160 * 1024) {
-				if (cfg.ww <= 32)
+				if (j.io16)
+					done = launch_seed_narrow16(FEED, cfg.nlive, g2, st,
+							kp, sa, j, lds);
+				else if (cfg.ww <= 32)
 					done = launch_seed_narrow(FEED, cfg.nlive, g2, st,
 							kp, sa, j, lds);
 				else if (cfg.ww == 35)
@@ -340,7 +390,9 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		}
 		if (!done && j.n >= (size_t)kVec) {
 			const int ngen = general_stages_for(cfg.ww);
-			if (cfg.ww <= 32)
+			if (j.io16)
+				done = launch_rot_narrow16(FEED, cfg.nlive, grid, st, kp, j);
+			else if (cfg.ww <= 32)
 				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);
 			else if (cfg.ww == 35 && !(cfg.flags & CORDIC_FLAG_NO_LJ))
 				done = launch_rot_lj29(FEED, cfg.nlive, grid, st, kp, j);
@@ -360,22 +412,20 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 				return check_launch();
 			RotatorJob t = j;
 			t.n = j.n - head;
-			t.ox += head; t.oy += head;
-			if (t.phase) t.phase += head;
-			if (t.x) t.x += head;
-			if (t.y) t.y += head;
+			t.ox = advance(t.ox, head, j.io16);
+			t.oy = advance(t.oy, head, j.io16);
+			t.phase = advance(t.phase, head, j.io16);
+			t.x = advance(t.x, head, j.io16);
+			t.y = advance(t.y, head, j.io16);
 			kp.index0 += head;
-			hipLaunchKernelGGL((rotator_generic<FEED>), dim3(1),
-				dim3(kBlock), 0, st, kp, t.x, t.y, t.phase, t.ox,
-				t.oy, t.n);
+			launch_rot_generic<FEED>(1, st, kp, t);
 			return check_launch();
 		}
 	}
 	const int grid = grid_for(kBlock, j.n);
 	if (grid < 0)
 		return CORDIC_ERR_DEVICE;
-	hipLaunchKernelGGL((rotator_generic<FEED>), dim3(grid), dim3(kBlock), 0,
-			st, kp, j.x, j.y, j.phase, j.ox, j.oy, j.n);
+	launch_rot_generic<FEED>(grid, st, kp, j);
 	return check_launch();
 }
 
@@ -406,7 +456,8 @@ int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 }
 
 int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
-		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream)
+		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream,
+		bool io16)
 {
 	clear_stale_error();
 	if (cfg.mode != CORDIC_R2P && cfg.mode != CORDIC_SR2P)
@@ -417,10 +468,12 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		return CORDIC_ERR_ARGS;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const CoreParams kp = make_params(cfg);
-	const bool vec_ok = aligned16(x) && aligned16(y) && aligned16(mag)
-			&& aligned16(phase);
+	bool (*const vec_aligned)(const void *) = io16 ? aligned8 : aligned16;
+	const bool vec_ok = vec_aligned(x) && vec_aligned(y) && vec_aligned(mag)
+			&& vec_aligned(phase);
 	const bool fast_ok = vec_ok && !(cfg.flags & CORDIC_FLAG_FORCE_GENERIC)
-		&& (!cfg.needs_wrap || cfg.ww == 32 || cfg.ww == 64);
+		&& (!cfg.needs_wrap || cfg.ww == 32 || cfg.ww == 64)
+		&& (!io16 || cfg.ww <= 32);
 	if (fast_ok) {
 		const int grid = grid_for(kTile, n);
 		if (grid < 0)
@@ -428,7 +481,10 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		bool done = false;
 		if (n >= (size_t)kVec) {
 			const int ngen = general_stages_for(cfg.ww);
-			if (cfg.ww <= 32)
+			if (io16)
+				done = launch_pol_narrow16(cfg.nlive, grid, st, kp, x, y,
+						mag, phase, n);
+			else if (cfg.ww <= 32)
 				done = launch_pol_narrow(cfg.nlive, grid, st, kp, x, y,
 						mag, phase, n);
 			else if (ngen <= 8)
@@ -442,17 +498,16 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 			const size_t head = n - n % kVec;
 			if (head == n)
 				return check_launch();
-			hipLaunchKernelGGL(topolar_generic, dim3(1), dim3(kBlock), 0,
-				st, kp, x + head, y + head, mag + head, phase + head,
-				n - head);
+			launch_pol_generic(1, st, kp, advance(x, head, io16),
+				advance(y, head, io16), advance(mag, head, io16),
+				advance(phase, head, io16), n - head, io16);
 			return check_launch();
 		}
 	}
 	const int grid = grid_for(kBlock, n);
 	if (grid < 0)
 		return CORDIC_ERR_DEVICE;
-	hipLaunchKernelGGL(topolar_generic, dim3(grid), dim3(kBlock), 0, st, kp,
-			x, y, mag, phase, n);
+	launch_pol_generic(grid, st, kp, x, y, mag, phase, n, io16);
 	return check_launch();
 }
 

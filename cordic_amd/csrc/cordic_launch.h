@@ -45,6 +45,11 @@ CORDIC_SEED_LAUNCHER(launch_seed_lj30);		// WW == 33, 34
 CORDIC_POL_LAUNCHER(launch_pol_narrow);
 CORDIC_POL_LAUNCHER(launch_pol_wide8);
 CORDIC_POL_LAUNCHER(launch_pol_wideall);
+// int16 / uint16 sample arrays (WW <= 32 only: the ports are <= 16 bits);
+// one dynamic-exit instance per feed (cordic_inst_io16.hip)
+CORDIC_ROT_LAUNCHER(launch_rot_narrow16);
+CORDIC_SEED_LAUNCHER(launch_seed_narrow16);
+CORDIC_POL_LAUNCHER(launch_pol_narrow16);
 
 } // namespace cordic_amd
 #endif

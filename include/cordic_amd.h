@@ -69,7 +69,9 @@ enum cordic_status {
 					   emits a core that cannot elaborate
 					   or never raises o_done              */
 	CORDIC_ERR_ARGS		= -7,	/* NULL pointer / bad command line     */
-	CORDIC_ERR_DEVICE	= -8	/* HIP runtime error (no GPU, launch)  */
+	CORDIC_ERR_DEVICE	= -8,	/* HIP runtime error (no GPU, launch)  */
+	CORDIC_ERR_CONTAINER	= -9	/* a port is wider than the 16-bit
+					   sample container of a *16 call      */
 };
 
 /* flags (cordic_config.flags) -- implementation selectors for A/B work */
@@ -215,6 +217,39 @@ int	cordic_plan_nco(const cordic_plan *plan, size_t n,
 		uint32_t phase0, uint32_t fcw, uint64_t index0,
 		int32_t xval, int32_t yval,
 		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* ---------------------------------------------- 16-bit sample containers
+ *
+ * The reference's 16-bit benches keep their samples in shorts
+ * (int16/uint16 host containers for -i 16 -o 16 -p 16).
+ * These entry points are the calls above on int16_t / uint16_t arrays: same
+ * arithmetic, same results (each value is the low 16 bits of what the 32-bit
+ * call returns, which is the whole value because the ports fit), half the
+ * memory traffic.  They require IW <= 16 and OW <= 16, and PW <= 16 wherever
+ * a phase ARRAY is read or written (the NCO forms take PW-bit scalars, any
+ * PW); otherwise CORDIC_ERR_CONTAINER.  Arrays should be 8-byte aligned for
+ * the vector path. */
+int	cordic_p2r16(const cordic_config *cfg, size_t n,
+		const int16_t *d_xval, const int16_t *d_yval,
+		const uint16_t *d_phase,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream);
+int	cordic_p2r16_const(const cordic_config *cfg, size_t n,
+		int32_t xval, int32_t yval, const uint16_t *d_phase,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream);
+int	cordic_nco16(const cordic_config *cfg, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		int32_t xval, int32_t yval,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream);
+int	cordic_r2p16(const cordic_config *cfg, size_t n,
+		const int16_t *d_xval, const int16_t *d_yval,
+		int16_t *d_omag, uint16_t *d_ophase, void *stream);
+int	cordic_plan_p2r16_const(const cordic_plan *plan, size_t n,
+		int32_t xval, int32_t yval, const uint16_t *d_phase,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream);
+int	cordic_plan_nco16(const cordic_plan *plan, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		int32_t xval, int32_t yval,
+		int16_t *d_oxval, int16_t *d_oyval, void *stream);
 
 /* Host only: the phase-side seed table of a core as 32-bit words
  *   [0] stages M  [1] bucket shift S  [2] nbuckets  [3] nleaves
