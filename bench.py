@@ -54,6 +54,12 @@ WORKLOADS = {
     "qtrtbl": dict(kind="tbl", table=(5, -1, 24, 18), bytes=8, shift=0,
                    desc="quarterwav PW=18 OW=24 (rtl/quarterwav.v), phase "
                    "ramp n"),
+    "quadtbl": dict(kind="tbl", quad=(-1, 13, 2, 18), bytes=8, shift=0,
+                    desc="quadtbl PW=18 OW=13 (rtl/quadtbl.v: 64-entry C/L/Q "
+                    "tables + quadratic interpolation), phase ramp n"),
+    "quadtbl24": dict(kind="tbl", quad=(-1, 24, 2, 32), bytes=8, shift=0,
+                      desc="quadtbl PW=32 OW=24 (512-entry tables), phase "
+                      "ramp n"),
     "cfg3": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, 20), bytes=16,
                  desc="topolar 20-stage, 24-bit I/Q ramps -> mag + phase"),
     "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
@@ -119,8 +125,13 @@ def _cpu_model():
 def bench_table(args, w, ca, dist, dev, world, rank):
     """Table cores (row F4): same timing discipline, gather kernel."""
     import oracle_lib as O
-    kind, iw, ow, pw = w["table"]
-    tab = ca.Table(kind, iw, ow, pw)
+    quad = "quad" in w
+    if quad:
+        tab = ca.Quad(*w["quad"])
+        oq = O.quad_cli(*w["quad"])
+    else:
+        kind, iw, ow, pw = w["table"]
+        tab = ca.Table(kind, iw, ow, pw)
     n = 1 << args.log2_samples
     index0 = rank * n
     phase = torch.empty(n, dtype=torch.int32, device=dev)
@@ -155,9 +166,12 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             np.arange(0, min(n, 4096)), np.arange(max(0, n - 4096), n),
             np.arange(0, n, 65521)])).astype(np.int64)
         ti = torch.from_numpy(idx).to(dev)
-        tv = O.table_values(kind, tab.pw, tab.ow)
-        exp = O.table_lookup(kind, tab.pw, tab.ow, tv,
-                             phase[ti].cpu().numpy().view(np.uint32))
+        sel = phase[ti].cpu().numpy().view(np.uint32)
+        if quad:
+            exp = O.quad_lookup(oq, O.quad_tables(oq), sel)
+        else:
+            tv = O.table_values(kind, tab.pw, tab.ow)
+            exp = O.table_lookup(kind, tab.pw, tab.ow, tv, sel)
         ok = bool(np.array_equal(out[ti].cpu().numpy(), exp))
         avg = float(np.mean(kern_ms)) / 1e3
         achieved = w["bytes"] * n / avg / 1e9
@@ -170,7 +184,8 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, w["desc"]),
                        "samples_per_gpu": n, "pw": tab.pw, "ow": tab.ow,
-                       "entries": tab.entries, "kernel": "table_lookup",
+                       "entries": tab.entries,
+                       "kernel": "quad_lookup" if quad else "table_lookup",
                        "input": args.input, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

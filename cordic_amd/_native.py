@@ -107,6 +107,18 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_quad_config_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int]),
+    "cordic_quad_config_init_core": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
+                                               C.c_int]),
+    "cordic_quad_tables": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p,
+                                     C.c_size_t]),
+    "cordic_quad_write_header": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p,
+                                           C.c_size_t]),
+    "cordic_quad_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cordic_quad_destroy": (None, [C.c_void_p]),
+    "cordic_quad_lookup": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "cordic_table_config_init": (C.c_int, [C.c_void_p] + [C.c_int] * 4),
     "cordic_table_values": (C.c_int, [C.c_void_p, _i32p, C.c_size_t]),
     "cordic_table_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -324,6 +336,72 @@ class Table:
     def close(self):
         if self._h:
             lib().cordic_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _CQuadConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "pw", "ow", "xtra", "tbl_width", "ww", "lgtbl", "entries", "dxbits",
+        "cbits", "lbits", "qbits", "has_reset", "has_aux")] + [
+        ("scale", C.c_int64), ("itbl_err", C.c_double),
+        ("tbl_err", C.c_double), ("spur_db", C.c_double)]
+
+
+class Quad:
+    """A -t qtbl core (quadratically interpolated sine): cordic_quad_config +
+    its device tables.  from_cli mirrors gencordic's flags; from_core the
+    emitter's (phase_bits, ow, nxtra) tuple."""
+
+    def __init__(self, iw=-1, ow=-1, xtra=2, pw=-1, device=True, core=None):
+        self.c = _CQuadConfig()
+        if core is not None:
+            _check(lib().cordic_quad_config_init_core(C.byref(self.c), *core),
+                   "cordic_quad_config_init_core")
+        else:
+            _check(lib().cordic_quad_config_init(C.byref(self.c), iw, ow, xtra,
+                                                 pw), "cordic_quad_config_init")
+        self._h = None
+        if device:
+            h = C.c_void_p()
+            _check(lib().cordic_quad_create(C.byref(self.c), C.byref(h)),
+                   "cordic_quad_create")
+            self._h = h
+
+    def __getattr__(self, name):
+        if name in ("c", "_h"):
+            raise AttributeError(name)
+        return getattr(self.c, name)
+
+    def tables(self):
+        import numpy as np
+        out = [np.empty(self.c.entries, dtype=np.int32) for _ in range(3)]
+        _check(lib().cordic_quad_tables(
+            C.byref(self.c), *[o.ctypes.data_as(_i32p) for o in out],
+            self.c.entries), "cordic_quad_tables")
+        return out
+
+    def header(self, name="quadtbl"):
+        buf = C.create_string_buffer(4096)
+        n = lib().cordic_quad_write_header(C.byref(self.c), name.encode(), buf,
+                                           4096)
+        if n < 0:
+            raise CordicError(n, "cordic_quad_write_header")
+        return buf.value.decode()
+
+    def lookup(self, phase, val, n=None, stream=None):
+        n = phase.numel() if n is None else n
+        _check(lib().cordic_quad_lookup(self._h, n, _ptr(phase), _ptr(val),
+                                        _stream(stream)), "cordic_quad_lookup")
+
+    def close(self):
+        if self._h:
+            lib().cordic_quad_destroy(self._h)
             self._h = None
 
     def __del__(self):

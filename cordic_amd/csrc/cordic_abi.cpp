@@ -278,6 +278,85 @@ int cordic_table_lookup(const cordic_table *tbl, size_t n,
 	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream);
 }
 
+// ------------------------------------------------- quadratic sine core
+struct cordic_quad {
+	cordic_quad_config cfg;
+	int32_t *d_tab = nullptr;	// entries x {C, L, Q, 0}
+};
+
+int cordic_quad_config_init(cordic_quad_config *cfg, int iw, int ow, int xtra,
+		int phase_bits)
+{
+	return quad_build_from_cli(cfg, iw, ow, xtra, phase_bits);
+}
+
+int cordic_quad_config_init_core(cordic_quad_config *cfg, int phase_bits, int ow,
+		int nxtra)
+{
+	return quad_build_core(cfg, phase_bits, ow, nxtra);
+}
+
+int cordic_quad_tables(const cordic_quad_config *cfg, int32_t *ctbl,
+		int32_t *ltbl, int32_t *qtbl, size_t cap)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	return quad_fill(*cfg, ctbl, ltbl, qtbl, cap);
+}
+
+int cordic_quad_write_header(const cordic_quad_config *cfg, const char *name,
+		char *buf, size_t cap)
+{
+	return quad_write_header(cfg, name, buf, cap);
+}
+
+int cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core)
+{
+	if (!cfg || !core || cfg->entries <= 0)
+		return CORDIC_ERR_ARGS;
+	const size_t n = (size_t)cfg->entries;
+	std::vector<int32_t> c(n), l(n), q(n), packed(n * 4);
+	int rc = quad_fill(*cfg, c.data(), l.data(), q.data(), n);
+	if (rc != CORDIC_OK)
+		return rc;
+	for (size_t k = 0; k < n; k++) {
+		packed[4 * k] = c[k];
+		packed[4 * k + 1] = l[k];
+		packed[4 * k + 2] = q[k];
+		packed[4 * k + 3] = 0;
+	}
+	cordic_quad *h = new (std::nothrow) cordic_quad;
+	if (!h)
+		return CORDIC_ERR_ARGS;
+	h->cfg = *cfg;
+	if (hipMalloc((void **)&h->d_tab, packed.size() * 4) != hipSuccess ||
+	    hipMemcpy(h->d_tab, packed.data(), packed.size() * 4,
+			hipMemcpyHostToDevice) != hipSuccess) {
+		if (h->d_tab) (void)hipFree(h->d_tab);
+		delete h;
+		return CORDIC_ERR_DEVICE;
+	}
+	*core = h;
+	return CORDIC_OK;
+}
+
+void cordic_quad_destroy(cordic_quad *core)
+{
+	if (!core)
+		return;
+	if (core->d_tab)
+		(void)hipFree(core->d_tab);
+	delete core;
+}
+
+int cordic_quad_lookup(const cordic_quad *core, size_t n, const uint32_t *d_phase,
+		int32_t *d_sin, void *stream)
+{
+	if (!core)
+		return CORDIC_ERR_ARGS;
+	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream);
+}
+
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
 {
 	if (!cfg)

@@ -30,6 +30,15 @@ const char *status_text(int s);
 int	table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw);
 int	table_fill(const cordic_table_config &t, int32_t *out, size_t cap);
 
+// ---- host: cordic_quadtbl.cpp
+int	quad_build_core(cordic_quad_config *q, int phase_bits, int ow, int nxtra);
+int	quad_build_from_cli(cordic_quad_config *q, int iw, int ow, int xtra,
+		int phase_bits);
+int	quad_fill(const cordic_quad_config &q, int32_t *c, int32_t *l,
+		int32_t *qq, size_t cap);
+int	quad_write_header(const cordic_quad_config *q, const char *name,
+		char *buf, size_t cap);
+
 // Seed tables: stages replaced by the lookup and threads per block of the
 // seeded kernels (one table per block).
 #ifndef CORDIC_SEED_STAGES
@@ -78,6 +87,8 @@ int	launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 		uint32_t mulx, uint32_t muly, int bits, void *stream);
 int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
+		size_t n, const uint32_t *phase, int32_t *val, void *stream);
+int	launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream);
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream);

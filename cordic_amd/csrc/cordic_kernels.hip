@@ -189,6 +189,84 @@ __global__ __launch_bounds__(kBlock) void table_lookup(
 		val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
 }
 
+// ------------------------------------------------- quadratic sine core
+//
+// rtl/quadtbl.v on one sample.  Table entries are {C, L, Q, 0} (one 16-byte
+// gather).  Every intermediate keeps the width of its RTL register:
+//   qprod  QBITS+DXBITS   lsum  LBITS   lprod  LBITS+DXBITS   r_value  CBITS.
+struct QuadParams {
+	int32_t	pw, ow, xtra, ww, lgtbl, dxbits, cbits, lbits;
+};
+
+__device__ __forceinline__ int64_t sext64n(int64_t v, int bits)
+{
+	const int s = 64 - bits;
+	return (int64_t)((uint64_t)v << s) >> s;
+}
+
+__device__ __forceinline__ int32_t quad_sample(const i32x4 e, uint32_t ph,
+		const QuadParams &qp)
+{
+	const int sh = qp.dxbits - 1;
+	const int32_t dx = (int32_t)(ph & ((1u << sh) - 1u));	// :153 {1'b0, ...}
+	const int64_t qprod = (int64_t)e[2] * dx;		// :170
+	// :214-221  w_qprod = sign-extended qprod[top : DXBITS-1]; lsum wraps
+	const int32_t lsum = (int32_t)sext64n((qprod >> sh) + e[1], qp.lbits);
+	const int64_t lprod = (int64_t)lsum * dx;		// :246
+	// :270-277  r_value = w_lprod + cv_3 in CBITS bits
+	const int64_t r = sext64n((lprod >> sh) + e[0], qp.cbits);
+	// :292-300  round to OW bits unless that would overflow
+	const uint32_t rw = (uint32_t)r & (uint32_t)((1ull << qp.ww) - 1ull);
+	const uint32_t body = (rw >> qp.xtra) & ((1u << (qp.ow - 1)) - 1u);
+	const uint32_t top = rw >> (qp.ww - 1);
+	uint32_t w = rw;
+	const bool pos_max = (top == 0) && body == ((1u << (qp.ow - 1)) - 1u);
+	const bool neg_half = (top == 1) && body == (1u << (qp.ow - 2));
+	if (!pos_max && !neg_half) {
+		const uint32_t b = (rw >> qp.xtra) & 1u;
+		w = rw + (1u << (qp.xtra - 1)) - 1u + b;
+	}
+	const int s = 32 - qp.ow;
+	return (int32_t)((w >> qp.xtra) << s) >> s;		// :308
+}
+
+// The tables are small (the generator stops growing them at one LSB of fit
+// error: at most 2^10 entries for the widest core it can write, 16 KiB
+// packed), so every block keeps its own copy in LDS.
+__global__ __launch_bounds__(kBlock) void quad_lookup(
+		const i32x4 *__restrict__ tab, QuadParams qp,
+		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
+		size_t n)
+{
+	extern __shared__ __attribute__((aligned(16))) i32x4 lds_tab[];
+	for (int i = threadIdx.x; i < (1 << qp.lgtbl); i += kBlock)
+		lds_tab[i] = tab[i];
+	__syncthreads();
+	const i32x4 *t = lds_tab;
+	const uint32_t imask = (1u << qp.lgtbl) - 1u;
+	const int ish = qp.dxbits - 1;
+	const size_t nvec = n / kVec;
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	const bool vec_ok = ((reinterpret_cast<uintptr_t>(phase)
+			| reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
+	size_t done = 0;
+	if (vec_ok) {
+		for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
+				g += stride) {
+			const u32x4 p = reinterpret_cast<const u32x4 *>(phase)[g];
+			i32x4 o;
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				o[v] = quad_sample(t[(p[v] >> ish) & imask], p[v], qp);
+			reinterpret_cast<i32x4 *>(val)[g] = o;
+		}
+		done = nvec * kVec;
+	}
+	for (size_t i = done + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+			i += stride)
+		val[i] = quad_sample(t[(phase[i] >> ish) & imask], phase[i], qp);
+}
+
 // mix(): a 64-bit finaliser over (global index, word) so that the digest is
 // sensitive to both value and position, yet shards simply add.
 __device__ __forceinline__ uint64_t digest_mix(uint64_t idx, uint32_t w)
@@ -553,6 +631,25 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 	else
 		hipLaunchKernelGGL(table_lookup<false>, dim3(grid), dim3(kBlock), 0,
 				st, d_tbl, phase, val, n, t.pw, t.ow);
+	return check_launch();
+}
+
+int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
+		size_t n, const uint32_t *phase, int32_t *val, void *stream)
+{
+	clear_stale_error();
+	if (n == 0) return CORDIC_OK;
+	if (!d_tables || !phase || !val) return CORDIC_ERR_ARGS;
+	const int grid = grid_for(kTile, n);
+	if (grid < 0) return CORDIC_ERR_DEVICE;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	QuadParams qp{q.pw, q.ow, q.xtra, q.ww, q.lgtbl, q.dxbits, q.cbits, q.lbits};
+	const i32x4 *tab = reinterpret_cast<const i32x4 *>(d_tables);
+	const size_t bytes = (size_t)q.entries * sizeof(i32x4);
+	if (bytes > 64 * 1024)
+		return CORDIC_ERR_UNSUPPORTED;
+	hipLaunchKernelGGL(quad_lookup, dim3(grid), dim3(kBlock), bytes, st, tab,
+			qp, phase, val, n);
 	return check_launch();
 }
 

@@ -1,0 +1,316 @@
+// cordic_quadtbl.cpp -- host side of the quadratically interpolated sine core
+// (gencordic -t qtbl): parameter derivation and the three coefficient tables.
+//
+// Follows, value for value, what the reference generator computes in
+//   sw/main.cpp:444-463     CLI defaulting (nxtra = -x + 1, PW from WW)
+//   sw/quadtbl.cpp:117-130  pick_tbl_size (only feeds an assert)
+//   sw/quadtbl.cpp:132-279  build_quadtbls: C / L / Q tables and their widths
+//   sw/quadtbl.cpp:281-313  quadtbl(): grow the table until |error| <= 1 LSB
+//   sw/quadtbl.cpp:771-811  the constants of the generated header
+// The floating-point expressions keep the reference's operation order (this
+// file is compiled with -ffp-contract=off), because table entries are
+// (long)(maxv * coefficient) and a last-bit difference in a double can move
+// an entry by one: the tables are tested for equality against the .hex files
+// the real generator writes (tests/golden/quad_golden.json).
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cordic_internal.h"
+
+namespace cordic_amd {
+namespace {
+
+// sw/quadtbl.cpp:58-61 -- note the argument is scaled by pi inside
+double sinc_of(double v)
+{
+	const double x = v * M_PI;
+	return std::sin(x) / x;
+}
+
+long largest_entry(int width) { return (1l << (width - 1)) - 2l; }	// :63-65
+
+// sw/quadtbl.cpp:74-115: the worst of the fit error at the left end, at the
+// right end and on a 64-point grid inside table interval `idx`
+double interval_error(double c, double l, double q, double idx, int entries)
+{
+	double ph = 2.0 * M_PI * idx / (double)entries;
+	const double at_left = c - std::sin(ph);
+	ph = 2.0 * M_PI * (idx + 1) / (double)entries;
+	const double at_right = c + l + q - std::sin(ph);
+	double inside = 0;
+	for (int k = 0; k < 64; k++) {
+		const double dx = k / 64.0;
+		const double mph = 2.0 * M_PI * (idx + dx) / entries;
+		const double e = c + (l + q * dx) * dx - std::sin(mph);
+		if (std::fabs(e) > std::fabs(inside))
+			inside = e;
+	}
+	double worst = at_left;
+	if (std::fabs(worst) < std::fabs(at_right))
+		worst = at_right;
+	if (std::fabs(worst) < std::fabs(inside))
+		worst = inside;
+	return worst;
+}
+
+int first_table_guess(int ww)						// :117-130
+{
+	const double limit = std::pow(0.5, ww);
+	for (int lg = 4; lg < 10; lg++)
+		if (std::pow(sinc_of(1.0 - (1. / (1 << lg))), 3.) < limit)
+			return lg;
+	return 11;
+}
+
+struct QuadFit {
+	int	cbits = 0, lbits = 0, qbits = 0;
+	double	err = 0;		// worst fit error in units of maxv
+	bool	representable = false;	// the reference's asserts all hold
+	std::vector<long> c, l, q;
+};
+
+// sw/quadtbl.cpp:132-279 for one table size
+QuadFit fit_tables(int lgsz, int wid)
+{
+	QuadFit f;
+	const int n = 1 << lgsz;
+	const long maxv = largest_entry(wid);
+	const double dl = M_PI / (double)n, dph = dl * 2.;
+	std::vector<double> c(n), l(n), q(n);
+
+	for (int i = 0; i < n; i++)				// :149-150
+		c[i] = std::sin(dph * i + dl);
+	for (int i = 1; i < n - 1; i++)				// :153-156
+		l[i] = (c[i + 1] - c[i - 1]) / 2.0;
+	l[0] = (c[1] - c[n - 1]) / 2.0;
+	l[n - 1] = (c[0] - c[n - 2]) / 2.0;
+	for (int i = 1; i < n - 1; i++)				// :159-162
+		q[i] = -(c[i] - 0.5 * (c[i + 1] + c[i - 1]));
+	q[0] = -(c[0] - 0.5 * (c[1] + c[n - 1]));
+	q[n - 1] = -(c[n - 1] - 0.5 * (c[0] + c[n - 2]));
+	for (int i = 0; i < n; i++)				// :167-170
+		c[i] = 0.75 * std::sin(dph * i + dl)
+			+ (std::sin(dph * (i - 1) + dl)
+			+  std::sin(dph * (i + 1) + dl)) / 8.0;
+
+	// re-centre the parabola on the left edge of its interval	   :179-185
+	const double del = 1.0, half = del / 2.0;
+	for (int i = 0; i < n; i++)
+		c[i] = q[i] * half * half - l[i] * half + c[i];
+	for (int i = 0; i < n; i++)
+		l[i] = l[i] - del * q[i];
+
+	const double fctr = std::pow(1. / sinc_of(dl), 3);		// :190-193
+	for (int i = 0; i < n; i++) c[i] *= fctr;
+	for (int i = 0; i < n; i++) l[i] *= fctr;
+	for (int i = 0; i < n; i++) q[i] *= fctr;
+
+	double mxc = 0.0;						// :196-205
+	for (int i = 0; i < n; i++)
+		mxc = (mxc > std::fabs(c[i])) ? mxc : std::fabs(c[i]);
+	for (int i = 0; i < n; i++) c[i] *= 1. / mxc;
+	for (int i = 0; i < n; i++) l[i] *= 1. / mxc;
+	for (int i = 0; i < n; i++) q[i] *= 1. / mxc;
+
+	double worst = 0.0;						// :207-217
+	for (int i = 0; i < n; i++) {
+		const double e = interval_error(c[i], l[i], q[i], i, n);
+		if (std::fabs(e) > std::fabs(worst))
+			worst = e;
+	}
+	worst *= maxv;
+	f.err = worst;
+
+	double mxl = 0.0, mxq = 0.0;					// :219-225
+	mxc = 0.0;
+	for (int i = 0; i < n; i++)
+		mxc = (mxc > std::fabs(c[i])) ? mxc : std::fabs(c[i]);
+	for (int i = 0; i < n; i++) {
+		mxl = (mxl > std::fabs(l[i])) ? mxl : std::fabs(l[i]);
+		mxq = (mxq > std::fabs(q[i])) ? mxq : std::fabs(q[i]);
+	}
+	f.cbits = wid + (int)std::ceil(std::log(mxc) / std::log(2.0));	   // :231-233
+	f.lbits = wid + (int)std::ceil(-std::log(1. / mxl) / std::log(2.0));
+	f.qbits = wid + (int)std::ceil(-std::log(1. / mxq) / std::log(2.0));
+
+	// the reference assert()s these (:237-241 and sw/hexfile.cpp:52-59,81-84)
+	bool ok = f.cbits >= wid && f.cbits < 31 && f.lbits >= 1 && f.lbits < 31
+		&& f.qbits >= 1 && f.qbits < 31;
+	for (int i = 0; ok && i < n; i++)
+		ok = std::fabs(c[i]) <= (double)(1 << (f.cbits - wid))
+			&& std::fabs(l[i]) <= std::pow(2., (f.lbits - wid))
+			&& std::fabs(q[i]) <= std::pow(2., (f.qbits - wid));
+
+	f.c.resize(n); f.l.resize(n); f.q.resize(n);
+	for (int k = 0; k < n; k++) {					// :243-259
+		f.c[k] = (long)(maxv * c[k]);
+		f.l[k] = (long)(maxv * l[k]);
+		f.q[k] = (long)(maxv * q[k]);
+	}
+	auto fits = [](long v, int bits) {
+		const long msk = (1l << bits) - 1l;
+		return (v > 0) ? (v <= msk) : (v >= -msk - 1);
+	};
+	for (int k = 0; ok && k < n; k++)
+		ok = fits(f.c[k], f.cbits) && fits(f.l[k], f.lbits)
+			&& fits(f.q[k], f.qbits);
+	f.representable = ok;
+	return f;
+}
+
+// sw/quadtbl.cpp:281-313: the fit the generator settles on
+int settle(int phase_bits, int ow, int nxtra, QuadFit *out, int *lgtbl)
+{
+	if (ow < 3 || ow > 32)		// rtl/quadtbl.v:294 selects r_value[WW-3:XTRA]
+		return CORDIC_ERR_WIDTH;
+	if (nxtra < 0)
+		return CORDIC_ERR_ARGS;				// assert(nxtra >= 0)
+	const int wid = ow + nxtra;
+	if (wid <= 6 || wid > 30)
+		return CORDIC_ERR_WIDTH;	// assert(wid > 6); hextable: < 31 bits
+	if (phase_bits <= 4 || phase_bits > 32
+			|| phase_bits <= first_table_guess(wid))
+		return CORDIC_ERR_PHASE_BITS;			// :294-295
+	int lg = 3;
+	QuadFit f;
+	do {
+		lg++;
+		f = fit_tables(lg, wid);
+		if (!f.representable)
+			return CORDIC_ERR_UNSUPPORTED;
+	} while (std::fabs(f.err) > 1.0 && lg < 20);
+	*out = std::move(f);
+	*lgtbl = lg;
+	return CORDIC_OK;
+}
+
+} // namespace
+
+int quad_build_core(cordic_quad_config *q, int phase_bits, int ow, int nxtra)
+{
+	if (!q)
+		return CORDIC_ERR_ARGS;
+	std::memset(q, 0, sizeof(*q));
+	QuadFit f;
+	int lg = 0;
+	if (int rc = settle(phase_bits, ow, nxtra, &f, &lg))
+		return rc;
+	q->pw = phase_bits;
+	q->ow = ow;
+	q->tbl_width = ow + nxtra;
+	q->xtra = (nxtra < 2) ? 2 : nxtra;			// :333-334
+	q->ww = q->ow + q->xtra;				// localparam WW
+	q->lgtbl = lg;
+	q->entries = 1 << lg;
+	q->dxbits = (phase_bits - lg) + 1;
+	q->cbits = f.cbits;
+	q->lbits = f.lbits;
+	q->qbits = f.qbits;
+	q->scale = largest_entry(ow);				// :789-790
+	q->itbl_err = f.err;
+	q->tbl_err = f.err * std::pow(0.5, ow + q->xtra);	// :793-794
+	double spur = std::pow(sinc_of(1.0 - (1. / (1 << lg))), 3.);
+	q->spur_db = 20. * std::log(spur) / std::log(10.0);	// :796-799
+	q->has_reset = 1;
+	q->has_aux = 0;
+	// What the emitted RTL needs in order to elaborate (rtl/quadtbl.v:149-153,
+	// 214-216, 244-271): two or more dx bits, the sign replications of
+	// w_qprod / w_lprod non-negative, and r_value at least WW bits wide.
+	if (q->dxbits < 2 || q->lbits - q->qbits - 1 < 0
+			|| q->cbits - q->lbits - 1 < 0 || q->cbits < q->ww
+			|| q->ww - q->ow < 1)
+		return CORDIC_ERR_UNSUPPORTED;
+	return CORDIC_OK;
+}
+
+// sw/main.cpp:444-463
+int quad_build_from_cli(cordic_quad_config *q, int iw, int ow, int xtra,
+		int phase_bits)
+{
+	if (!q)
+		return CORDIC_ERR_ARGS;
+	if (iw <= 0 && ow > 0)
+		iw = ow;
+	if (ow <= 0)
+		ow = iw;
+	if (iw <= 0 || ow <= 0)
+		iw = ow = 24;					// DEFAULT_BITWIDTH
+	if (iw > 32 || ow > 32)
+		return CORDIC_ERR_WIDTH;
+	const int nxtra = xtra + 1;
+	const int ww = ((ow > iw) ? ow : iw) + nxtra;
+	if (phase_bits <= 0) {
+		if (ww < 1 || ww > 62)
+			return CORDIC_ERR_WORKING_WIDTH;
+		phase_bits = phase_bits_for(ww);
+	}
+	return quad_build_core(q, phase_bits, ow, nxtra);
+}
+
+int quad_fill(const cordic_quad_config &q, int32_t *c, int32_t *l, int32_t *qq,
+		size_t cap)
+{
+	if (!c || !l || !qq || cap < (size_t)q.entries)
+		return CORDIC_ERR_ARGS;
+	if (q.lgtbl < 4 || q.lgtbl > 20 || q.tbl_width <= 6 || q.tbl_width > 30)
+		return CORDIC_ERR_ARGS;
+	const QuadFit f = fit_tables(q.lgtbl, q.tbl_width);
+	if (!f.representable || f.cbits != q.cbits || f.lbits != q.lbits
+			|| f.qbits != q.qbits)
+		return CORDIC_ERR_ARGS;
+	for (int k = 0; k < q.entries; k++) {
+		c[k] = (int32_t)f.c[k];
+		l[k] = (int32_t)f.l[k];
+		qq[k] = (int32_t)f.q[k];
+	}
+	return CORDIC_OK;
+}
+
+// The constants block of the generated header (sw/quadtbl.cpp:771-811),
+// from "#ifndef" to "#endif".
+int quad_write_header(const cordic_quad_config *q, const char *name, char *buf,
+		size_t cap)
+{
+	if (!q || !name)
+		return CORDIC_ERR_ARGS;
+	// guard = "<name>.h" upper-cased with '.' -> '_'	(:774-782)
+	std::string guard = std::string(name) + ".h";
+	for (auto &ch : guard)
+		ch = (ch == '.') ? '_' : (char)std::toupper((unsigned char)ch);
+	char line[160];
+	std::string s;
+	auto add = [&](const char *fmt, auto... a) {
+		std::snprintf(line, sizeof line, fmt, a...);
+		s += line;
+	};
+	add("#ifndef	%s\n", guard.c_str());
+	add("#define	%s\n", guard.c_str());
+	add("const\tint\tOW         = %d; // bits\n", q->ow);
+	add("const\tint\tNEXTRA     = %d; // bits\n", q->xtra);
+	add("const\tint\tPW         = %d; // bits\n", q->pw);
+	add("const\tlong\tTBL_LGSZ  = %d; // (Units)\n", q->lgtbl);
+	add("const\tlong\tTBL_SZ    = %ld; // (Units)\n", 1l << q->lgtbl);
+	add("const\tlong\tSCALE     = %ld; // (Units)\n", (long)q->scale);
+	add("const\tdouble\tITBL_ERR  = %.2f; // (OW Units)\n", q->itbl_err);
+	add("const\tdouble\tTBL_ERR   = %.16f; // (sin Units)\n", q->tbl_err);
+	add("const\tdouble\tSPURDB    = %6.2f; // dB\n", q->spur_db);
+	add("const\tbool\tHAS_RESET = %s;\n", q->has_reset ? "true" : "false");
+	add("const\tbool\tHAS_AUX   = %s;\n", q->has_aux ? "true" : "false");
+	if (q->has_reset)
+		s += "#define\tHAS_RESET_WIRE\n";
+	if (q->has_aux)
+		s += "#define\tHAS_AUX_WIRES\n";
+	add("#endif	// %s\n", guard.c_str());
+	if (buf && cap > 0) {
+		const size_t k = (s.size() < cap - 1) ? s.size() : cap - 1;
+		std::memcpy(buf, s.data(), k);
+		buf[k] = 0;
+	}
+	return (int)s.size();
+}
+
+} // namespace cordic_amd

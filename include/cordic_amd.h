@@ -294,6 +294,60 @@ void	cordic_table_destroy(cordic_table *tbl);
 int	cordic_table_lookup(const cordic_table *tbl, size_t n,
 		const uint32_t *d_phase, int32_t *d_val, void *stream);
 
+/* ---------------------------------- quadratically interpolated sine core
+ *
+ * gencordic -t qtbl (sw/quadtbl.cpp, rtl/quadtbl.v): three 2^LGTBL-entry
+ * coefficient tables C, L, Q indexed by the top LGTBL phase bits, and
+ *   o_sin = round((((Q*dx >> (DXBITS-1)) + L) * dx >> (DXBITS-1)) + C)
+ * on the remaining phase bits dx, in the exact bit widths of rtl/quadtbl.v
+ * :149-153 (lookup), :170 (qprod), :214-221 (lsum), :246 (lprod), :270-277
+ * (r_value), :292-300 (convergent rounding with the two no-overflow cases),
+ * :308 (o_sin).
+ */
+typedef struct cordic_quad_config {
+	int32_t	pw;		/* PW                                         */
+	int32_t	ow;		/* OW                                         */
+	int32_t	xtra;		/* XTRA of the emitted core = max(nxtra, 2)   */
+	int32_t	tbl_width;	/* OW + nxtra: width the tables are built for */
+	int32_t	ww;		/* WW = OW + XTRA                             */
+	int32_t	lgtbl;		/* LGTBL                                      */
+	int32_t	entries;	/* TBLENTRIES = 2^LGTBL                       */
+	int32_t	dxbits;		/* DXBITS = PW - LGTBL + 1                    */
+	int32_t	cbits, lbits, qbits;	/* CBITS, LBITS, QBITS                */
+	int32_t	has_reset, has_aux;
+	int64_t	scale;		/* SCALE    (generated header)                */
+	double	itbl_err;	/* ITBL_ERR, full precision                   */
+	double	tbl_err;	/* TBL_ERR                                    */
+	double	spur_db;	/* SPURDB                                     */
+} cordic_quad_config;
+
+typedef struct cordic_quad cordic_quad;	/* tables resident on the device */
+
+/* gencordic -t qtbl -i iw -o ow -x xtra -p phase_bits (sw/main.cpp:444-463);
+ * <= 0 = absent.  The table size grows from 16 entries until the fit error
+ * is within one LSB of the working width (sw/quadtbl.cpp:306-310). */
+int	cordic_quad_config_init(cordic_quad_config *cfg, int iw, int ow,
+		int xtra, int phase_bits);
+/* the emitter's own tuple: quadtbl(fp, fhp, cmdline, fname, phase_bits, ow,
+ * nxtra, ...) (sw/quadtbl.h:47-49), nxtra already incremented */
+int	cordic_quad_config_init_core(cordic_quad_config *cfg, int phase_bits,
+		int ow, int nxtra);
+/* The three tables as the generator writes them to <name>_ctbl.hex,
+ * <name>_ltbl.hex, <name>_qtbl.hex (sw/quadtbl.cpp:243-259), as sign-extended
+ * values; each array has room for `cap` >= entries values. */
+int	cordic_quad_tables(const cordic_quad_config *cfg, int32_t *ctbl,
+		int32_t *ltbl, int32_t *qtbl, size_t cap);
+/* constants header of the core (sw/quadtbl.cpp:771-811), as
+ * cordic_config_write_header */
+int	cordic_quad_write_header(const cordic_quad_config *cfg, const char *name,
+		char *buf, size_t cap);
+int	cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core);
+void	cordic_quad_destroy(cordic_quad *core);
+/* d_sin[i] = o_sin of the core for i_phase = d_phase[i] (low PW bits),
+ * sign-extended OW-bit values */
+int	cordic_quad_lookup(const cordic_quad *core, size_t n,
+		const uint32_t *d_phase, int32_t *d_sin, void *stream);
+
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,

@@ -13,6 +13,7 @@
  * text (see the header).  Table/parameter math is pinned against the real
  * generator's output.
  */
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 #include "cordic_oracle.h"
@@ -657,6 +658,269 @@ void orc_nco(const orc_config *c, size_t n, uint32_t phase0, uint32_t fcw,
 		orc_rotate(c, 1, &x0, &y0, 0, &ph, &ox[s], &oy[s]);
 	}
 }
+
+/* ------------------------------------------------------------ quadtbl core
+ *
+ * sw/quadtbl.cpp builds three tables in double precision; the statements
+ * below are kept in the reference's evaluation order on purpose (an entry is
+ * (long)(maxv * coefficient), so the doubles have to agree to the last bit;
+ * compile with -ffp-contract=off).  Pinned by tests/golden/quad_golden.json:
+ * the .hex files and header constants the real generator writes. */
+
+static double q_sinc(double v)			/* sw/quadtbl.cpp:58-61 */
+{
+	double x = v * M_PI;
+	return sin(x) / x;
+}
+
+static long q_max_integer(int width)		/* :63-65 */
+{
+	return (1l << (width - 1)) - 2l;
+}
+
+static double q_est_max_err(double c, double l, double q, double idx, int N)
+{						/* :74-115 */
+	double lft, rht, mid, ph, er;
+	ph = 2.0 * M_PI * idx / (double)N;
+	lft = c - sin(ph);
+	ph = 2.0 * M_PI * (idx + 1) / (double)N;
+	rht = c + l + q - sin(ph);
+	mid = 0;
+	for (int k = 0; k < 64; k++) {
+		double mdx = k / 64.0;
+		double mph = 2.0 * M_PI * (idx + mdx) / N;
+		double mer = c + (l + q * mdx) * mdx - sin(mph);
+		if (fabs(mer) > fabs(mid))
+			mid = mer;
+	}
+	er = lft;
+	if (fabs(er) < fabs(rht)) er = rht;
+	if (fabs(er) < fabs(mid)) er = mid;
+	return er;
+}
+
+static int q_pick_tbl_size(int ww)		/* :117-130 */
+{
+	double limit = pow(0.5, ww);
+	for (int lgtbl = 4; lgtbl < 10; lgtbl++)
+		if (pow(q_sinc(1.0 - (1. / (1 << lgtbl))), 3.) < limit)
+			return lgtbl;
+	return 11;
+}
+
+/* sw/quadtbl.cpp:132-279.  Returns 0, or -1 where the reference assert()s.
+ * c/l/q may be NULL (widths and error only). */
+static int q_build(int lgsz, int wid, int *cbits, int *lbits, int *qbits,
+		double *tblerr, long *ct, long *lt, long *qt)
+{
+	if (lgsz <= 2 || wid <= 6)	/* assert(lgsz > 2); assert(wid > 6) */
+		return -1;
+	int ln = 1 << lgsz, rc = 0;
+	long maxv = q_max_integer(wid);
+	double dl = M_PI / (double)ln, dph = dl * 2.;
+	double *table = calloc(ln, sizeof(double));
+	double *slope = calloc(ln, sizeof(double));
+	double *dslope = calloc(ln, sizeof(double));
+	if (!table || !slope || !dslope) {
+		free(table); free(slope); free(dslope);
+		return -1;
+	}
+	for (int i = 0; i < ln; i++)
+		table[i] = sin(dph * i + dl);
+	for (int i = 1; i < ln - 1; i++)
+		slope[i] = (table[i + 1] - table[i - 1]) / 2.0;
+	slope[0] = (table[1] - table[ln - 1]) / 2.0;
+	slope[ln - 1] = (table[0] - table[ln - 2]) / 2.0;
+	for (int i = 1; i < ln - 1; i++)
+		dslope[i] = -(table[i] - 0.5 * (table[i + 1] + table[i - 1]));
+	dslope[0] = -(table[0] - 0.5 * (table[1] + table[ln - 1]));
+	dslope[ln - 1] = -(table[ln - 1] - 0.5 * (table[0] + table[ln - 2]));
+	for (int i = 0; i < ln; i++)
+		table[i] = 0.75 * sin(dph * i + dl)
+			+ (sin(dph * (i - 1) + dl) + sin(dph * (i + 1) + dl)) / 8.0;
+	{
+		const double del = 1.0, hlfdel = del / 2.0;
+		for (int i = 0; i < ln; i++)
+			table[i] = dslope[i] * hlfdel * hlfdel
+				- slope[i] * hlfdel + table[i];
+		for (int i = 0; i < ln; i++)
+			slope[i] = slope[i] - del * dslope[i];
+	}
+	{
+		double fctr = pow(1. / q_sinc(dl), 3);
+		for (int i = 0; i < ln; i++) table[i] *= fctr;
+		for (int i = 0; i < ln; i++) slope[i] *= fctr;
+		for (int i = 0; i < ln; i++) dslope[i] *= fctr;
+	}
+	double mxtbl = 0.0, mxslope = 0.0, mxdslope = 0.0;
+	for (int i = 0; i < ln; i++)
+		mxtbl = (mxtbl > fabs(table[i])) ? mxtbl : fabs(table[i]);
+	for (int i = 0; i < ln; i++) table[i] *= 1. / mxtbl;
+	for (int i = 0; i < ln; i++) slope[i] *= 1. / mxtbl;
+	for (int i = 0; i < ln; i++) dslope[i] *= 1. / mxtbl;
+
+	double mxerr = 0.0;
+	for (int i = 0; i < ln; i++) {
+		double err = q_est_max_err(table[i], slope[i], dslope[i], i, ln);
+		if (fabs(err) > fabs(mxerr))
+			mxerr = err;
+	}
+	mxerr *= maxv;
+	*tblerr = mxerr;
+
+	mxtbl = 0.0;
+	for (int i = 0; i < ln; i++)
+		mxtbl = (mxtbl > fabs(table[i])) ? mxtbl : fabs(table[i]);
+	for (int i = 0; i < ln; i++) {
+		mxslope = (mxslope > fabs(slope[i])) ? mxslope : fabs(slope[i]);
+		mxdslope = (mxdslope > fabs(dslope[i])) ? mxdslope : fabs(dslope[i]);
+	}
+	*cbits = wid + (int)ceil(log(mxtbl) / log(2.0));
+	*lbits = wid + (int)ceil(-log(1. / mxslope) / log(2.0));
+	*qbits = wid + (int)ceil(-log(1. / mxdslope) / log(2.0));
+
+	/* the asserts of :237-241 and of hextable (sw/hexfile.cpp:52-59,81-84) */
+	if (*cbits < wid || *cbits >= 31 || *lbits < 1 || *lbits >= 31
+			|| *qbits < 1 || *qbits >= 31)
+		rc = -1;
+	for (int i = 0; !rc && i < ln; i++) {
+		if (!(fabs(table[i]) <= (1 << (*cbits - wid)))) rc = -1;
+		if (!(fabs(slope[i]) <= pow(2., (*lbits - wid)))) rc = -1;
+		if (!(fabs(dslope[i]) <= pow(2., (*qbits - wid)))) rc = -1;
+	}
+	for (int k = 0; !rc && k < ln; k++) {
+		long v[3] = { (long)(maxv * table[k]), (long)(maxv * slope[k]),
+			      (long)(maxv * dslope[k]) };
+		int b[3] = { *cbits, *lbits, *qbits };
+		for (int j = 0; j < 3; j++) {
+			long msk = (1l << b[j]) - 1l;
+			if ((v[j] > 0) ? (v[j] > msk) : (v[j] < -msk - 1))
+				rc = -1;
+		}
+		if (ct) { ct[k] = v[0]; lt[k] = v[1]; qt[k] = v[2]; }
+	}
+	free(table); free(slope); free(dslope);
+	return rc;
+}
+
+/* sw/quadtbl.cpp:281-357: the emitter's view */
+int orc_quad_core(orc_quad *q, int phase_bits, int ow, int nxtra)
+{
+	memset(q, 0, sizeof(*q));
+	if (nxtra < 0 || ow < 3 || ow > 32)
+		return -1;
+	int wid = ow + nxtra;
+	if (wid <= 6 || wid > 30)			/* assert(wid > 6) */
+		return -1;
+	if (phase_bits <= 4 || phase_bits > 32)		/* assert(phase_bits>4) */
+		return -1;
+	if (phase_bits <= q_pick_tbl_size(wid))		/* assert(phase_bits>lgtbl) */
+		return -1;
+	int lgtbl = 3, cbits, lbits, qbits;
+	double tblerr;
+	do {
+		lgtbl++;
+		if (q_build(lgtbl, wid, &cbits, &lbits, &qbits, &tblerr,
+				NULL, NULL, NULL))
+			return -2;
+	} while ((fabs(tblerr) > 1.0) && (lgtbl < 20));
+	if (nxtra < 2)
+		nxtra = 2;
+	q->pw = phase_bits; q->ow = ow; q->xtra = nxtra; q->wid = wid;
+	q->ww = ow + nxtra;				/* localparam WW=(OW+XTRA) */
+	q->lgtbl = lgtbl;
+	q->dxbits = (phase_bits - lgtbl) + 1;
+	q->cbits = cbits; q->lbits = lbits; q->qbits = qbits;
+	q->scale = q_max_integer(ow);
+	q->itbl_err = tblerr;
+	q->tbl_err = tblerr * pow(0.5, ow + nxtra);
+	{
+		double spur = pow(q_sinc(1.0 - (1. / (1 << lgtbl))), 3.);
+		q->spur_db = 20. * log(spur) / log(10.0);
+	}
+	/* part selects of rtl/quadtbl.v that must stay in range */
+	if (q->dxbits < 2 || lbits - qbits - 1 < 0 || cbits - lbits - 1 < 0
+			|| cbits < q->ww)
+		return -2;
+	return 0;
+}
+
+int orc_quad_cli(orc_quad *q, int iw, int ow, int xtra, int phase_bits)
+{						/* sw/main.cpp:444-463 */
+	int nxtra = xtra, ww;
+	if ((iw <= 0) && (ow > 0)) iw = ow;
+	if (ow <= 0) ow = iw;
+	if ((iw <= 0) || (ow <= 0)) { iw = 24; ow = 24; }
+	ww = (ow > iw) ? ow : iw;
+	nxtra += 1;
+	ww += nxtra;
+	if (phase_bits <= 0) {
+		if (ww < 1 || ww > 62)
+			return -1;
+		phase_bits = orc_calc_phase_bits(ww);
+	}
+	return orc_quad_core(q, phase_bits, ow, nxtra);
+}
+
+int orc_quad_tables(const orc_quad *q, long *ctbl, long *ltbl, long *qtbl)
+{
+	int c, l, qq;
+	double e;
+	return q_build(q->lgtbl, q->wid, &c, &l, &qq, &e, ctbl, ltbl, qtbl);
+}
+
+/* value of bits [hi:lo] of v */
+static uint64_t q_bits(uint64_t v, int hi, int lo)
+{
+	return (v >> lo) & ((hi - lo + 1 >= 64) ? ~0ull
+				: ((1ull << (hi - lo + 1)) - 1ull));
+}
+
+/* rtl/quadtbl.v:140-310, one sample, register by register */
+void orc_quad_lookup(const orc_quad *q, const long *ctbl, const long *ltbl,
+		const long *qtbl, size_t n, const uint32_t *phase, int32_t *out)
+{
+	const int PW = q->pw, OW = q->ow, XTRA = q->xtra, WW = q->ww;
+	const int DX = q->dxbits, QB = q->qbits, LB = q->lbits, CB = q->cbits;
+	for (size_t s = 0; s < n; s++) {
+		const uint64_t ph = phase[s] & pmask(PW);
+		/* clock 1 (:149-153) */
+		const uint64_t idx = q_bits(ph, PW - 1, DX - 1);
+		const int64_t qv = sx(qtbl[idx], QB), lv = sx(ltbl[idx], LB),
+			cv = sx(ctbl[idx], CB);
+		const int64_t dx = (int64_t)q_bits(ph, DX - 2, 0); /* {1'b0, ...} */
+		/* clock 2 (:170): signed product in QBITS+DXBITS bits */
+		const uint64_t qprod = (uint64_t)sx(qv * dx, QB + DX);
+		/* clock 3 (:214-221) */
+		uint64_t w_qprod = q_bits(qprod, QB + DX - 1, DX - 1);	/* [QBITS:0] */
+		if (LB - QB - 1 > 0 && q_bits(qprod, QB + DX - 1, QB + DX - 1))
+			w_qprod |= ((1ull << (LB - QB - 1)) - 1ull) << (QB + 1);
+		const int64_t lsum = sx((int64_t)(w_qprod + (uint64_t)lv), LB);
+		/* clock 4 (:246) */
+		const uint64_t lprod = (uint64_t)sx(lsum * dx, LB + DX);
+		/* clock 5 (:270-277) */
+		uint64_t w_lprod = q_bits(lprod, LB + DX - 1, DX - 1);	/* [LBITS:0] */
+		if (CB - LB - 1 > 0 && q_bits(lprod, LB + DX - 1, LB + DX - 1))
+			w_lprod |= ((1ull << (CB - LB - 1)) - 1ull) << (LB + 1);
+		const uint64_t r = (uint64_t)sx((int64_t)(w_lprod + (uint64_t)cv), CB)
+			& ((1ull << CB) - 1ull);
+		/* clock 6 (:292-300) */
+		uint64_t w;
+		if (!q_bits(r, WW - 1, WW - 1)
+				&& q_bits(r, WW - 2, XTRA) == (1ull << (WW - 1 - XTRA)) - 1ull)
+			w = r;
+		else if (q_bits(r, WW - 1, WW - 2) == 3 && !q_bits(r, WW - 3, XTRA))
+			w = r;
+		else {
+			const uint64_t b = q_bits(r, WW - OW, WW - OW);
+			const uint64_t rest = b ? 0 : ((1ull << (WW - OW - 1)) - 1ull);
+			w = r + ((b << (WW - OW - 1)) | rest);
+		}
+		w &= (1ull << WW) - 1ull;
+		out[s] = (int32_t)sx((int64_t)q_bits(w, WW - 1, XTRA), OW); /* :308 */
+	}
+}
+
 
 /* ------------------------------------------------------------ CPU baseline
  *

@@ -111,6 +111,23 @@ void	orc_table_values(int kind, int pw, int ow, int32_t *out);
 void	orc_table_lookup(int kind, int pw, int ow, const int32_t *tbl, size_t n,
 		const uint32_t *phase, int32_t *out);
 
+/* quadratically interpolated sine core (sw/quadtbl.cpp, rtl/quadtbl.v) */
+typedef struct orc_quad {
+	int	pw, ow, xtra;		/* XTRA of the emitted core */
+	int	wid;			/* OW + nxtra the tables were built for */
+	int	ww, lgtbl, dxbits, cbits, lbits, qbits;
+	long	scale;
+	double	itbl_err, tbl_err, spur_db;
+} orc_quad;
+/* CLI level (sw/main.cpp:444-463); returns 0 or a negative code when the
+ * reference would assert / emit a core that cannot elaborate */
+int	orc_quad_cli(orc_quad *q, int iw, int ow, int xtra, int phase_bits);
+int	orc_quad_core(orc_quad *q, int phase_bits, int ow, int nxtra);
+/* tables of 2^lgtbl signed entries each */
+int	orc_quad_tables(const orc_quad *q, long *ctbl, long *ltbl, long *qtbl);
+void	orc_quad_lookup(const orc_quad *q, const long *ctbl, const long *ltbl,
+		const long *qtbl, size_t n, const uint32_t *phase, int32_t *out);
+
 /* bench.py cpu_baseline: samples processed by nthreads threads in `seconds` */
 uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
 		double seconds, uint32_t phase_mul, int32_t x0, int32_t y0);

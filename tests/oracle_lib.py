@@ -191,3 +191,64 @@ def table_lookup(kind, pw, ow, tbl, phase):
     lib().orc_table_lookup(kind, pw, ow, _i32(np.ascontiguousarray(tbl)),
                            phase.size, _u32(phase), _i32(out))
     return out
+
+
+# ---- quadratically interpolated sine core (oracle: orc_quad_*)
+
+class OrcQuad(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "pw", "ow", "xtra", "wid", "ww", "lgtbl", "dxbits", "cbits", "lbits",
+        "qbits")] + [("scale", C.c_long), ("itbl_err", C.c_double),
+                     ("tbl_err", C.c_double), ("spur_db", C.c_double)]
+
+
+def _quad_protos():
+    L = lib()
+    if getattr(L, "_quad_ready", False):
+        return L
+    qp, lp = C.POINTER(OrcQuad), C.POINTER(C.c_long)
+    L.orc_quad_cli.argtypes = [qp] + [C.c_int] * 4
+    L.orc_quad_core.argtypes = [qp] + [C.c_int] * 3
+    L.orc_quad_tables.argtypes = [qp, lp, lp, lp]
+    L.orc_quad_lookup.argtypes = [qp, lp, lp, lp, C.c_size_t,
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    L.orc_quad_lookup.restype = None
+    L._quad_ready = True
+    return L
+
+
+def quad_cli(iw=-1, ow=-1, xtra=2, pw=-1):
+    q = OrcQuad()
+    rc = _quad_protos().orc_quad_cli(C.byref(q), iw, ow, xtra, pw)
+    if rc:
+        raise ValueError("orc_quad_cli rc=%d" % rc)
+    return q
+
+
+def quad_core(pw, ow, nxtra):
+    q = OrcQuad()
+    rc = _quad_protos().orc_quad_core(C.byref(q), pw, ow, nxtra)
+    if rc:
+        raise ValueError("orc_quad_core rc=%d" % rc)
+    return q
+
+
+def quad_tables(q):
+    n = 1 << q.lgtbl
+    t = [np.empty(n, dtype=np.int64) for _ in range(3)]
+    lp = C.POINTER(C.c_long)
+    rc = _quad_protos().orc_quad_tables(C.byref(q),
+                                        *[a.ctypes.data_as(lp) for a in t])
+    if rc:
+        raise ValueError("orc_quad_tables rc=%d" % rc)
+    return t
+
+
+def quad_lookup(q, tables, phase):
+    phase = np.ascontiguousarray(phase, dtype=np.uint32)
+    out = np.empty(phase.size, dtype=np.int32)
+    lp = C.POINTER(C.c_long)
+    t = [np.ascontiguousarray(a, dtype=np.int64) for a in tables]
+    _quad_protos().orc_quad_lookup(C.byref(q), *[a.ctypes.data_as(lp) for a in t],
+                                   phase.size, _u32(phase), _i32(out))
+    return out

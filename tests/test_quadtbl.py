@@ -1,0 +1,143 @@
+"""Quadratically interpolated sine core (gencordic -t qtbl).
+
+Pinning: tests/golden/quad_golden.json holds, for ten parameter sets, what the
+REAL reference generator emits (localparams, header constants, the three .hex
+tables) and per-sample outputs obtained by executing the emitted Verilog with
+tests/vsim.py.  CPU tests check the oracle AND the product's host derivation
+against those; GPU tests check the kernel against the oracle, bit for bit, and
+against the pass criterion of bench/cpp/quadtbl_tb.cpp."""
+import json
+import math
+import os
+import re
+import shlex
+
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "quad_golden.json")))
+GOOD = sorted(k for k, v in GOLD.items() if v["elaborates"])
+
+
+def cli_args(args):
+    """-i/-o/-x/-p of a gencordic command line -> (iw, ow, xtra, pw)"""
+    a = shlex.split(args)
+    get = lambda f, d: int(a[a.index(f) + 1]) if f in a else d  # noqa: E731
+    return get("-i", -1), get("-o", -1), get("-x", 2), get("-p", -1)
+
+
+@pytest.mark.parametrize("name", GOOD)
+def test_oracle_matches_generator_and_rtl(name):
+    g = GOLD[name]
+    q = O.quad_cli(*cli_args(g["args"]))
+    lp = g["localparams"]
+    assert (q.pw, q.ow, q.xtra, q.lgtbl, q.qbits, q.lbits, q.cbits) == (
+        lp["PW"], lp["OW"], lp["XTRA"], lp["LGTBL"], lp["QBITS"], lp["LBITS"],
+        lp["CBITS"])
+    t = O.quad_tables(q)
+    for arr, key in zip(t, ("ctbl", "ltbl", "qtbl")):
+        assert arr.tolist() == g[key], key
+    out = O.quad_lookup(q, t, np.array(g["phase"], dtype=np.uint32))
+    assert out.tolist() == g["o_sin"]
+
+
+@pytest.mark.parametrize("name", GOOD)
+def test_host_derivation_matches_generator(name):
+    g = GOLD[name]
+    q = ca.Quad(*cli_args(g["args"]), device=False)
+    lp, hd = g["localparams"], g["header"]
+    assert (q.pw, q.ow, q.xtra, q.lgtbl, q.qbits, q.lbits, q.cbits) == (
+        lp["PW"], lp["OW"], lp["XTRA"], lp["LGTBL"], lp["QBITS"], lp["LBITS"],
+        lp["CBITS"])
+    assert q.dxbits == lp["PW"] - lp["LGTBL"] + 1 and q.ww == lp["OW"] + lp["XTRA"]
+    for arr, key in zip(q.tables(), ("ctbl", "ltbl", "qtbl")):
+        assert arr.tolist() == g[key], key
+    # header text: every constant as the generator printed it (HAS_AUX follows
+    # the -a flag, which the golden runs set and the default config does not)
+    mine = dict(re.findall(r"const\t\w+\t(\w+)\s*= ([^;]+);", q.header("core")))
+    for k, v in hd.items():
+        if k != "HAS_AUX":
+            assert mine[k] == v, k
+    assert q.header("core").startswith("#ifndef\tCORE_H\n#define\tCORE_H\n")
+
+
+def test_emitter_tuple_and_cli_agree():
+    a = ca.Quad(ow=13, xtra=2, pw=18, device=False)
+    b = ca.Quad(core=(18, 13, 3), device=False)           # nxtra = xtra + 1
+    assert bytes(a.c) == bytes(b.c)
+    o = O.quad_core(18, 13, 3)
+    assert (o.lgtbl, o.cbits, o.lbits, o.qbits) == (a.lgtbl, a.cbits, a.lbits,
+                                                    a.qbits)
+
+
+def test_refuses_what_the_reference_cannot_build():
+    bad = GOLD["o12x0p16"]
+    assert not bad["elaborates"]
+    with pytest.raises(ca.CordicError):
+        ca.Quad(*cli_args(bad["args"]), device=False)
+    with pytest.raises(ValueError):
+        O.quad_cli(*cli_args(bad["args"]))
+    for kw in (dict(ow=13, pw=4),        # assert(phase_bits > 4)
+               dict(ow=2, pw=12),        # r_value[WW-3:XTRA] needs OW >= 3
+               dict(ow=30, pw=32),       # tables wider than hextable allows
+               dict(ow=3, xtra=0, pw=12)):   # assert(wid > 6)
+        with pytest.raises(ca.CordicError):
+            ca.Quad(device=False, **kw)
+
+
+def test_oracle_passes_reference_bench_criterion():
+    """bench/cpp/quadtbl_tb.cpp:172-190 on the checked-in core: every phase,
+    |sin*SCL - o_sin| <= |TBL_ERR| + 2."""
+    q = O.quad_cli(ow=13, pw=18)
+    ph = np.arange(1 << 18, dtype=np.uint32)
+    out = O.quad_lookup(q, O.quad_tables(q), ph)
+    want = np.sin(ph * (2 * math.pi / (1 << 18))) * ((1 << 12) - 1)
+    assert np.abs(want - out).max() <= abs(q.tbl_err) + 2.0
+    assert out.max() <= 4095 and out.min() >= -4096
+
+
+# ------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOOD)
+def test_gpu_lookup_matches_oracle_and_rtl_vectors(name):
+    import torch
+    g = GOLD[name]
+    args = cli_args(g["args"])
+    core = ca.Quad(*args)
+    oq = O.quad_cli(*args)
+    ot = O.quad_tables(oq)
+    rng = np.random.RandomState(7)
+    n = (1 << 20) + 3
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    ph[:len(g["phase"])] = np.array(g["phase"], dtype=np.uint32)
+    for off in (0, 1):
+        d = torch.zeros(n + 8, dtype=torch.int32, device="cuda:0")
+        o = torch.zeros(n + 8, dtype=torch.int32, device="cuda:0")
+        d[off:off + n].copy_(torch.from_numpy(ph.view(np.int32)))
+        core.lookup(d[off:off + n], o[off:off + n], n=n)
+        torch.cuda.synchronize()
+        got = o[off:off + n].cpu().numpy()
+        assert got[:len(g["o_sin"])].tolist() == g["o_sin"]
+        assert np.array_equal(got, O.quad_lookup(oq, ot, ph))
+
+
+@pytest.mark.gpu
+def test_gpu_exhaustive_checked_in_core_and_bench_criterion():
+    import torch
+    core = ca.Quad(ow=13, pw=18)
+    n = 1 << 18
+    d = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    o = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    core.lookup(d, o)
+    torch.cuda.synchronize()
+    got = o.cpu().numpy()
+    oq = O.quad_cli(ow=13, pw=18)
+    assert np.array_equal(got, O.quad_lookup(oq, O.quad_tables(oq),
+                                             np.arange(n, dtype=np.uint32)))
+    want = np.sin(np.arange(n) * (2 * math.pi / n)) * ((1 << 12) - 1)
+    assert np.abs(want - got).max() <= abs(core.tbl_err) + 2.0

@@ -102,3 +102,33 @@ def test_gencordic_amd_writes_the_reference_hex_tables(tmp_path):
             subprocess.run([gen] + args.split() + ["-f", str(ref)], check=True,
                            capture_output=True)
             assert text == (tmp_path / "ref.hex").read_text(), args
+
+
+def test_gencordic_amd_writes_the_reference_quadtbl_files(tmp_path):
+    """-t qtbl: the three coefficient .hex files and the constants header
+    carry what the real generator wrote (tests/golden/quad_golden.json)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden",
+                                       "quad_golden.json")))
+    for name in ("rtl_quadtbl", "o16", "o20x4p24"):
+        e = gold[name]
+        vf = tmp_path / "core.v"
+        r = subprocess.run([GEN, "-a", "-c"] + e["args"].split() +
+                           ["-f", str(vf)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for t, bits in (("c", "CBITS"), ("l", "LBITS"), ("q", "QBITS")):
+            b = e["localparams"][bits]
+            toks = (tmp_path / ("core_%stbl.hex" % t)).read_text().split()
+            assert toks[0] == "@00000000" and toks[9] == "@00000008"
+            vals = [int(x, 16) for x in toks if not x.startswith("@")]
+            assert all(len(x) == (b + 3) // 4 for x in toks
+                       if not x.startswith("@"))
+            vals = [v - (1 << b) if v >> (b - 1) else v for v in vals]
+            assert vals == e[t + "tbl"], (name, t)
+        hdr = dict(re.findall(r"const\t\w+\t(\w+)\s*= ([^;]+);",
+                              (tmp_path / "core.h").read_text()))
+        assert hdr == e["header"], name
+    r = subprocess.run([GEN, "-t", "qtbl", "-o", "12", "-x", "0", "-p", "16",
+                        "-f", str(tmp_path / "bad.v")], capture_output=True,
+                       text=True)
+    assert r.returncode != 0 and "ERR" in r.stderr

@@ -15,9 +15,11 @@ rounding vector) shows up as a sample mismatch.
 Subset: one module; localparam header; input/output/wire/reg declarations with
 optional `signed`, a packed range and one unpacked array range; `assign`;
 `initial`; `always @(posedge clk ...)`; `generate for`; begin/end, if/else,
-case; blocking and non-blocking assignments; expressions with + - unary-, !,
-&& ||, == != < <= > >=, >> >>> <<, concatenation, replication, bit and part
-selects, sized literals and $signed().  Values are evaluated as unbounded
+case; blocking and non-blocking assignments; `always @(*)`; continuous
+assignments to part selects of a wire; localparam items; expressions with
++ - * unary-, !, reduction & and |, && ||, == != < <= > >=, >> >>> <<,
+concatenation, replication, bit and part selects, sized literals and
+$signed().  Values are evaluated as unbounded
 integers in the signedness Verilog assigns to the expression and truncated to
 the declared width on assignment; this is exact for every expression the
 generator emits (no intermediate result depends on a carry that a narrower
@@ -82,7 +84,7 @@ class Parser:
         return self.binary(0)
 
     LEVELS = [["||"], ["&&"], ["==", "!="], ["<", "<=", ">", ">="],
-              [">>>", ">>", "<<", "<<<"], ["+", "-"]]
+              [">>>", ">>", "<<", "<<<"], ["+", "-"], ["*"]]
 
     def binary(self, lvl):
         if lvl == len(self.LEVELS):
@@ -94,7 +96,7 @@ class Parser:
         return left
 
     def unary(self):
-        if self.peek() in ("-", "!", "~", "&", "+"):
+        if self.peek() in ("-", "!", "~", "&", "|", "+"):
             op = self.next()
             return Node("un", op, self.unary())
         return self.primary()
@@ -212,6 +214,8 @@ class Module:
         self.params = {}
         self.decl = {}          # name -> (width, signed, array_len or None)
         self.assigns = {}       # wire name -> expr
+        self.assign_parts = {}  # wire name -> [(hi, lo, expr, env)]
+        self.comb = []          # always @(*) blocks
         self.always = []        # (stmt, genvar bindings)
         self.initials = []
         self.state = {}
@@ -232,7 +236,7 @@ class Module:
         if k == "bin":
             op, a, b = node.args
             a, b = self.const(a, env), self.const(b, env)
-            return {"+": a + b, "-": a - b, "<": int(a < b), "<=": int(a <= b),
+            return {"+": a + b, "-": a - b, "*": a * b, "<": int(a < b), "<=": int(a <= b),
                     ">": int(a > b), ">=": int(a >= b), "==": int(a == b),
                     "!=": int(a != b), "<<": a << b if op == "<<" else 0,
                     ">>": a >> b if op == ">>" else 0}[op]
@@ -303,6 +307,15 @@ class Module:
         if v in ("wire", "reg"):
             self._declare(p, (";",))
             p.expect(";")
+        elif v == "localparam":
+            p.next()
+            while True:
+                name = p.next()
+                p.expect("=")
+                self.params[name] = self.const(p.expr(), env)
+                if not p.accept(","):
+                    break
+            p.expect(";")
         elif v == "genvar":
             p.next(); p.next(); p.expect(";")
         elif v == "assign":
@@ -313,6 +326,13 @@ class Module:
             p.expect(";")
             if lhs.kind == "id":
                 self.assigns[lhs.args[0]] = (rhs, dict(env))
+            elif lhs.kind == "part" or (lhs.kind == "idx" and self.decl[
+                    lhs.args[0].args[0]][2] is None):
+                # assign w[hi:lo] = value: the wire is the union of its pieces
+                hi = self.const(lhs.args[1], env)
+                lo = self.const(lhs.args[2], env) if lhs.kind == "part" else hi
+                self.assign_parts.setdefault(lhs.args[0].args[0], []).append(
+                    (hi, lo, rhs, dict(env)))
             else:                               # assign mem[k] = value
                 name = lhs.args[0].args[0]
                 idx = self.const(lhs.args[1], env)
@@ -333,11 +353,12 @@ class Module:
             p.next()
             p.expect("@")
             p.expect("(")
-            depth = 1
+            depth, star = 1, False
             while depth:
                 t = p.next()
+                star = star or t == "*"
                 depth += (t == "(") - (t == ")")
-            self.always.append((p.stmt(), dict(env)))
+            (self.comb if star else self.always).append((p.stmt(), dict(env)))
         elif v == "generate":
             p.next()
             p.expect("for")
@@ -431,7 +452,7 @@ class Module:
         if k == "signed":
             return self.sig(node.args[0], env)[0], True
         if k == "un":
-            if node.args[0] in ("!", "&"):
+            if node.args[0] in ("!", "&", "|"):
                 return 1, False
             return self.sig(node.args[1], env)
         op, a, b = node.args
@@ -471,6 +492,11 @@ class Module:
             if n in self.assigns:
                 rhs, e2 = self.assigns[n]
                 return leaf(self.val(rhs, e2) & ((1 << w) - 1))
+            if n in self.assign_parts:
+                u = 0
+                for hi, lo, rhs, e2 in self.assign_parts[n]:
+                    u |= (self.val(rhs, e2) & ((1 << (hi - lo + 1)) - 1)) << lo
+                return leaf(u)
             return leaf(self.state[n])
         if k == "idx":
             base = node.args[0]
@@ -505,6 +531,8 @@ class Module:
             if op == "&":
                 aw = self.sig(a, env)[0]
                 return int(self.raw(a, env) == (1 << aw) - 1)
+            if op == "|":
+                return int(self.raw(a, env) != 0)
             if op == "-":
                 return -self.val(a, env, signed)
             if op == "~":
@@ -531,6 +559,8 @@ class Module:
                 return (x & ((1 << max(w, 64)) - 1)) >> sh if x < 0 else x >> sh
             return x << sh
         x, y = self.val(a, env, signed), self.val(b, env, signed)
+        if op == "*":
+            return x * y
         return x + y if op == "+" else x - y
 
     def exec(self, st, env, ups, blocking=False):
@@ -599,15 +629,29 @@ class Module:
         for n, v in inputs.items():
             w = self.decl[n][0]
             self.state[n] = v & ((1 << w) - 1)
+        self.settle()
         ups = []
         for st, env in self.always:
             self.exec(st, env, ups)
         for name, idx, v in ups:
             self._store(name, idx, v)
+        self.settle()
+
+    def settle(self):
+        """always @(*) blocks, in source order (the generator never emits one
+        that depends on a later one)."""
+        for st, env in self.comb:
+            self.exec(st, env, [], blocking=True)
+
+    def get(self, name):
+        """current raw value of a reg, or of a wire driven by `assign`."""
+        if name in self.assigns or name in self.assign_parts:
+            return self.raw(Node("id", name), {})
+        return self.state[name]
 
     def out(self, name):
         w, s, _ = self.decl[name]
-        v = self.state[name]
+        v = self.get(name)
         if s and (v >> (w - 1)) & 1:
             v -= 1 << w
         return v
@@ -635,7 +679,7 @@ def run_pipelined(m, samples):
     for k in range(len(samples) + 200):
         s = samples[k] if k < len(samples) else zero
         m.tick(i_ce=1, i_aux=1 if k < len(samples) else 0, **ctl, **s)
-        if m.state["o_aux"]:
+        if m.get("o_aux"):
             res.append({n: m.out(n) for n in outs})
         if len(res) == len(samples):
             break

@@ -25,7 +25,8 @@ static void usage()
 {
 	fprintf(stderr,
 "USAGE: gencordic_amd [-aAchrRv] [-f <fname>] [-i <iw>] [-o <ow>]\n"
-"\t[-n <stages>] [-p <phasebits>] [-t p2r|r2p|sp2r|sr2p] [-x <xtrabits>]\n"
+"\t[-n <stages>] [-p <phasebits>] [-t p2r|r2p|sp2r|sr2p|tbl|qtr|qtbl]\n"
+"\t[-x <xtrabits>]\n"
 "\t[--run <log2 samples>]\n"
 "\n"
 "\tSame meaning as the flags of ZipCPU/cordic's gencordic.  -c writes the\n"
@@ -146,6 +147,117 @@ int main(int argc, char **argv)
 				printf("streamed 10 x 2^%d samples: %.1f Msamples/s\n",
 					run_lg, (double)n * 10 / dt / 1e6);
 				cordic_table_destroy(tb);
+				(void)hipFree(ph); (void)hipFree(o);
+			}
+			return EXIT_SUCCESS;
+		}
+	}
+
+	// -t qtbl: the quadratically interpolated sine core.  Writes the three
+	// coefficient tables the reference writes (<fname>_ctbl.hex, _ltbl.hex,
+	// _qtbl.hex; sw/quadtbl.cpp:243-259) and, with -c, its constants header.
+	{
+		bool quad = false, hdr = false, aux = false, noreset = false;
+		int iw = -1, ow = -1, pw = -1, xtra = 2;
+		std::string f;
+		for (size_t k = 1; k < args.size(); k++) {
+			const char *a = args[k];
+			const char *v = (k + 1 < args.size()) ? args[k + 1] : nullptr;
+			if (a[0] != '-')
+				continue;
+			if (!strcmp(a, "-t") && v) quad = !strcmp(v, "qtbl");
+			else if (!strcmp(a, "-i") && v) iw = atoi(v);
+			else if (!strcmp(a, "-o") && v) ow = atoi(v);
+			else if (!strcmp(a, "-p") && v) pw = atoi(v);
+			else if (!strcmp(a, "-x") && v) xtra = atoi(v);
+			else if (!strcmp(a, "-f") && v) f = v;
+			else if (!strpbrk(a, "finoptx")) {	// bundle of plain flags
+				if (strchr(a, 'c')) hdr = true;
+				if (strchr(a, 'a')) aux = true;
+				if (strchr(a, 'R')) noreset = true;
+			}
+		}
+		if (quad) {
+			cordic_quad_config qc;
+			const int qrc = cordic_quad_config_init(&qc, iw, ow, xtra, pw);
+			if (qrc != CORDIC_OK) {
+				fprintf(stderr, "ERR: %s\n", cordic_strerror(qrc));
+				return EXIT_FAILURE;
+			}
+			qc.has_aux = aux;
+			qc.has_reset = !noreset;
+			if (f.empty())
+				f = "quadtbl.v";
+			std::string stem = f;
+			const size_t dot = stem.rfind('.');
+			if (dot != std::string::npos)
+				stem = stem.substr(0, dot);
+			if (verbose)
+				printf("Generated a quadratic-interpolation sine core: PW %d, "
+					"OW %d, XTRA %d, %d-entry tables, CBITS:LBITS:QBITS = "
+					"%d:%d:%d, table error %.6f\n", qc.pw, qc.ow, qc.xtra,
+					qc.entries, qc.cbits, qc.lbits, qc.qbits, qc.itbl_err);
+			std::vector<int32_t> tc(qc.entries), tl(qc.entries), tq(qc.entries);
+			cordic_quad_tables(&qc, tc.data(), tl.data(), tq.data(), tc.size());
+			const struct { const char *sfx; const std::vector<int32_t> *v; int bits; }
+				files[3] = { { "_ctbl", &tc, qc.cbits }, { "_ltbl", &tl, qc.lbits },
+					     { "_qtbl", &tq, qc.qbits } };
+			for (const auto &t : files) {
+				const std::string hn = stem + t.sfx + ".hex";
+				FILE *hf = fopen(hn.c_str(), "w");
+				if (!hf) {
+					fprintf(stderr, "ERR: Cannot open %s for writing\n", hn.c_str());
+					return EXIT_FAILURE;
+				}
+				const int nc = (t.bits + 3) / 4;
+				const long msk = (1l << t.bits) - 1l;
+				for (int k = 0; k < qc.entries; k++) {
+					if (0 == (k % 8))
+						fprintf(hf, "%s@%08x ", (k != 0) ? "\n" : "", k);
+					fprintf(hf, "%0*lx ", nc, (long)(*t.v)[k] & msk);
+				}
+				fprintf(hf, "\n");
+				fclose(hf);
+			}
+			if (hdr) {
+				std::string base = stem;
+				const size_t sl = base.rfind('/');
+				if (sl != std::string::npos)
+					base = base.substr(sl + 1);
+				char text[2048];
+				cordic_quad_write_header(&qc, base.c_str(), text, sizeof text);
+				const std::string hn = stem + ".h";
+				FILE *hf = fopen(hn.c_str(), "w");
+				if (!hf) {
+					fprintf(stderr, "WARNING: Could not open %s\n", hn.c_str());
+				} else {
+					fputs(text, hf);
+					fclose(hf);
+				}
+			}
+			if (run_lg >= 0) {
+				if (run_lg > 31) run_lg = 31;
+				const size_t n = (size_t)1 << run_lg;
+				uint32_t *ph; int32_t *o;
+				cordic_quad *core = nullptr;
+				if (hipMalloc((void **)&ph, n * 4) != hipSuccess ||
+				    hipMalloc((void **)&o, n * 4) != hipSuccess ||
+				    cordic_quad_create(&qc, &core) != CORDIC_OK) {
+					fprintf(stderr, "ERR: %s\n", cordic_strerror(CORDIC_ERR_DEVICE));
+					return EXIT_FAILURE;
+				}
+				cordic_fill_phase_ramp(ph, n, 0, 0, nullptr);
+				cordic_quad_lookup(core, n, ph, o, nullptr);
+				(void)hipDeviceSynchronize();
+				const auto t0 = std::chrono::steady_clock::now();
+				for (int k = 0; k < 10; k++)
+					cordic_quad_lookup(core, n, ph, o, nullptr);
+				(void)hipDeviceSynchronize();
+				const double dt = std::chrono::duration<double>(
+						std::chrono::steady_clock::now() - t0).count();
+				printf("streamed 10 x 2^%d samples: %.1f Msamples/s\n",
+					run_lg, (double)n * 10 / dt / 1e6);
+				cordic_quad_destroy(core);
 				(void)hipFree(ph); (void)hipFree(o);
 			}
 			return EXIT_SUCCESS;
