@@ -107,6 +107,14 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_stream_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
+    "cordic_stream_destroy": (None, [C.c_void_p]),
+    "cordic_stream_workspace": (C.c_size_t, [C.c_size_t]),
+    "cordic_stream_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "cordic_stream_latency": (C.c_int, [C.c_void_p]),
+    "cordic_stream_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_stream_ticks": (C.c_int, [C.c_void_p, C.c_size_t] +
+                            [C.c_void_p] * 10),
     "cordic_quad_config_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_int]),
     "cordic_quad_config_init_core": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
@@ -402,6 +410,50 @@ class Quad:
     def close(self):
         if self._h:
             lib().cordic_quad_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    """cordic_stream: a pipelined core (p2r / r2p) stepped in blocks of clocks
+    with per-clock i_ce / i_reset / i_aux, pipeline state carried between
+    calls (include/cordic_amd.h, "clocked view")."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(lib().cordic_stream_create(cfg.ref, C.byref(h)),
+               "cordic_stream_create")
+        self._h = h
+
+    @property
+    def latency(self):
+        return lib().cordic_stream_latency(self._h)
+
+    def reserve(self, ticks):
+        _check(lib().cordic_stream_reserve(self._h, ticks),
+               "cordic_stream_reserve")
+
+    def reset(self, stream=None):
+        _check(lib().cordic_stream_reset(self._h, _stream(stream)),
+               "cordic_stream_reset")
+
+    def ticks(self, x, y, phase, out0, out1, oaux=None, ce=None, reset=None,
+              aux=None, n=None, stream=None):
+        n = x.numel() if n is None else n
+        _check(lib().cordic_stream_ticks(
+            self._h, n, _ptr(ce), _ptr(reset), _ptr(aux), _ptr(x), _ptr(y),
+            _ptr(phase), _ptr(out0), _ptr(out1), _ptr(oaux), _stream(stream)),
+            "cordic_stream_ticks")
+
+    def close(self):
+        if self._h:
+            lib().cordic_stream_destroy(self._h)
             self._h = None
 
     def __del__(self):

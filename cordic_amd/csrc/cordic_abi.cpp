@@ -357,6 +357,126 @@ int cordic_quad_lookup(const cordic_quad *core, size_t n, const uint32_t *d_phas
 	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream);
 }
 
+// ------------------------------------------------- clocked view (stream)
+struct cordic_stream {
+	cordic_config cfg;
+	StreamState st;
+	int latency = 0;
+};
+
+void cordic_stream_destroy(cordic_stream *s)
+{
+	if (!s)
+		return;
+	StreamState &t = s->st;
+	for (int k = 0; k < 2; k++) {
+		if (t.hx[k]) (void)hipFree(t.hx[k]);
+		if (t.hy[k]) (void)hipFree(t.hy[k]);
+		if (t.hph[k]) (void)hipFree(t.hph[k]);
+		if (t.haux[k]) (void)hipFree(t.haux[k]);
+		if (t.epoch[k]) (void)hipFree(t.epoch[k]);
+	}
+	if (t.born_phase) (void)hipFree(t.born_phase);
+	if (t.ws) (void)hipFree(t.ws);
+	delete s;
+}
+
+int cordic_stream_create(const cordic_config *cfg, cordic_stream **out)
+{
+	if (!cfg || !out)
+		return CORDIC_ERR_ARGS;
+	if (cfg->mode != CORDIC_P2R && cfg->mode != CORDIC_R2P)
+		return CORDIC_ERR_MODE;
+	cordic_stream *s = new (std::nothrow) cordic_stream;
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	s->cfg = *cfg;
+	const int L = cfg->nstages + 2;
+	s->latency = L;
+	StreamState &t = s->st;
+	bool ok = true;
+	for (int k = 0; k < 2 && ok; k++) {
+		ok = hipMalloc((void **)&t.hx[k], L * 4) == hipSuccess
+			&& hipMalloc((void **)&t.hy[k], L * 4) == hipSuccess
+			&& hipMalloc((void **)&t.hph[k], L * 4) == hipSuccess
+			&& hipMalloc((void **)&t.haux[k], L) == hipSuccess
+			&& hipMalloc((void **)&t.epoch[k], 4) == hipSuccess
+			&& hipMemset(t.hx[k], 0, L * 4) == hipSuccess
+			&& hipMemset(t.hy[k], 0, L * 4) == hipSuccess
+			&& hipMemset(t.hph[k], 0, L * 4) == hipSuccess
+			&& hipMemset(t.haux[k], 0, L) == hipSuccess
+			&& hipMemset(t.epoch[k], 0, 4) == hipSuccess;
+	}
+	// rtl/topolar.v:235-243 on cleared registers: the phase accumulator of a
+	// stage born at reset still collects angle[i] of every live stage it
+	// passes; after e enabled clocks the output register shows the one born
+	// in register NSTAGES-e+1 (cordic_stream.hip).  Skipped stages
+	// (rtl/topolar.v:217-225) add nothing.
+	std::vector<uint32_t> born((size_t)L + 1, 0u);
+	const uint32_t pmask = (cfg->pw >= 32) ? 0xffffffffu : ((1u << cfg->pw) - 1u);
+	for (int e = 1; e <= L - 1; e++) {
+		uint32_t acc = 0;
+		for (int i = cfg->nstages - e + 1; i < cfg->nstages; i++)
+			if (i >= 0 && i < cfg->nlive)
+				acc += cfg->angle[i];
+		born[(size_t)e] = acc & pmask;
+	}
+	ok = ok && hipMalloc((void **)&t.born_phase, born.size() * 4) == hipSuccess
+		&& hipMemcpy(t.born_phase, born.data(), born.size() * 4,
+				hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		cordic_stream_destroy(s);
+		return CORDIC_ERR_DEVICE;
+	}
+	*out = s;
+	return CORDIC_OK;
+}
+
+size_t cordic_stream_workspace(size_t ticks) { return stream_workspace_bytes(ticks); }
+
+int cordic_stream_reserve(cordic_stream *s, size_t max_ticks)
+{
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	const size_t need = stream_workspace_bytes(max_ticks);
+	if (need <= s->st.ws_bytes)
+		return CORDIC_OK;
+	// kernels of earlier calls may still be using the old scratch
+	if (hipDeviceSynchronize() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	if (s->st.ws) (void)hipFree(s->st.ws);
+	s->st.ws = nullptr;
+	s->st.ws_bytes = 0;
+	if (hipMalloc(&s->st.ws, need) != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	s->st.ws_bytes = need;
+	return CORDIC_OK;
+}
+
+int cordic_stream_latency(const cordic_stream *s) { return s ? s->latency : CORDIC_ERR_ARGS; }
+
+int cordic_stream_reset(cordic_stream *s, void *stream)
+{
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	return (hipMemsetAsync(s->st.epoch[s->st.cur], 0, 4,
+			static_cast<hipStream_t>(stream)) == hipSuccess)
+		? CORDIC_OK : CORDIC_ERR_DEVICE;
+}
+
+int cordic_stream_ticks(cordic_stream *s, size_t ticks, const uint8_t *d_ce,
+		const uint8_t *d_reset, const uint8_t *d_aux, const int32_t *d_xval,
+		const int32_t *d_yval, const uint32_t *d_phase, int32_t *d_out0,
+		int32_t *d_out1, uint8_t *d_oaux, void *stream)
+{
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	if (int rc = cordic_stream_reserve(s, ticks))
+		return rc;
+	return launch_stream_ticks(s->cfg, s->st, ticks, d_ce, d_reset, d_aux,
+			d_xval, d_yval, d_phase, d_out0, d_out1, d_oaux, stream);
+}
+
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
 {
 	if (!cfg)

@@ -88,6 +88,24 @@ int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 		uint32_t mulx, uint32_t muly, int bits, void *stream);
 int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream);
+// ---- clocked view of the pipelined cores: cordic_stream.hip
+struct StreamState {
+	void	*ws = nullptr;		// scan / gather workspace
+	size_t	ws_bytes = 0;
+	// the L = NSTAGES+2 samples inside the pipeline (double buffered) and
+	// the number of advancing clocks since the last reset, all on the device
+	int32_t	 *hx[2] = {nullptr, nullptr}, *hy[2] = {nullptr, nullptr};
+	uint32_t *hph[2] = {nullptr, nullptr};
+	uint8_t	 *haux[2] = {nullptr, nullptr};
+	uint32_t *epoch[2] = {nullptr, nullptr};
+	uint32_t *born_phase = nullptr;	// topolar: o_phase of a cleared stage
+	int	cur = 0;
+};
+size_t	stream_workspace_bytes(size_t ticks);
+int	launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
+		const uint8_t *ce, const uint8_t *reset, const uint8_t *aux,
+		const int32_t *x, const int32_t *y, const uint32_t *phase,
+		int32_t *o0, int32_t *o1, uint8_t *oaux, void *stream);
 int	launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream);
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,

@@ -1,0 +1,429 @@
+// cordic_stream.hip -- clock-accurate view of the PIPELINED cores
+// (rtl/cordic.v, rtl/topolar.v) for benches that drive i_ce / i_reset / i_aux
+// per clock (bench/cpp/testb.h:87-106 tick(); bench/cpp/cordic_tb.cpp:136-176).
+//
+// A Verilated model is stepped one tick() at a time.  On a GPU the unit of
+// work is a BLOCK OF CLOCKS: the caller hands over the port activity of T
+// consecutive clocks as arrays and receives the output ports as they stand
+// after each of those clocks; the pipeline contents are carried from call to
+// call inside the cordic_stream object.
+//
+// Why this is exact.  Every register of the pipelined cores is either cleared
+// (i_reset, which wins over i_ce: rtl/cordic.v:118-124,244-252,304-309),
+// held (i_ce low) or loaded from the previous stage (i_ce high).  So after
+// any clock the output register holds f(sample that entered L-1 advancing
+// clocks before the most recent advancing clock), L = NSTAGES+2 registers
+// (pre-rotation, NSTAGES stages, output; the aux shift register
+// rtl/cordic.v:100-105,313 has the same length), where an ADVANCING clock is
+// one with i_ce && !i_reset.  With e = number of advancing clocks since the
+// last reset:
+//    e == 0          outputs hold their reset value (0)
+//    1 <= e <= L-1   the output register holds what the cleared registers turn
+//                    into on their way out: x = y = 0 stays 0 through every
+//                    stage and through the rounding, so o_xval/o_yval/o_mag
+//                    = 0 and o_aux = 0, while topolar's phase accumulator
+//                    still adds angle[i] at every stage it passes (y >= 0
+//                    branch, rtl/topolar.v:235-243):
+//                    o_phase = sum of angle[i], i = NSTAGES-e+1 .. NSTAGES-1
+//    e >= L          f(input of the advancing clock with ordinal e-L+1)
+// The clock -> source-sample map is two prefix scans (count of advancing
+// clocks, index of the last reset) plus a compaction; f() itself is the batch
+// kernel of the core, run on the gathered samples.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cordic_device.h"
+#include "cordic_internal.h"
+
+namespace cordic_amd {
+namespace {
+using namespace dev;
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;	// clocks per block
+
+struct TickFlags {
+	const uint8_t *ce;	// NULL: i_ce = 1 on every clock
+	const uint8_t *reset;	// NULL: never reset
+	__device__ __forceinline__ bool is_reset(uint32_t t) const
+	{
+		return reset && reset[t] != 0;
+	}
+	__device__ __forceinline__ bool advances(uint32_t t) const
+	{
+		return (!ce || ce[t] != 0) && !is_reset(t);
+	}
+};
+
+// block-wide inclusive scan of one value per thread (sum) and of the running
+// maximum of another, over kScanThreads threads
+__device__ __forceinline__ void block_scan(uint32_t &sum, int32_t &mx,
+		uint32_t *lds_sum, int32_t *lds_max)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t s = __shfl_up(sum, off, 64);
+		const int32_t m = __shfl_up(mx, off, 64);
+		if (lane >= off) {
+			sum += s;
+			mx = (m > mx) ? m : mx;
+		}
+	}
+	if (lane == 63) {
+		lds_sum[wave] = sum;
+		lds_max[wave] = mx;
+	}
+	__syncthreads();
+	for (int w = 0; w < wave; w++) {
+		sum += lds_sum[w];
+		mx = (lds_max[w] > mx) ? lds_max[w] : mx;
+	}
+	__syncthreads();
+}
+
+// pass 1: per tile, the number of advancing clocks and the last reset clock
+__global__ __launch_bounds__(kScanThreads) void stream_tile_totals(TickFlags f,
+		uint32_t T, uint32_t *tile_adv, int32_t *tile_last)
+{
+	__shared__ uint32_t lds_sum[kScanThreads / 64];
+	__shared__ int32_t lds_max[kScanThreads / 64];
+	const uint32_t t0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+	uint32_t sum = 0;
+	int32_t last = -1;
+#pragma unroll
+	for (int j = 0; j < kScanItems; j++) {
+		const uint32_t t = t0 + j;
+		if (t < T) {
+			if (f.is_reset(t)) last = (int32_t)t;
+			sum += f.advances(t) ? 1u : 0u;
+		}
+	}
+	block_scan(sum, last, lds_sum, lds_max);
+	if (threadIdx.x == kScanThreads - 1) {
+		tile_adv[blockIdx.x] = sum;
+		tile_last[blockIdx.x] = last;
+	}
+}
+
+// pass 2 (one block): exclusive scan of the tile totals, in place
+__global__ __launch_bounds__(kScanThreads) void stream_tile_spine(
+		uint32_t *tile_adv, int32_t *tile_last, uint32_t ntiles)
+{
+	__shared__ uint32_t lds_sum[kScanThreads / 64];
+	__shared__ int32_t lds_max[kScanThreads / 64];
+	__shared__ uint32_t carry_sum;
+	__shared__ int32_t carry_max;
+	if (threadIdx.x == 0) {
+		carry_sum = 0;
+		carry_max = -1;
+	}
+	__syncthreads();
+	for (uint32_t base = 0; base < ntiles; base += kScanThreads) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t own_s = (i < ntiles) ? tile_adv[i] : 0u;
+		const int32_t own_m = (i < ntiles) ? tile_last[i] : -1;
+		uint32_t s = own_s;
+		int32_t m = own_m;
+		block_scan(s, m, lds_sum, lds_max);
+		const uint32_t cs = carry_sum;
+		const int32_t cm = carry_max;
+		const int32_t prev = __shfl_up(m, 1, 64);
+		__syncthreads();
+		if (i < ntiles) {
+			// exclusive: everything before tile i
+			tile_adv[i] = cs + s - own_s;
+			int32_t before = cm;
+			if ((threadIdx.x & 63) != 0)
+				before = (prev > before) ? prev : before;
+			else
+				for (int w = 0; w < (int)(threadIdx.x >> 6); w++)
+					before = (lds_max[w] > before) ? lds_max[w] : before;
+			tile_last[i] = before;
+		}
+		if (threadIdx.x == kScanThreads - 1) {
+			carry_sum = cs + s;
+			carry_max = (m > cm) ? m : cm;
+		}
+		__syncthreads();
+	}
+}
+
+// pass 3: A[t] = advancing clocks in [0, t], R[t] = last reset clock <= t
+// (-1: none), pos[k] = the clock of the advancing clock with ordinal k (0-based)
+__global__ __launch_bounds__(kScanThreads) void stream_tile_apply(TickFlags f,
+		uint32_t T, const uint32_t *tile_adv, const int32_t *tile_last,
+		uint32_t *A, int32_t *R, uint32_t *pos)
+{
+	__shared__ uint32_t lds_sum[kScanThreads / 64];
+	__shared__ int32_t lds_max[kScanThreads / 64];
+	const uint32_t t0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+	uint32_t cnt[kScanItems];
+	int32_t lst[kScanItems];
+	uint32_t sum = 0;
+	int32_t last = -1;
+#pragma unroll
+	for (int j = 0; j < kScanItems; j++) {
+		const uint32_t t = t0 + j;
+		if (t < T) {
+			if (f.is_reset(t)) last = (int32_t)t;
+			sum += f.advances(t) ? 1u : 0u;
+		}
+		cnt[j] = sum;
+		lst[j] = last;
+	}
+	uint32_t inc_s = sum;
+	int32_t inc_m = last;
+	block_scan(inc_s, inc_m, lds_sum, lds_max);
+	const uint32_t before_s = tile_adv[blockIdx.x] + inc_s - sum;
+	// running maximum over the threads before this one
+	int32_t before_m = __shfl_up(inc_m, 1, 64);
+	if ((threadIdx.x & 63) == 0) {
+		before_m = -1;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); w++)
+			before_m = (lds_max[w] > before_m) ? lds_max[w] : before_m;
+	}
+	const int32_t tl = tile_last[blockIdx.x];
+	before_m = (tl > before_m) ? tl : before_m;
+#pragma unroll
+	for (int j = 0; j < kScanItems; j++) {
+		const uint32_t t = t0 + j;
+		if (t < T) {
+			const uint32_t a = before_s + cnt[j];
+			A[t] = a;
+			R[t] = (lst[j] > before_m) ? lst[j] : before_m;
+			if (f.advances(t))
+				pos[a - 1] = t;
+		}
+	}
+}
+
+struct StreamView {
+	const int32_t *x, *y;		// block inputs (ports, one value per clock)
+	const uint32_t *phase;		// NULL for topolar
+	const uint8_t *aux;		// NULL: i_aux = 0
+	const int32_t *hx, *hy;		// history: the L samples in the pipeline
+					// when the block starts (oldest first)
+	const uint32_t *hph;
+	const uint8_t *haux;
+	const uint32_t *epoch;		// advancing clocks since the last reset
+					// before this block (saturated)
+	const uint32_t *A;		// NULL: every clock advances
+	const int32_t *R;
+	const uint32_t *pos;
+	uint32_t T;
+	int32_t L;			// NSTAGES + 2
+};
+
+constexpr uint32_t kEpochSat = 1u << 30;
+
+// e and, where e >= L, where the sample now in the output register came from
+__device__ __forceinline__ uint32_t resolve(const StreamView &v, uint32_t t,
+		bool &from_hist, uint32_t &src)
+{
+	const uint32_t a = v.A ? v.A[t] : t + 1;
+	const int32_t r = v.R ? v.R[t] : -1;
+	uint32_t e;
+	if (r >= 0) {
+		e = a - v.A[r];
+	} else {
+		const uint32_t e0 = *v.epoch;
+		e = (e0 >= kEpochSat || a >= kEpochSat) ? kEpochSat : e0 + a;
+	}
+	from_hist = false;
+	src = 0;
+	if (e >= (uint32_t)v.L) {
+		const int64_t k = (int64_t)a - (v.L - 1);	// ordinal, 1-based
+		if (k >= 1) {
+			src = v.pos ? v.pos[k - 1] : (uint32_t)(k - 1);
+		} else {			// k in -(L-1) .. 0
+			from_hist = true;
+			src = (uint32_t)(v.L + k - 1);
+		}
+	}
+	return e;
+}
+
+// gather the sample behind every clock's output; born[t] = 0 for a real
+// sample, e (1..L-1) for a cleared register on its way out, 255 for e == 0
+__global__ __launch_bounds__(kBlock) void stream_gather(StreamView v,
+		int32_t *gx, int32_t *gy, uint32_t *gph, uint8_t *born,
+		uint8_t *oaux)
+{
+	const uint32_t stride = gridDim.x * kBlock;
+	for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < v.T; t += stride) {
+		bool hist;
+		uint32_t src;
+		const uint32_t e = resolve(v, t, hist, src);
+		int32_t x = 0, y = 0;
+		uint32_t ph = 0;
+		uint8_t ax = 0, b = 0;
+		if (e >= (uint32_t)v.L) {
+			if (hist) {
+				x = v.hx[src]; y = v.hy[src];
+				ph = v.hph ? v.hph[src] : 0u;
+				ax = v.haux[src];
+			} else {
+				x = v.x[src]; y = v.y[src];
+				ph = v.phase ? v.phase[src] : 0u;
+				ax = v.aux ? (uint8_t)(v.aux[src] != 0) : (uint8_t)0;
+			}
+		} else {
+			b = (e == 0) ? (uint8_t)255 : (uint8_t)e;
+		}
+		gx[t] = x;
+		gy[t] = y;
+		if (gph) gph[t] = ph;
+		born[t] = b;
+		if (oaux) oaux[t] = ax;
+	}
+}
+
+// topolar: o_phase of the clocks whose output register holds a cleared stage
+__global__ __launch_bounds__(kBlock) void stream_fix_phase(uint32_t T,
+		const uint8_t *born, const uint32_t *born_phase, uint32_t *ophase)
+{
+	const uint32_t stride = gridDim.x * kBlock;
+	for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < T; t += stride) {
+		const uint8_t b = born[t];
+		if (b)
+			ophase[t] = (b == 255) ? 0u : born_phase[b];
+	}
+}
+
+// new history = the last L advancing samples of (old history ++ this block)
+__global__ void stream_carry(StreamView v, int32_t *nx, int32_t *ny,
+		uint32_t *nph, uint8_t *naux, uint32_t *nepoch)
+{
+	const int H = v.L;
+	const uint32_t adv = v.A ? v.A[v.T - 1] : v.T;	// advancing clocks here
+	for (int j = threadIdx.x; j < H; j += blockDim.x) {
+		// ordinal (1-based, this block) of history slot j
+		const int64_t k = (int64_t)adv - H + 1 + j;
+		if (k >= 1) {
+			const uint32_t s = v.pos ? v.pos[k - 1] : (uint32_t)(k - 1);
+			nx[j] = v.x[s]; ny[j] = v.y[s];
+			nph[j] = v.phase ? v.phase[s] : 0u;
+			naux[j] = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
+		} else {
+			const int64_t o = H + k - 1;	// slot of the old history
+			if (o >= 0) {
+				nx[j] = v.hx[o]; ny[j] = v.hy[o];
+				nph[j] = v.hph[o]; naux[j] = v.haux[o];
+			} else {
+				nx[j] = 0; ny[j] = 0; nph[j] = 0; naux[j] = 0;
+			}
+		}
+	}
+	if (threadIdx.x == 0) {
+		const int32_t r = v.R ? v.R[v.T - 1] : -1;
+		uint32_t e;
+		if (r >= 0) {
+			e = adv - v.A[r];
+		} else {
+			const uint32_t e0 = *v.epoch;
+			e = (e0 >= kEpochSat || adv >= kEpochSat) ? kEpochSat : e0 + adv;
+		}
+		*nepoch = (e > kEpochSat) ? kEpochSat : e;
+	}
+}
+
+int grid_1d(size_t n)
+{
+	const size_t b = (n + kBlock - 1) / kBlock;
+	return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+} // namespace
+
+size_t stream_workspace_bytes(size_t T)
+{
+	const size_t ntiles = (T + kScanTile - 1) / kScanTile;
+	// A, R, pos, gx, gy, gph (4 bytes each), born (1), two tile arrays
+	return T * 25 + ntiles * 8 + 256;
+}
+
+int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
+		const uint8_t *ce, const uint8_t *reset, const uint8_t *aux,
+		const int32_t *x, const int32_t *y, const uint32_t *phase,
+		int32_t *o0, int32_t *o1, uint8_t *oaux, void *stream)
+{
+	(void)hipGetLastError();
+	if (T == 0)
+		return CORDIC_OK;
+	if (T >= (1ull << 31))
+		return CORDIC_ERR_ARGS;
+	const bool rot = (cfg.mode == CORDIC_P2R);
+	if (!rot && cfg.mode != CORDIC_R2P)
+		return CORDIC_ERR_MODE;
+	if (!x || !y || !o0 || !o1 || (rot && !phase))
+		return CORDIC_ERR_ARGS;
+	if (stream_workspace_bytes(T) > s.ws_bytes)
+		return CORDIC_ERR_ARGS;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const uint32_t n = (uint32_t)T;
+
+	// carve the workspace (every array 16-byte aligned)
+	char *w = static_cast<char *>(s.ws);
+	auto take = [&](size_t bytes) {
+		char *p = w;
+		w += (bytes + 15) & ~(size_t)15;
+		return p;
+	};
+	const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
+	int32_t *gx = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+	int32_t *gy = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+	uint32_t *gph = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+	uint8_t *born = reinterpret_cast<uint8_t *>(take(n));
+	uint32_t *A = nullptr, *pos = nullptr;
+	int32_t *R = nullptr;
+
+	if (ce || reset) {
+		A = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+		R = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+		pos = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+		uint32_t *tile_adv = reinterpret_cast<uint32_t *>(take((size_t)ntiles * 4));
+		int32_t *tile_last = reinterpret_cast<int32_t *>(take((size_t)ntiles * 4));
+		TickFlags f{ce, reset};
+		hipLaunchKernelGGL(stream_tile_totals, dim3(ntiles), dim3(kScanThreads),
+				0, st, f, n, tile_adv, tile_last);
+		hipLaunchKernelGGL(stream_tile_spine, dim3(1), dim3(kScanThreads), 0,
+				st, tile_adv, tile_last, ntiles);
+		hipLaunchKernelGGL(stream_tile_apply, dim3(ntiles), dim3(kScanThreads),
+				0, st, f, n, tile_adv, tile_last, A, R, pos);
+	}
+
+	const int cur = s.cur, nxt = cur ^ 1;
+	StreamView v{x, y, rot ? phase : nullptr, aux, s.hx[cur], s.hy[cur],
+			s.hph[cur], s.haux[cur], s.epoch[cur], A, R, pos, n,
+			cfg.nstages + 2};
+	hipLaunchKernelGGL(stream_gather, dim3(grid_1d(n)), dim3(kBlock), 0, st, v,
+			gx, gy, rot ? gph : nullptr, born, oaux);
+	if (hipGetLastError() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+
+	int rc;
+	if (rot) {
+		RotatorJob j;
+		j.x = gx; j.y = gy; j.phase = gph;
+		j.ox = o0; j.oy = o1; j.n = n;
+		rc = launch_rotator(cfg, Feed::PhaseArray_XYArray, j, stream);
+	} else {
+		rc = launch_topolar(cfg, n, gx, gy, o0, reinterpret_cast<uint32_t *>(o1),
+				stream);
+		if (rc == CORDIC_OK)
+			hipLaunchKernelGGL(stream_fix_phase, dim3(grid_1d(n)),
+					dim3(kBlock), 0, st, n, born, s.born_phase,
+					reinterpret_cast<uint32_t *>(o1));
+	}
+	if (rc != CORDIC_OK)
+		return rc;
+	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(64), 0, st, v, s.hx[nxt],
+			s.hy[nxt], s.hph[nxt], s.haux[nxt], s.epoch[nxt]);
+	s.cur = nxt;
+	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
+}
+
+} // namespace cordic_amd

@@ -348,6 +348,45 @@ void	cordic_quad_destroy(cordic_quad *core);
 int	cordic_quad_lookup(const cordic_quad *core, size_t n,
 		const uint32_t *d_phase, int32_t *d_sin, void *stream);
 
+/* ------------------------------------------- clocked view (streaming shim)
+ *
+ * For benches that step the Verilated PIPELINED cores clock by clock with
+ * i_ce / i_reset / i_aux (bench/cpp/testb.h:87-106, cordic_tb.cpp:136-176):
+ * a cordic_stream is the core with its pipeline contents; cordic_stream_ticks
+ * applies T consecutive clocks, given as arrays with one entry per clock, and
+ * returns what the output ports show after each of them -- the latency of
+ * NSTAGES+2 enabled clocks, the hold on i_ce = 0, the clearing on i_reset
+ * and the i_aux -> o_aux delay line (rtl/cordic.v:100-105,118-124,244-252,
+ * 304-313; rtl/topolar.v likewise) are reproduced exactly.  State carries
+ * over from call to call.  Modes: CORDIC_P2R, CORDIC_R2P (the sequential
+ * cores have no i_ce pipeline: use the batch calls, which return their o_done
+ * values).
+ *
+ *   d_ce, d_reset, d_aux : one byte per clock (non-zero = asserted); NULL
+ *                          means i_ce = 1 / i_reset = 0 / i_aux = 0 throughout.
+ *                          d_reset is i_reset, or !i_areset_n for -A cores.
+ *   p2r: d_xval, d_yval, d_phase -> d_out0 = o_xval, d_out1 = o_yval
+ *   r2p: d_xval, d_yval (d_phase NULL) -> d_out0 = o_mag, d_out1 = o_phase
+ *   d_oaux : o_aux per clock (may be NULL)
+ * A freshly created stream is in the reset state.  The call needs
+ * cordic_stream_workspace(T) bytes of device scratch; cordic_stream_reserve
+ * allocates it up front, otherwise the first call that needs more allocates
+ * (and thereby synchronises).
+ */
+typedef struct cordic_stream cordic_stream;
+int	cordic_stream_create(const cordic_config *cfg, cordic_stream **s);
+void	cordic_stream_destroy(cordic_stream *s);
+size_t	cordic_stream_workspace(size_t ticks);
+int	cordic_stream_reserve(cordic_stream *s, size_t max_ticks);
+/* latency in enabled clocks from i_* to o_* (NSTAGES + 2) */
+int	cordic_stream_latency(const cordic_stream *s);
+int	cordic_stream_reset(cordic_stream *s, void *stream);
+int	cordic_stream_ticks(cordic_stream *s, size_t ticks,
+		const uint8_t *d_ce, const uint8_t *d_reset, const uint8_t *d_aux,
+		const int32_t *d_xval, const int32_t *d_yval,
+		const uint32_t *d_phase,
+		int32_t *d_out0, int32_t *d_out1, uint8_t *d_oaux, void *stream);
+
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,

@@ -1,0 +1,144 @@
+"""Clocked view of the pipelined cores (cordic_stream).
+
+tests/golden/stream_vectors.json holds clock-by-clock port traces produced by
+executing the reference generator's Verilog (vsim.py) under random i_ce /
+i_reset / i_aux activity.  CPU: the register-level model (stream_model.py, on
+top of the oracle) reproduces them.  GPU: cordic_stream_ticks reproduces them
+when the trace is fed in blocks of arbitrary length, and equals the model on
+long random traces."""
+import json
+import os
+import shlex
+
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+from stream_model import PipeModel
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "stream_vectors.json")))
+MODE = {"p2r": ca.P2R, "r2p": ca.R2P}
+
+
+def configs(args):
+    a = shlex.split(args)
+    get = lambda f, d: int(a[a.index(f) + 1]) if f in a else d  # noqa: E731
+    t = (MODE[a[a.index("-t") + 1]], get("-i", -1), get("-o", -1),
+         get("-x", 2), get("-p", -1), get("-n", -1))
+    return t
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_register_model_reproduces_rtl_traces(name):
+    g = GOLD[name]
+    ocfg = O.config_cli(*configs(g["args"]))
+    rot = "phase" in g
+    m = PipeModel(ocfg, rot)
+    assert m.ns == g["NSTAGES"]
+    o0, o1, oa = m.run(g["x"], g["y"], g.get("phase"), g["ce"], g["reset"],
+                       g["aux"])
+    k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+    assert o0.tolist() == g[k0]
+    assert o1.tolist() == g[k1]
+    assert oa.tolist() == g["o_aux"]
+
+
+def _gpu_run(stream, rot, x, y, ph, ce, rs, aux, cuts):
+    import torch
+    dev = "cuda:0"
+
+    def d32(a):
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)
+                                .astype(np.uint32).view(np.int32)).to(dev)
+
+    def d8(a):
+        return None if a is None else torch.from_numpy(
+            np.ascontiguousarray(a, dtype=np.uint8)).to(dev)
+    n = len(x)
+    dx, dy = d32(x), d32(y)
+    dph = d32(ph) if rot else None
+    dce, drs, dax = d8(ce), d8(rs), d8(aux)
+    o0 = torch.zeros(n, dtype=torch.int32, device=dev)
+    o1 = torch.zeros(n, dtype=torch.int32, device=dev)
+    oa = torch.zeros(n, dtype=torch.uint8, device=dev)
+    edges = [0] + list(cuts) + [n]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b <= a:
+            continue
+        sl = slice(a, b)
+        stream.ticks(dx[sl], dy[sl], dph[sl] if rot else None, o0[sl], o1[sl],
+                     oa[sl], ce=None if dce is None else dce[sl],
+                     reset=None if drs is None else drs[sl],
+                     aux=None if dax is None else dax[sl], n=b - a)
+    torch.cuda.synchronize()
+    r0 = o0.cpu().numpy().astype(np.int64)
+    r1 = o1.cpu().numpy()
+    r1 = r1.astype(np.int64) if rot else r1.view(np.uint32).astype(np.int64)
+    return r0, r1, oa.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_gpu_stream_reproduces_rtl_traces(name):
+    g = GOLD[name]
+    cfg = ca.Config.from_cli(*configs(g["args"]))
+    rot = "phase" in g
+    k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+    n = len(g["x"])
+    # one call, then the same trace cut into blocks at awkward places
+    # (shorter than the pipeline, inside stalls, right after resets)
+    for cuts in ([], [1, 2, 3, 7, 8, 40, 41, n // 6 + 3, n // 2, n // 2 + 5,
+                      n - 9, n - 1]):
+        s = ca.Stream(cfg)
+        assert s.latency == g["NSTAGES"] + 2
+        r0, r1, ra = _gpu_run(s, rot, g["x"], g["y"], g.get("phase"), g["ce"],
+                              g["reset"], g["aux"], cuts)
+        assert r0.tolist() == g[k0]
+        assert r1.tolist() == g[k1]
+        assert ra.tolist() == g["o_aux"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,iw,ow,pw,ns", [
+    (ca.P2R, 13, 13, -1, -1), (ca.R2P, 13, 13, -1, -1),
+    (ca.P2R, 32, 32, 32, 16), (ca.R2P, 24, 24, -1, 20)])
+@pytest.mark.parametrize("flags", ["all", "ce", "reset", "none"])
+def test_gpu_stream_long_random_trace_equals_model(mode, iw, ow, pw, ns, flags):
+    cfg = ca.Config.from_cli(mode, iw, ow, 2, pw, ns)
+    ocfg = O.config_cli(mode, iw, ow, 2, pw, ns)
+    rot = mode == ca.P2R
+    rng = np.random.RandomState(5)
+    n = 40000                       # ~20 scan tiles, several spine rounds
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x, y = rng.randint(lo, hi, n), rng.randint(lo, hi, n)
+    ph = rng.randint(0, 1 << cfg.pw, n, dtype=np.int64)
+    aux = rng.randint(0, 2, n).astype(np.uint8)
+    ce = (rng.randint(0, 4, n) != 0).astype(np.uint8) \
+        if flags in ("all", "ce") else None
+    rs = (rng.randint(0, 3000, n) == 0).astype(np.uint8) \
+        if flags in ("all", "reset") else None
+    if ce is not None:
+        ce[5000:5000 + 3 * (cfg.nstages + 2)] = 0
+    cuts = [17, 2048, 2049, 4096 + 5, 20000, 20001, 39990]
+    s = ca.Stream(cfg)
+    r0, r1, ra = _gpu_run(s, rot, x, y, ph, ce, rs, aux, cuts)
+    m0, m1, ma = PipeModel(ocfg, rot).run(x, y, ph, ce, rs, aux)
+    assert np.array_equal(r0, m0)
+    assert np.array_equal(r1, m1)
+    assert np.array_equal(ra, ma)
+    # cordic_stream_reset == a clock with i_reset: outputs restart from zero
+    s.reset()
+    r0, r1, ra = _gpu_run(s, rot, x[:200], y[:200], ph[:200], None, None,
+                          aux[:200], [])
+    m0, m1, ma = PipeModel(ocfg, rot).run(x[:200], y[:200], ph[:200], None,
+                                          None, aux[:200])
+    assert np.array_equal(r0, m0) and np.array_equal(r1, m1)
+    assert np.array_equal(ra, ma)
+
+
+@pytest.mark.gpu
+def test_stream_refuses_sequential_cores():
+    with pytest.raises(ca.CordicError):
+        ca.Stream(ca.Config.from_cli(ca.SP2R, 13, 13))
