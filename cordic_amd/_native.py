@@ -7,6 +7,7 @@ MAX_STAGES = 64
 FLAG_FORCE_GENERIC = 0x1
 FLAG_NO_LJ = 0x4
 FLAG_NO_SEED = 0x8
+FLAG_UNIT_GAIN = 0x10
 # enum cordic_status (the codes tests assert on)
 ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9
 
@@ -107,6 +108,8 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_gain_annihilator": (C.c_uint32, [C.c_int]),
+    "cordic_config_gain_annihilator": (C.c_uint32, [_cfgp]),
     "cordic_stream_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
     "cordic_stream_destroy": (None, [C.c_void_p]),
     "cordic_stream_workspace": (C.c_size_t, [C.c_size_t]),

@@ -540,6 +540,11 @@ int cordic_config_write_header(const cordic_config *cfg, const char *name,
 
 int cordic_nextlg(unsigned vl) { return next_lg(vl); }
 double cordic_gain(int nstages) { return rotation_gain(nstages); }
+uint32_t cordic_gain_annihilator(int nstages) { return gain_annihilator(nstages); }
+uint32_t cordic_config_gain_annihilator(const cordic_config *cfg)
+{
+	return cfg ? core_gain_annihilator(*cfg) : 0u;
+}
 double cordic_phase_variance(int nstages, int phase_bits)
 {
 	return phase_variance(nstages, phase_bits);

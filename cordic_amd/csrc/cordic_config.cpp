@@ -44,6 +44,25 @@ double rotation_gain(int nstages)
 	return g;
 }
 
+// "You can annihilate this gain by multiplying by 32'h%08x and right shifting
+// by 32 bits": sw/cordiclib.cpp:205-209.
+uint32_t gain_annihilator(int nstages)
+{
+	return (unsigned)(1.0 / rotation_gain(nstages) * (4.0 * (1ul << 30)));
+}
+
+// The constant as the generator prints it for this core: the sequential
+// emitters pad the table to a power of two before the comment block is
+// written (sw/cordiclib.cpp:145-149 via sw/seqcordic.cpp:285,
+// sw/seqpolar.cpp:237), the pipelined ones do not.
+uint32_t core_gain_annihilator(const cordic_config &c)
+{
+	int n = c.nstages;
+	if (c.mode == CORDIC_SP2R || c.mode == CORDIC_SR2P)
+		n = 1 << next_lg((unsigned)c.nstages);
+	return gain_annihilator(n);
+}
+
 // Variance (radians^2) of the truncated angle table plus the initial 1/12;
 // sw/cordiclib.cpp:82-109.
 double phase_variance(int nstages, int phase_bits)

@@ -61,6 +61,8 @@ struct CoreParams {
 	int32_t	x0, y0;		// constant-vector feeds (sign extended)
 	uint32_t phase0, fcw;	// NCO, left-justified
 	uint64_t index0;	// NCO: global index of sample 0
+	uint32_t post_mul;	// 0, or the gain-annihilation multiplier
+				// (CORDIC_FLAG_UNIT_GAIN): o = (o * post_mul) >> 32
 };
 
 // ---------------------------------------------------------------- utilities
@@ -391,6 +393,24 @@ __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &k
 	return (int32_t)(w >> kp.r_lj);
 }
 
+// Optional fused output scaling: "You can annihilate this gain by multiplying
+// by 32'h%08x and right shifting by 32 bits" (sw/cordiclib.cpp:205-209).  The
+// OW-bit output is the signed factor, the constant an unsigned 32-bit one;
+// the shift is arithmetic.  Wave-uniform branch: free when the flag is off.
+__device__ __forceinline__ int32_t unit_gain(int32_t o, uint32_t k)
+{
+	return (int32_t)(((int64_t)o * (int64_t)(uint64_t)k) >> 32);
+}
+template <typename V>
+__device__ __forceinline__ void apply_unit_gain(V &v, const CoreParams &kp)
+{
+	if (kp.post_mul != 0) {
+#pragma unroll
+		for (int i = 0; i < kVec; i++)
+			v[i] = unit_gain(v[i], kp.post_mul);
+	}
+}
+
 // ------------------------------------------------------- memory accessors
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -611,6 +631,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				}
 			}
 		}
+		apply_unit_gain(rx, kp);
+		apply_unit_gain(ry, kp);
 		store_out<true>(&ox[g], IO::narrow(rx));
 		store_out<true>(&oy[g], IO::narrow(ry));
 	}
@@ -811,6 +833,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				}
 			}
 		}
+		apply_unit_gain(rx, kp);
+		apply_unit_gain(ry, kp);
 		store_out<false>(&ox[g], IO::narrow(rx));
 		store_out<false>(&oy[g], IO::narrow(ry));
 	}
@@ -888,6 +912,7 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			rm[v] = round_to_ow<T>((T)x[v], kp);
 			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
 		}
+		apply_unit_gain(rm, kp);
 		store_out<true>(&omag[g], IO::narrow(rm));
 		store_out<true>(&oph[g], IO::narrow(rp));
 	}

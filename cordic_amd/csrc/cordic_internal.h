@@ -13,6 +13,8 @@ namespace cordic_amd {
 // ---- host: cordic_config.cpp
 uint32_t arctan_entry(unsigned k, int phase_bits);
 double	rotation_gain(int nstages);
+uint32_t gain_annihilator(int nstages);
+uint32_t core_gain_annihilator(const cordic_config &c);
 double	phase_variance(int nstages, int phase_bits);
 double	quantization_variance(int nstages, int xtrabits, int dropped_bits);
 int	next_lg(unsigned vl);

@@ -32,8 +32,9 @@ __device__ __forceinline__ int32_t round_generic(int64_t v, const CoreParams &kp
 	const uint64_t b = ((uint64_t)v >> kp.r) & (uint64_t)kp.round_bit;
 	int64_t w = (int64_t)((uint64_t)v + (uint64_t)kp.round_base + b);
 	w = wrap_ww(w, kp);
-	const int32_t o = (int32_t)(w >> kp.r);
-	return kp.wrap ? sext32(o, kp.ow) : o;
+	int32_t o = (int32_t)(w >> kp.r);
+	o = kp.wrap ? sext32(o, kp.ow) : o;
+	return kp.post_mul ? unit_gain(o, kp.post_mul) : o;
 }
 
 template <Feed FEED, typename IO = Io32>
@@ -389,6 +390,7 @@ CoreParams make_params(const cordic_config &c)
 	const int lj = (c.ww == 35) ? 29 : 30;
 	kp.r_lj = kp.r + lj;
 	kp.round_base_lj = (int64_t)((uint64_t)kp.round_base << lj);
+	kp.post_mul = (c.flags & CORDIC_FLAG_UNIT_GAIN) ? core_gain_annihilator(c) : 0u;
 	return kp;
 }
 

@@ -78,6 +78,10 @@ enum cordic_status {
 #define CORDIC_FLAG_FORCE_GENERIC	0x1u	/* never use an unrolled kernel */
 #define CORDIC_FLAG_NO_LJ		0x4u	/* WW 33..35: right-justified
 						   64-bit kernel (for A/B)      */
+#define CORDIC_FLAG_UNIT_GAIN		0x10u	/* fuse the gain-annihilation
+						   multiply into the output:
+						   o = (o * K) >> 32, K =
+						   cordic_config_gain_annihilator */
 #define CORDIC_FLAG_NO_SEED		0x8u	/* plans: full recurrence, no
 						   seed table (for A/B)         */
 
@@ -146,6 +150,14 @@ int	cordic_config_write_header(const cordic_config *cfg, const char *name,
  * them directly. */
 int	cordic_nextlg(unsigned vl);
 double	cordic_gain(int nstages);
+/* "You can annihilate this gain by multiplying by 32'h%08x and right shifting
+ * by 32 bits" (sw/cordiclib.cpp:205-209): that constant for a stage count, and
+ * as the generator prints it into the given core (the sequential cores' tables
+ * are padded to a power of two first, sw/cordiclib.cpp:145-149).  With
+ * CORDIC_FLAG_UNIT_GAIN set in cfg.flags every kernel applies it to o_xval /
+ * o_yval / o_mag before the store: o = (int64(o) * K) >> 32. */
+uint32_t cordic_gain_annihilator(int nstages);
+uint32_t cordic_config_gain_annihilator(const cordic_config *cfg);
 double	cordic_phase_variance(int nstages, int phase_bits);
 double	cordic_transform_quantization_variance(int nstages, int xtrabits,
 		int dropped_bits);

@@ -5,7 +5,8 @@ generator (oracle/_ref/gencordic, built by oracle/Makefile from
 
 For every command line below the generator is run; from the Verilog it emits
 we keep only DATA: the localparam values, the cordic_angle[] table and the
-pre-rotation phase constants; from the C header it emits (-c) we keep the
+pre-rotation phase constants and the gain-annihilation multiplier of the
+comment block (sw/cordiclib.cpp:205-209); from the C header it emits (-c) we keep the
 constant lines between #ifndef/#endif.  These pin the parameter derivation
 (sw/main.cpp:260-357), the angle table (sw/cordiclib.cpp:157-169) and the
 header emission (sw/basiccordic.cpp:449-505, sw/topolar.cpp:412-451,
@@ -84,6 +85,10 @@ def run_one(name, args):
     out["prerot_consts"] = [int(hx, 16) for hx in re.findall(
         r"(?:preph|ph\[0\])\s*<=\s*(?:i_phase - )?\d+'h([0-9a-f]+);", v)]
     out["rounds"] = ("Round our" in v)
+    # "You can annihilate this gain by multiplying by 32'h%08x"
+    # (sw/cordiclib.cpp:205-209)
+    m = re.search(r"annihilate this gain by multiplying by 32'h([0-9a-f]+)", v)
+    out["annihilate"] = int(m.group(1), 16) if m else None
     m = re.search(r"#ifndef.*#endif[^\n]*\n", h, re.S)
     out["header"] = m.group(0) if m else ""
     return out

@@ -642,3 +642,48 @@ def test_entry_points_are_stream_ordered_and_graph_capturable():
         rm, rp = O.topolar(rocfg, rx, ry)
         assert np.array_equal(to_np(mag), rm)
         assert np.array_equal(to_np(ang, np.uint32), rp)
+
+
+# ------------------------------------------------ fused gain annihilation
+
+@pytest.mark.parametrize("mode,iw,ow,pw,ns,flags", [
+    (ca.P2R, 32, 32, 32, 16, 0),                 # seeded / LJ unrolled
+    (ca.P2R, 13, 13, -1, -1, 0),                 # narrow
+    (ca.P2R, 32, 32, 32, 19, 0),                 # dynamic-exit instance
+    (ca.SP2R, 13, 13, -1, -1, 0),                # padded-table constant
+    (ca.P2R, 13, 13, -1, -1, ca.FLAG_FORCE_GENERIC),
+    (ca.R2P, 24, 24, -1, 20, 0),
+    (ca.R2P, 13, 13, -1, -1, ca.FLAG_FORCE_GENERIC),
+])
+def test_unit_gain_flag_is_output_times_k_shift_32(mode, iw, ow, pw, ns, flags):
+    """CORDIC_FLAG_UNIT_GAIN: every output is (o * K) >> 32 with the K the
+    generator prints into the core (sw/cordiclib.cpp:205-209)."""
+    base, ocfg = both(mode, iw, ow, 2, pw, ns)
+    cfg = base.with_flags(flags | ca.FLAG_UNIT_GAIN)
+    k = ca.lib().cordic_config_gain_annihilator(cfg.ref)
+    assert 0xd0000000 < k < 0xe0000000
+    rng = np.random.RandomState(21)
+    n = (1 << 16) + 3
+    x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, n)
+
+    def scaled(a):
+        return ((a.astype(np.int64) * k) >> 32).astype(np.int32)
+    if mode in (ca.P2R, ca.SP2R):
+        gx, gy = gpu_p2r(cfg, x, y, ph)
+        rx, ry = O.rotate(ocfg, x, y, ph)
+        assert np.array_equal(gx, scaled(rx)) and np.array_equal(gy, scaled(ry))
+        x0 = (1 << (cfg.iw - 1)) - 1
+        gx, gy = gpu_plan_p2r(ca.Plan(cfg), x0, 0, ph)
+        rx, ry = O.rotate(ocfg, x0, 0, ph)
+        assert np.array_equal(gx, scaled(rx)) and np.array_equal(gy, scaled(ry))
+        # amplitude really is ~ unity gain now: |out| ~ x0 * 2^(OW-IW-1)... * 1
+        if mode == ca.P2R:
+            mag = np.hypot(gx.astype(float), gy.astype(float))
+            want = x0 * 2.0 ** (cfg.ow - cfg.iw - 1) * \
+                (ca.lib().cordic_gain(cfg.nstages) * k / 2.0 ** 32)
+            assert abs(mag.mean() / want - 1) < 1e-3
+            assert abs(ca.lib().cordic_gain(cfg.nstages) * k / 2.0 ** 32 - 1) < 1e-6
+    else:
+        gm, gp = gpu_r2p(cfg, x, y)
+        rm, rp = O.topolar(ocfg, x, y)
+        assert np.array_equal(gm, scaled(rm)) and np.array_equal(gp, rp)

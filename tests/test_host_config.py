@@ -61,8 +61,13 @@ def test_config_matches_reference_generator(golden):
         assert (cfg.iw, cfg.ow, cfg.ww, cfg.pw, cfg.nstages, cfg.nextra) == (
             e["IW"], e["OW"], e["WW"], e["PW"], e["NSTAGES"], e["XTRA"]), name
         assert cfg.angles == e["angles"][: cfg.nstages], name
+        # the multiplier of the "annihilate this gain" comment
+        # (sw/cordiclib.cpp:205-209), as printed into this very core
+        assert ca.lib().cordic_config_gain_annihilator(cfg.ref) == \
+            e["annihilate"], name
         checked += 1
     assert checked >= 140
+    assert ca.lib().cordic_gain_annihilator(16) == 0xdbd95b16   # rtl/cordic.v:224
 
 
 def test_header_text_is_byte_identical(golden):
