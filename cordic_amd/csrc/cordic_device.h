@@ -396,15 +396,16 @@ __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &k
 // Optional fused output scaling: "You can annihilate this gain by multiplying
 // by 32'h%08x and right shifting by 32 bits" (sw/cordiclib.cpp:205-209).  The
 // OW-bit output is the signed factor, the constant an unsigned 32-bit one;
-// the shift is arithmetic.  Wave-uniform branch: free when the flag is off.
+// the shift is arithmetic.  Compiled into separate (dynamic-exit) instances,
+// UG = true: even a wave-uniform branch on it measured ~1 % on the hot kernels.
 __device__ __forceinline__ int32_t unit_gain(int32_t o, uint32_t k)
 {
 	return (int32_t)(((int64_t)o * (int64_t)(uint64_t)k) >> 32);
 }
-template <typename V>
+template <bool UG, typename V>
 __device__ __forceinline__ void apply_unit_gain(V &v, const CoreParams &kp)
 {
-	if (kp.post_mul != 0) {
+	if constexpr (UG) {
 #pragma unroll
 		for (int i = 0; i < kVec; i++)
 			v[i] = unit_gain(v[i], kp.post_mul);
@@ -493,7 +494,7 @@ __device__ __forceinline__ void store_out(V *dst, V v)
 // 0..3 trailing samples to the generic kernel.  Keeping the tail out of this
 // kernel is what lets hipcc emit global_load_dwordx4 / global_store_dwordx4.
 template <typename C, int NLIVE, int NGEN, Feed FEED, bool DYN = false,
-		typename IO = Io32>
+		typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		const typename IO::ivec *__restrict__ xin,
 		const typename IO::ivec *__restrict__ yin,
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				}
 			}
 		}
-		apply_unit_gain(rx, kp);
-		apply_unit_gain(ry, kp);
+		apply_unit_gain<UG>(rx, kp);
+		apply_unit_gain<UG>(ry, kp);
 		store_out<true>(&ox[g], IO::narrow(rx));
 		store_out<true>(&oy[g], IO::narrow(ry));
 	}
@@ -654,7 +655,7 @@ struct SeedArgs {
 };
 
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
-		typename IO = Io32>
+		typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		SeedArgs sa, const typename IO::uvec *__restrict__ phin,
 		typename IO::ivec *__restrict__ ox,
@@ -833,8 +834,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				}
 			}
 		}
-		apply_unit_gain(rx, kp);
-		apply_unit_gain(ry, kp);
+		apply_unit_gain<UG>(rx, kp);
+		apply_unit_gain<UG>(ry, kp);
 		store_out<false>(&ox[g], IO::narrow(rx));
 		store_out<false>(&oy[g], IO::narrow(ry));
 	}
@@ -863,7 +864,7 @@ __device__ __forceinline__ void fold_quadrant_masks(T ex, T ey, int32_t ix,
 }
 
 template <typename C, int NLIVE, int NGEN, bool DYN = false,
-		typename IO = Io32>
+		typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 		const typename IO::ivec *__restrict__ xin,
 		const typename IO::ivec *__restrict__ yin,
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			rm[v] = round_to_ow<T>((T)x[v], kp);
 			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
 		}
-		apply_unit_gain(rm, kp);
+		apply_unit_gain<UG>(rm, kp);
 		store_out<true>(&omag[g], IO::narrow(rm));
 		store_out<true>(&oph[g], IO::narrow(rp));
 	}

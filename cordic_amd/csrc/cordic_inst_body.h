@@ -22,6 +22,19 @@ bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 {
 	using namespace dev;
 	constexpr int G = CORDIC_INST_NGEN;
+	// fused output scaling (CORDIC_FLAG_UNIT_GAIN): its own dynamic-exit
+	// instance, so that the static instances carry no trace of it
+	if (kp.post_mul != 0) {
+		if (nlive < 1 || nlive > kDynStages)
+			return false;
+		hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER,
+				kDynStages, (G > kDynStages ? kDynStages : G), FEED,
+				true, Io32, true>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i32x4 *)j.x, (const i32x4 *)j.y,
+			(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
+			j.n / kVec);
+		return true;
+	}
 	switch (nlive) {
 #define X(N) case N: \
 	hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER, N, \
@@ -65,6 +78,20 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 		const dev::SeedArgs &sa, const RotatorJob &j, size_t lds_bytes)
 {
 	using namespace dev;
+	if (kp.post_mul != 0) {		// see launch_feed
+		if (nlive < kSeedStages || nlive > kDynStages)
+			return false;
+		auto kern = rotator_seeded<CORDIC_INST_CONTAINER, kDynStages,
+				kSeedStages, FEED, true, Io32, true>;
+		if (lds_bytes > 64 * 1024)
+			(void)hipFuncSetAttribute((const void *)kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)lds_bytes);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st,
+			kp, sa, (const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
+			j.n / kVec);
+		return true;
+	}
 	switch (nlive) {
 #define X(N) case N: { \
 	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
@@ -113,6 +140,15 @@ bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,
 {
 	using namespace dev;
 	constexpr int G = CORDIC_INST_NGEN;
+	if (kp.post_mul != 0) {		// see launch_feed
+		if (nlive < 1 || nlive > kDynStages)
+			return false;
+		hipLaunchKernelGGL((topolar_unrolled<CORDIC_INST_CONTAINER, kDynStages,
+				(G > kDynStages ? kDynStages : G), true, Io32, true>),
+			dim3(grid), dim3(kBlock), 0, st, kp, (const i32x4 *)x,
+			(const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, n / kVec);
+		return true;
+	}
 	switch (nlive) {
 #define X(N) case N: \
 	hipLaunchKernelGGL((topolar_unrolled<CORDIC_INST_CONTAINER, N, \

@@ -20,10 +20,16 @@ bool rot16(int nlive, int grid, hipStream_t st, const CoreParams &kp,
 {
 	if (nlive < 1 || nlive > kDynStages)
 		return false;
-	hipLaunchKernelGGL((rotator_unrolled<Narrow32, kDynStages, 0, FEED, true,
-			Io16>), dim3(grid), dim3(kBlock), 0, st, kp,
-		(const i16x4 *)j.x, (const i16x4 *)j.y, (const u16x4 *)j.phase,
-		(i16x4 *)j.ox, (i16x4 *)j.oy, j.n / kVec);
+	if (kp.post_mul != 0)		// CORDIC_FLAG_UNIT_GAIN
+		hipLaunchKernelGGL((rotator_unrolled<Narrow32, kDynStages, 0, FEED,
+				true, Io16, true>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i16x4 *)j.x, (const i16x4 *)j.y, (const u16x4 *)j.phase,
+			(i16x4 *)j.ox, (i16x4 *)j.oy, j.n / kVec);
+	else
+		hipLaunchKernelGGL((rotator_unrolled<Narrow32, kDynStages, 0, FEED,
+				true, Io16>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i16x4 *)j.x, (const i16x4 *)j.y, (const u16x4 *)j.phase,
+			(i16x4 *)j.ox, (i16x4 *)j.oy, j.n / kVec);
 	return true;
 }
 
@@ -33,8 +39,10 @@ bool seed16(int nlive, int grid, hipStream_t st, const CoreParams &kp,
 {
 	if (nlive < kSeedStages || nlive > kDynStages)
 		return false;
-	auto kern = rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true,
-			Io16>;
+	auto kern = (kp.post_mul != 0)
+		? rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true, Io16,
+				true>
+		: rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true, Io16>;
 	if (lds_bytes > 64 * 1024)
 		(void)hipFuncSetAttribute((const void *)kern,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -77,9 +85,16 @@ bool launch_pol_narrow16(int nlive, int grid, hipStream_t st,
 {
 	if (nlive < 1 || nlive > kDynStages)
 		return false;
-	hipLaunchKernelGGL((topolar_unrolled<Narrow32, kDynStages, 0, true, Io16>),
-		dim3(grid), dim3(kBlock), 0, st, kp, (const i16x4 *)x,
-		(const i16x4 *)y, (i16x4 *)mag, (u16x4 *)ph, n / kVec);
+	if (kp.post_mul != 0)
+		hipLaunchKernelGGL((topolar_unrolled<Narrow32, kDynStages, 0, true,
+				Io16, true>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i16x4 *)x, (const i16x4 *)y, (i16x4 *)mag, (u16x4 *)ph,
+			n / kVec);
+	else
+		hipLaunchKernelGGL((topolar_unrolled<Narrow32, kDynStages, 0, true,
+				Io16>), dim3(grid), dim3(kBlock), 0, st, kp,
+			(const i16x4 *)x, (const i16x4 *)y, (i16x4 *)mag, (u16x4 *)ph,
+			n / kVec);
 	return true;
 }
 

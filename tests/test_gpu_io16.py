@@ -173,3 +173,39 @@ def test_container_errors():
     # the NCO takes scalar phases: any PW
     ca.nco(ca.Config.from_cli(ca.P2R, 16, 16, 2, 32, 16), 16, 0, 1, 0, 1, 0, t, t)
     torch.cuda.synchronize()
+
+
+def test_unit_gain_on_16bit_containers():
+    """CORDIC_FLAG_UNIT_GAIN through the io16 instances (rotator, seeded,
+    converter)."""
+    base, ocfg = both(ca.P2R, 16, 16, 2, 16, 16)
+    cfg = base.with_flags(ca.FLAG_UNIT_GAIN)
+    k = ca.lib().cordic_config_gain_annihilator(cfg.ref)
+    rng = np.random.RandomState(33)
+    n = (1 << 16) + 2
+    x, y, ph = rand16(rng, 16, 16, n)
+
+    def scaled(a):
+        return ((a.astype(np.int64) * k) >> 32).astype(np.int16)
+    rx, ry = O.rotate(ocfg, x.astype(np.int32), y.astype(np.int32),
+                      ph.astype(np.uint32))
+    ox, oy = out16(n), out16(n)
+    ca.p2r(cfg, dev16(x), dev16(y), dev16(ph), ox, oy, n=n)
+    torch.cuda.synchronize()
+    assert np.array_equal(ox.cpu().numpy(), scaled(rx))
+    assert np.array_equal(oy.cpu().numpy(), scaled(ry))
+    rx, ry = O.rotate(ocfg, 32767, 0, ph.astype(np.uint32))
+    ca.Plan(cfg).p2r_const(32767, 0, dev16(ph), ox, oy, n=n)
+    torch.cuda.synchronize()
+    assert np.array_equal(ox.cpu().numpy(), scaled(rx))
+    assert np.array_equal(oy.cpu().numpy(), scaled(ry))
+
+    base, ocfg = both(ca.R2P, 16, 16, 2, 16, -1)
+    cfg = base.with_flags(ca.FLAG_UNIT_GAIN)
+    k = ca.lib().cordic_config_gain_annihilator(cfg.ref)
+    rm, rp = O.topolar(ocfg, x.astype(np.int32), y.astype(np.int32))
+    mag, oph = out16(n), out16(n)
+    ca.r2p(cfg, dev16(x), dev16(y), mag, oph, n=n)
+    torch.cuda.synchronize()
+    assert np.array_equal(mag.cpu().numpy(), scaled(rm))
+    assert np.array_equal(oph.cpu().numpy().view(np.uint16), rp.astype(np.uint16))

@@ -29,7 +29,8 @@ def counters(sub):
 
 def short(name):
     for key in ("rotator_seeded", "rotator_unrolled", "rotator_generic",
-                "topolar_unrolled", "topolar_generic"):
+                "topolar_unrolled", "topolar_generic", "table_lookup",
+                "quad_lookup"):
         if key in name:
             return key
     return None
