@@ -424,9 +424,21 @@ typedef int16_t i16x4 __attribute__((ext_vector_type(4)));
 // at most 16 bits wide (the 16-bit benches of the reference keep their
 // samples in shorts) -- half the HBM bytes per sample; a lane then moves
 // 8 bytes per array per pass.  In registers both are 32-bit.
+//
+// The vector types that global pointers point to only promise ELEMENT
+// alignment: hipcc still emits global_load/store_dwordx4 (dwordx2) for them,
+// and gfx950 executes those at any element-aligned address (measured,
+// tools/unaligned_probe.hip: a 1R2W stream displaced by 4/8/12 bytes runs at
+// 3.9 TB/s against 4.7 TB/s aligned).  So a caller's odd offset costs ~20 %
+// instead of dropping the job onto the generic kernel.
+typedef u32x4 u32x4g __attribute__((aligned(4)));
+typedef i32x4 i32x4g __attribute__((aligned(4)));
+typedef u16x4 u16x4g __attribute__((aligned(2)));
+typedef i16x4 i16x4g __attribute__((aligned(2)));
+
 struct Io32 {
-	typedef u32x4 uvec;
-	typedef i32x4 ivec;
+	typedef u32x4g uvec;
+	typedef i32x4g ivec;
 	typedef uint32_t uelem;
 	typedef int32_t ielem;
 	static __device__ __forceinline__ u32x4 widen(u32x4 v) { return v; }
@@ -435,8 +447,8 @@ struct Io32 {
 	static __device__ __forceinline__ i32x4 narrow(i32x4 v) { return v; }
 };
 struct Io16 {
-	typedef u16x4 uvec;
-	typedef i16x4 ivec;
+	typedef u16x4g uvec;
+	typedef i16x4g ivec;
 	typedef uint16_t uelem;
 	typedef int16_t ielem;
 	static __device__ __forceinline__ u32x4 widen(u16x4 v)
@@ -458,35 +470,32 @@ struct Io16 {
 };
 
 // Input loads: streamed once, never re-read (-DCORDIC_NT_LOADS: non-temporal).
-template <typename V>
-__device__ __forceinline__ V load_in(const V *src)
-{
+// Macros, not function templates: template deduction would strip the element
+// alignment off the pointer's vector typedef (Io32 / Io16).
 #ifdef CORDIC_NT_LOADS
-	return __builtin_nontemporal_load(src);
+#define CORDIC_LOAD_IN(ptr) __builtin_nontemporal_load(ptr)
 #else
-	return *src;
+#define CORDIC_LOAD_IN(ptr) (*(ptr))
 #endif
-}
 
 // Output stores.  Outputs are written once and never re-read by the engine.
 // Measured on MI355X: the non-temporal form is as good or better for the
 // VALU-bound kernels (full recurrence), while the table-seeded kernel, which
 // runs close to HBM speed, is faster with plain stores (cfg2: 439 vs 406
 // Gsample/s) -- so the choice is per kernel.
-template <bool NT, typename V>
-__device__ __forceinline__ void store_out(V *dst, V v)
-{
 #if defined(CORDIC_FORCE_NT_STORES)
-	__builtin_nontemporal_store(v, dst);
+#define CORDIC_STORE_OUT(NT, ptr, val) __builtin_nontemporal_store((val), (ptr))
 #elif defined(CORDIC_FORCE_PLAIN_STORES)
-	*dst = v;
+#define CORDIC_STORE_OUT(NT, ptr, val) (*(ptr) = (val))
 #else
-	if constexpr (NT)
-		__builtin_nontemporal_store(v, dst);
-	else
-		*dst = v;
+#define CORDIC_STORE_OUT(NT, ptr, val) \
+	do { \
+		if constexpr (NT) \
+			__builtin_nontemporal_store((val), (ptr)); \
+		else \
+			*(ptr) = (val); \
+	} while (0)
 #endif
-}
 
 // --------------------------------------------------------- unrolled rotator
 
@@ -634,8 +643,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		}
 		apply_unit_gain<UG>(rx, kp);
 		apply_unit_gain<UG>(ry, kp);
-		store_out<true>(&ox[g], IO::narrow(rx));
-		store_out<true>(&oy[g], IO::narrow(ry));
+		CORDIC_STORE_OUT(true, &ox[g], IO::narrow(rx));
+		CORDIC_STORE_OUT(true, &oy[g], IO::narrow(ry));
 	}
 }
 
@@ -748,13 +757,13 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	typename IO::uvec nph{};
 	if constexpr (FEED != Feed::Nco_ConstXY)
 		if (g < hi)
-			nph = load_in(&phin[g]);
+			nph = CORDIC_LOAD_IN(&phin[g]);
 	for (; g < hi; g += stride) {
 		const u32x4 tph = IO::widen(nph);
 		if constexpr (FEED != Feed::Nco_ConstXY) {
 			const size_t gn = g + stride;
 			if (gn < hi)
-				nph = load_in(&phin[gn]);
+				nph = CORDIC_LOAD_IN(&phin[gn]);
 		}
 		uint32_t P[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
@@ -836,8 +845,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 		apply_unit_gain<UG>(rx, kp);
 		apply_unit_gain<UG>(ry, kp);
-		store_out<false>(&ox[g], IO::narrow(rx));
-		store_out<false>(&oy[g], IO::narrow(ry));
+		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
+		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	}
 }
 
@@ -914,8 +923,8 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 			rp[v] = (uint32_t)p[v] >> kp.pw_shl;	// rtl/topolar.v:269
 		}
 		apply_unit_gain<UG>(rm, kp);
-		store_out<true>(&omag[g], IO::narrow(rm));
-		store_out<true>(&oph[g], IO::narrow(rp));
+		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
+		CORDIC_STORE_OUT(true, &oph[g], IO::narrow(rp));
 	}
 }
 

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void digest_u32(const uint32_t *w, size_t n
 
 // ------------------------------------------------------------ host helpers
 
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+bool aligned2(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 1u) == 0; }
 
 // sample arrays are int32 or (io16) int16 underneath the int32_t* of the job
 template <typename P> P *advance(P *p, size_t samples, bool io16)
@@ -421,8 +421,8 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 	kp.fcw = j.fcw << kp.pw_shl;
 	kp.index0 = j.index0;
 
-	// a lane moves kVec samples per array per pass: 16 bytes, or 8 (io16)
-	bool (*const vec_aligned)(const void *) = j.io16 ? aligned8 : aligned16;
+	// the vector kernels need element alignment only (cordic_device.h: Io32)
+	bool (*const vec_aligned)(const void *) = j.io16 ? aligned2 : aligned4;
 	bool vec_ok = vec_aligned(j.ox) && vec_aligned(j.oy);
 	if (FEED != Feed::Nco_ConstXY)
 		vec_ok = vec_ok && vec_aligned(j.phase);
@@ -548,7 +548,7 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		return CORDIC_ERR_ARGS;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const CoreParams kp = make_params(cfg);
-	bool (*const vec_aligned)(const void *) = io16 ? aligned8 : aligned16;
+	bool (*const vec_aligned)(const void *) = io16 ? aligned2 : aligned4;
 	const bool vec_ok = vec_aligned(x) && vec_aligned(y) && vec_aligned(mag)
 			&& vec_aligned(phase);
 	const bool fast_ok = vec_ok && !(cfg.flags & CORDIC_FLAG_FORCE_GENERIC)
