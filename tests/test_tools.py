@@ -132,3 +132,23 @@ def test_gencordic_amd_writes_the_reference_quadtbl_files(tmp_path):
                         "-f", str(tmp_path / "bad.v")], capture_output=True,
                        text=True)
     assert r.returncode != 0 and "ERR" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cordic_tb_quadtbl_report():
+    """bench/cpp/quadtbl_tb.cpp on the checked-in core (-p 18 -o 13)."""
+    r = subprocess.run([TB, "-t", "qtbl", "-o", "13", "-p", "18"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SUCCESS!!" in r.stdout
+    mx = float(re.search(r"MXERR: ([\d.]+) \(Expected (-?[\d.]+)\)",
+                         r.stdout).group(1))
+    q = O.quad_cli(ow=13, pw=18)
+    ph = np.arange(1 << 18, dtype=np.uint32)
+    out = O.quad_lookup(q, O.quad_tables(q), ph)
+    want = np.sin(ph * (2 * np.pi / (1 << 18))) * 4095
+    assert abs(mx - np.abs(want - out).max()) < 1e-5
+    assert "MXVAL: 0x%08x" % out.max() in r.stdout
+    assert "MNVAL: 0x%08x" % (int(out.min()) & 0xffffffff) in r.stdout
+    sfdr = float(re.search(r"SFDR = +([\d.]+)", r.stdout).group(1))
+    assert sfdr > 80.0

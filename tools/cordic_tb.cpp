@@ -7,10 +7,14 @@
 //
 //   cordic_tb <gencordic args>        e.g.  cordic_tb -t p2r -i 13 -o 13 -x 2
 //   cordic_tb -t r2p -i 13 -o 13 -x 2
+//   cordic_tb -t qtbl -o 13 -p 18     (bench/cpp/quadtbl_tb.cpp)
 //
 // p2r / sp2r : bench/cpp/cordic_tb.cpp:61-69 (x = 2^(IW-1)-1, y = 0),
 //              :127-139 (all 2^PW phases), :223-337 (statistics, thresholds),
 //              :342-371 (SFDR; printed, not asserted, PW < 26 only).
+// qtbl       : bench/cpp/quadtbl_tb.cpp:82-127 (min(2^PW, 2^26) phases, rounded
+//              onto the PW-bit grid when PW > 26), :146-177 (max error against
+//              sin * (2^(OW-1)-1), threshold |TBL_ERR| + 2), :182-211 (SFDR).
 // r2p / sr2p : bench/cpp/topolar_tb.cpp:127-147 (two turns of a circle of
 //              radius 2^(IW-1)-1, (int) truncation), :222-256, :303-315.
 //
@@ -21,6 +25,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "cordic_amd.h"
@@ -204,8 +209,80 @@ static int run_r2p(const cordic_config &cfg)
 	return EXIT_SUCCESS;
 }
 
+static int run_qtbl(int argc, char **argv)
+{
+	int iw = -1, ow = -1, pw = -1, xtra = 2;
+	for (int k = 1; k + 1 < argc; k++) {
+		if (!strcmp(argv[k], "-i")) iw = atoi(argv[k + 1]);
+		else if (!strcmp(argv[k], "-o")) ow = atoi(argv[k + 1]);
+		else if (!strcmp(argv[k], "-p")) pw = atoi(argv[k + 1]);
+		else if (!strcmp(argv[k], "-x")) xtra = atoi(argv[k + 1]);
+	}
+	cordic_quad_config qc;
+	CORDIC_OK_OR_DIE(cordic_quad_config_init(&qc, iw, ow, xtra, pw));
+	const int PW = qc.pw, OW = qc.ow;
+	const long LGNSAMPLES = (PW > 26) ? 26 : PW;
+	const size_t n = (size_t)1 << LGNSAMPLES;
+
+	// quadtbl_tb.cpp:100-114
+	std::vector<uint32_t> pdata(n);
+	const int shift = (int)(PW - LGNSAMPLES);
+	for (size_t i = 0; i < n; i++)
+		pdata[i] = (uint32_t)((uint64_t)i << shift);
+	std::vector<int32_t> sdata(n);
+	uint32_t *d_ph; int32_t *d_o;
+	cordic_quad *core = nullptr;
+	HIP_OK(hipMalloc((void **)&d_ph, n * 4));
+	HIP_OK(hipMalloc((void **)&d_o, n * 4));
+	HIP_OK(hipMemcpy(d_ph, pdata.data(), n * 4, hipMemcpyHostToDevice));
+	CORDIC_OK_OR_DIE(cordic_quad_create(&qc, &core));
+	CORDIC_OK_OR_DIE(cordic_quad_lookup(core, n, d_ph, d_o, nullptr));
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipMemcpy(sdata.data(), d_o, n * 4, hipMemcpyDeviceToHost));
+	cordic_quad_destroy(core);
+	(void)hipFree(d_ph); (void)hipFree(d_o);
+
+	// quadtbl_tb.cpp:146-177
+	double mxerr = 0.0;
+	int imxv = 0, imnv = 0;
+	for (size_t i = 0; i < n; i++) {
+		double ph = (double)(int)pdata[i];
+		ph = ph * M_PI * 2.0 / (double)(1ul << PW);
+		const double scl = ((1 << (OW - 1)) - 1);
+		const double dsin = sin(ph) * scl;
+		const double err = fabs(dsin - sdata[i]);
+		if (err > mxerr) mxerr = err;
+		if (sdata[i] > imxv) imxv = sdata[i];
+		else if (sdata[i] < imnv) imnv = sdata[i];
+	}
+	printf("MXERR: %f (Expected %f)\n", mxerr, qc.tbl_err);
+	const bool failed = fabs(mxerr) > fabs(qc.tbl_err) + 2.;
+	printf("MXVAL: 0x%08x\n", imxv);
+	printf("MNVAL: 0x%08x\n", imnv);
+	if (failed) { printf("TEST FAILURE\n"); return EXIT_FAILURE; }
+
+	// quadtbl_tb.cpp:182-211
+	if (PW < 26 && n == ((size_t)1 << PW)) {
+		std::vector<std::complex<double>> o(n);
+		for (size_t k = 0; k < n; k++)
+			o[k] = std::complex<double>(sdata[(k + n / 4) & (n - 1)], sdata[k]);
+		fft(o);
+		const double master = std::norm(o[1]);
+		double spur = std::norm(o[0]);
+		for (size_t k = 2; k < n; k++)
+			if (std::norm(o[k]) > spur) spur = std::norm(o[k]);
+		printf("SFDR = %7.2f dBc\n", 10 * log(master / spur) / log(10.));
+	} else if (PW >= 26)
+		printf("Too many phase bits ... skipping SFDR calculation\n");
+	printf("SUCCESS!!\n");
+	return EXIT_SUCCESS;
+}
+
 int main(int argc, char **argv)
 {
+	for (int k = 1; k + 1 < argc; k++)
+		if (!strcmp(argv[k], "-t") && !strcmp(argv[k + 1], "qtbl"))
+			return run_qtbl(argc, argv);
 	cordic_config cfg;
 	char fname[256];
 	int hdr = 0;
