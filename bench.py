@@ -122,6 +122,16 @@ def _cpu_model():
     return "unknown"
 
 
+def _pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json), or None if that workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def bench_table(args, w, ca, dist, dev, world, rank):
     """Table cores (row F4): same timing discipline, gather kernel."""
     import oracle_lib as O
@@ -189,7 +199,8 @@ def bench_table(args, w, ca, dist, dev, world, rank):
                        "input": args.input, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": _pmc_traffic(args.workload),
                          "bytes_per_sample": w["bytes"],
                          "kernel_ms_avg": avg * 1e3},
             "bit_exact_vs_oracle": ok}))
@@ -415,15 +426,8 @@ def main():
         total = float(world) * n * args.steps
         value = total / elapsed / 1e6
         achieved = w["bytes"] * n / kern_avg_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                key = args.workload + ("_noseed" if args.no_seed else "")
-                traffic = json.load(open(pmc)).get(key, {}).get(
-                    "hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+        traffic = _pmc_traffic(args.workload
+                               + ("_noseed" if args.no_seed else ""))
         out = {
             "metric": "Msamples/sec (sin+cos pairs) at 16-stage/32-bit"
                       if args.workload == "cfg2" else
