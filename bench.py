@@ -122,6 +122,26 @@ def _cpu_model():
     return "unknown"
 
 
+def _pmc_valu(key, samples_per_launch, samples_per_s):
+    """VALU instructions per sample (rocprofv3 SQ_INSTS_VALU of
+    the committed PMC pass, x64 lanes, / samples per launch) and the lane-op
+    rate that implies at the measured sample rate, against the nominal
+    256 CU x 64 lanes x 2.4 GHz = 39.3e12 lane-ops/s.  (gfx950 issues the
+    full-rate integer ops faster than one wave per 4 cycles --
+    profiles/valu_microbench_r01.txt measures 58-65e12 lane-ops/s for
+    add/xor/shift and 37e12 for the half-rate ops -- so the fraction of the
+    nominal figure can exceed 1.)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            e = json.load(f).get(key, {})
+        per_sample = e["SQ_INSTS_VALU"] * 64.0 / samples_per_launch
+    except (OSError, ValueError, KeyError):
+        return None
+    return {"valu_instr_per_sample": per_sample,
+            "lane_ops_per_s": per_sample * samples_per_s,
+            "frac_of_nominal_39e12": per_sample * samples_per_s / 39.3e12}
+
+
 def _pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json), or None if that workload was not profiled."""
@@ -473,6 +493,9 @@ def main():
                              and not args.generic) else
                          "integer-VALU bound, not HBM bound: DESIGN.md 4.5"),
             },
+            "valu": _pmc_valu(args.workload
+                              + ("_noseed" if args.no_seed else ""),
+                              1 << 30, n / kern_avg_s),
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,
         }

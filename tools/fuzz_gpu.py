@@ -60,3 +60,108 @@ for t in range(ncfg):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (t, "r2p")
     done += 1
 print("fuzz ok: %d cores checked, %d refused by both; paths %s" % (done, refused, paths))
+
+# ---- second part: the options around the path, on random cores ------------
+import torch  # noqa: E402
+from stream_model import PipeModel  # noqa: E402
+from test_stream import _gpu_run  # noqa: E402
+
+DEV = "cuda:0"
+extra = {"unit_gain": 0, "io16": 0, "quad": 0, "quad_refused": 0, "stream": 0}
+
+for t in range(max(ncfg // 4, 20)):
+    # unit gain on a random (accepted) core
+    mode = int(rng.randint(4))
+    iw, ow = int(rng.randint(2, 33)), int(rng.randint(2, 33))
+    xtra, pw, ns = int(rng.randint(0, 6)), int(rng.randint(6, 33)), int(rng.randint(2, 41))
+    try:
+        cfg = ca.Config.from_cli(mode, iw, ow, xtra, pw, ns)
+    except ca.CordicError:
+        continue
+    ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
+    ug = cfg.with_flags(ca.FLAG_UNIT_GAIN)
+    k = ca.lib().cordic_config_gain_annihilator(ug.ref)
+    n = int(rng.choice([5, 1024, 4099]))
+    x, y, ph = rand_inputs(rng, iw, pw, n)
+
+    def sc(a):
+        return ((a.astype(np.int64) * k) >> 32).astype(np.int32)
+    if mode in (ca.P2R, ca.SP2R):
+        a = gpu_p2r(ug, x, y, ph)
+        b = O.rotate(ocfg, x, y, ph)
+        assert np.array_equal(a[0], sc(b[0])) and np.array_equal(a[1], sc(b[1])), (t, "ug")
+        plan = ca.Plan(ug)
+        a = gpu_plan_p2r(plan, int(x[1]), int(y[2]), ph)
+        b = O.rotate(ocfg, int(x[1]), int(y[2]), ph)
+        assert np.array_equal(a[0], sc(b[0])) and np.array_equal(a[1], sc(b[1])), (t, "ugplan")
+    else:
+        a = gpu_r2p(ug, x, y)
+        b = O.topolar(ocfg, x, y)
+        assert np.array_equal(a[0], sc(b[0])) and np.array_equal(a[1], b[1]), (t, "ugr2p")
+    extra["unit_gain"] += 1
+
+    # 16-bit containers
+    if iw <= 16 and ow <= 16 and pw <= 16:
+        def d16(a):
+            return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)
+                                    .astype(np.uint16).view(np.int16)).to(DEV)
+        o0 = torch.zeros(n, dtype=torch.int16, device=DEV)
+        o1 = torch.zeros(n, dtype=torch.int16, device=DEV)
+        if mode in (ca.P2R, ca.SP2R):
+            ca.p2r(cfg, d16(x), d16(y), d16(ph), o0, o1, n=n)
+            b = O.rotate(ocfg, x, y, ph)
+            torch.cuda.synchronize()
+            assert np.array_equal(o0.cpu().numpy(), b[0].astype(np.int16)), (t, "io16")
+            assert np.array_equal(o1.cpu().numpy(), b[1].astype(np.int16)), (t, "io16")
+        else:
+            ca.r2p(cfg, d16(x), d16(y), o0, o1, n=n)
+            b = O.topolar(ocfg, x, y)
+            torch.cuda.synchronize()
+            assert np.array_equal(o0.cpu().numpy(), b[0].astype(np.int16)), (t, "io16")
+            assert np.array_equal(o1.cpu().numpy().view(np.uint16),
+                                  b[1].astype(np.uint16)), (t, "io16")
+        extra["io16"] += 1
+
+    # clocked view on the pipelined cores
+    if mode in (ca.P2R, ca.R2P) and t % 3 == 0:
+        rot = mode == ca.P2R
+        nn = 3000
+        lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+        sx, sy = rng.randint(lo, hi, nn), rng.randint(lo, hi, nn)
+        sp = rng.randint(0, 1 << cfg.pw, nn, dtype=np.int64)
+        ce = (rng.randint(0, 3, nn) != 0).astype(np.uint8)
+        rs = (rng.randint(0, 400, nn) == 0).astype(np.uint8)
+        ax = rng.randint(0, 2, nn).astype(np.uint8)
+        s = ca.Stream(cfg)
+        r = _gpu_run(s, rot, sx, sy, sp, ce, rs, ax, [7, 1000, 1001, 2500])
+        m = PipeModel(ocfg, rot).run(sx, sy, sp, ce, rs, ax)
+        assert all(np.array_equal(a, b) for a, b in zip(r, m)), (t, "stream")
+        s.close()
+        extra["stream"] += 1
+
+for t in range(max(ncfg // 8, 20)):
+    ow, xtra = int(rng.randint(3, 29)), int(rng.randint(0, 5))
+    pw = int(rng.choice([-1, int(rng.randint(6, 33))]))
+    try:
+        q = ca.Quad(-1, ow, xtra, pw)
+    except ca.CordicError:
+        try:
+            O.quad_cli(-1, ow, xtra, pw)
+            raise SystemExit("oracle accepts a quadtbl core the product refuses: %r"
+                             % ((ow, xtra, pw),))
+        except ValueError:
+            extra["quad_refused"] += 1
+            continue
+    oq = O.quad_cli(-1, ow, xtra, pw)
+    ot = O.quad_tables(oq)
+    assert all(np.array_equal(a, b) for a, b in zip(q.tables(), ot)), (t, "quadtables")
+    n = 20000
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    d = torch.from_numpy(ph.view(np.int32)).to(DEV)
+    o = torch.empty_like(d)
+    q.lookup(d, o)
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), O.quad_lookup(oq, ot, ph)), (t, "quad", ow, xtra, pw)
+    q.close()
+    extra["quad"] += 1
+print("fuzz ok (options):", extra)
