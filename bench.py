@@ -122,6 +122,78 @@ def _cpu_model():
     return "unknown"
 
 
+def other_paths(ca, dev, log2n=29, steps=8):
+    """Rates of the other entry points of the engine on this GPU (single-GPU
+    default run only; informational, not `value`): 2^log2n samples, HIP events
+    over `steps` launches after four warm-up launches, results spot-checked against the
+    oracle.  Keys are bench.py workload names."""
+    import oracle_lib as O
+    n = 1 << log2n
+    res = {}
+
+    def timed(fn):
+        for _ in range(4):      # the GPU idled during cpu_baseline: re-clock
+            fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    idx = torch.arange(0, n, 65521, device=dev)
+
+    def i32(k=1):
+        return [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(k)]
+
+    # cfg3: r2p 20 stages on I/Q ramps
+    cfg = ca.Config.from_cli(1, 24, 24, 2, -1, 20)
+    xin, yin, a, b = i32(4)
+    ca.fill_iq_ramp(xin, yin, 0, 0x9E3779B1, 0x85EBCA77, 24)
+    ms = timed(lambda: ca.r2p(cfg, xin, yin, a, b))
+    rm, rp = O.topolar(O.config_cli(1, 24, 24, 2, -1, 20),
+                       xin[idx].cpu().numpy(), yin[idx].cpu().numpy())
+    ok = bool(np.array_equal(a[idx].cpu().numpy(), rm) and np.array_equal(
+        b[idx].cpu().numpy().view(np.uint32), rp))
+    res["cfg3"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 16,
+                   "bit_exact_vs_oracle": ok}
+    # p2rxy: per-sample x, y and phase
+    cfg = ca.Config.from_cli(0, 32, 32, 2, 32, 16)
+    ocfg = O.config_cli(0, 32, 32, 2, 32, 16)
+    ph = i32()[0]
+    ca.fill_phase_ramp(ph, 0, 2)
+    ca.fill_iq_ramp(xin, yin, 0, 0x9E3779B1, 0x85EBCA77, 32)
+    ms = timed(lambda: ca.p2r(cfg, xin, yin, ph, a, b))
+    rx, ry = O.rotate(ocfg, xin[idx].cpu().numpy(), yin[idx].cpu().numpy(),
+                      ph[idx].cpu().numpy().view(np.uint32))
+    ok = bool(np.array_equal(a[idx].cpu().numpy(), rx)
+              and np.array_equal(b[idx].cpu().numpy(), ry))
+    res["p2rxy"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 20,
+                    "bit_exact_vs_oracle": ok}
+    # cfg5: fused NCO, store only
+    plan = ca.Plan(cfg)
+    ms = timed(lambda: plan.nco(n, 0, 0x01234567, 0, 2**31 - 1, 0, a, b))
+    pn = ((idx.cpu().numpy().astype(np.uint64) * np.uint64(0x01234567))
+          & np.uint64(0xffffffff)).astype(np.uint32)
+    rx, ry = O.rotate(ocfg, 2**31 - 1, 0, pn)
+    ok = bool(np.array_equal(a[idx].cpu().numpy(), rx)
+              and np.array_equal(b[idx].cpu().numpy(), ry))
+    res["cfg5"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 8,
+                   "bit_exact_vs_oracle": ok}
+    # quadtbl: the checked-in quadratic-interpolation core
+    quad = ca.Quad(-1, 13, 2, 18)
+    ms = timed(lambda: quad.lookup(ph, a))
+    oq = O.quad_cli(-1, 13, 2, 18)
+    ok = bool(np.array_equal(a[idx].cpu().numpy(), O.quad_lookup(
+        oq, O.quad_tables(oq), ph[idx].cpu().numpy().view(np.uint32))))
+    res["quadtbl"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 8,
+                      "bit_exact_vs_oracle": ok}
+    return res
+
+
 def _pmc_valu(key, samples_per_launch, samples_per_s):
     """VALU instructions per sample (rocprofv3 SQ_INSTS_VALU of
     the committed PMC pass, x64 lanes, / samples per launch) and the lane-op
@@ -236,6 +308,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-other-paths", action="store_true",
+                    help="skip the informational rates of the other entry "
+                    "points after the default (cfg2) run")
     ap.add_argument("--log2-samples", type=int, default=30,
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -505,6 +580,10 @@ def main():
             out["gather_ms"] = gather_ms
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+        if world == 1 and args.workload == "cfg2" and not args.no_other_paths:
+            del a, b, phase
+            torch.cuda.empty_cache()
+            out["other_paths"] = other_paths(ca, dev)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
