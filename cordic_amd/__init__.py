@@ -16,7 +16,7 @@ from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
     FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_UNIT_GAIN,
     ERR_ARGS, ERR_DEVICE, ERR_CONTAINER,
-    Config, CordicError, Plan, Table, TBL, QTR, Quad, Stream, seed_table,
+    Config, CordicError, Plan, Table, TBL, QTR, Quad, Stream, Seq, seed_table,
     lib, lib_path,
     p2r, p2r_const, nco, r2p,
     p2r_host, r2p_host,
@@ -25,7 +25,7 @@ from ._native import (  # noqa: F401
 
 __all__ = [
     "P2R", "R2P", "SP2R", "SR2P", "Config", "CordicError", "Plan",
-    "seed_table", "Table", "TBL", "QTR", "Quad", "Stream", "lib", "lib_path",
+    "seed_table", "Table", "TBL", "QTR", "Quad", "Stream", "Seq", "lib", "lib_path",
     "p2r", "p2r_const", "nco", "r2p", "p2r_host", "r2p_host",
     "fill_phase_ramp", "fill_iq_ramp", "digest_u32",
 ]

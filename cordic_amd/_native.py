@@ -118,6 +118,13 @@ ABI = {
     "cordic_stream_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_stream_ticks": (C.c_int, [C.c_void_p, C.c_size_t] +
                             [C.c_void_p] * 10),
+    "cordic_seq_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
+    "cordic_seq_destroy": (None, [C.c_void_p]),
+    "cordic_seq_workspace": (C.c_size_t, [C.c_size_t]),
+    "cordic_seq_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "cordic_seq_ticks": (C.c_int, [C.c_void_p, C.c_size_t] +
+                         [C.c_void_p] * 12),
+    "cordic_seq_violations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cordic_quad_config_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_int]),
     "cordic_quad_config_init_core": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
@@ -457,6 +464,43 @@ class Stream:
     def close(self):
         if self._h:
             lib().cordic_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Seq:
+    """cordic_seq: a sequential core (sp2r / sr2p) behind its i_stb / o_busy /
+    o_done handshake, stepped in blocks of clocks."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(lib().cordic_seq_create(cfg.ref, C.byref(h)), "cordic_seq_create")
+        self._h = h
+
+    def ticks(self, stb, x, y, phase, out0, out1, busy=None, done=None,
+              oaux=None, reset=None, aux=None, n=None, stream=None):
+        n = stb.numel() if n is None else n
+        _check(lib().cordic_seq_ticks(
+            self._h, n, _ptr(stb), _ptr(reset), _ptr(aux), _ptr(x), _ptr(y),
+            _ptr(phase), _ptr(out0), _ptr(out1), _ptr(busy), _ptr(done),
+            _ptr(oaux), _stream(stream)), "cordic_seq_ticks")
+
+    @property
+    def violations(self):
+        v = C.c_uint64()
+        _check(lib().cordic_seq_violations(self._h, C.byref(v)),
+               "cordic_seq_violations")
+        return v.value
+
+    def close(self):
+        if self._h:
+            lib().cordic_seq_destroy(self._h)
             self._h = None
 
     def __del__(self):

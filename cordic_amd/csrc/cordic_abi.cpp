@@ -477,6 +477,105 @@ int cordic_stream_ticks(cordic_stream *s, size_t ticks, const uint8_t *d_ce,
 			d_xval, d_yval, d_phase, d_out0, d_out1, d_oaux, stream);
 }
 
+// ------------------------------------- handshake view, sequential cores
+struct cordic_seq {
+	cordic_config cfg;
+	SeqState st;
+};
+
+void cordic_seq_destroy(cordic_seq *s)
+{
+	if (!s)
+		return;
+	SeqState &t = s->st;
+	for (int k = 0; k < 2; k++) {
+		void *ptrs[] = { t.c[k], t.px[k], t.py[k], t.pph[k], t.paux[k],
+				 t.l0[k], t.l1[k], t.la[k] };
+		for (void *p : ptrs)
+			if (p) (void)hipFree(p);
+	}
+	if (t.violations) (void)hipFree(t.violations);
+	if (t.ws) (void)hipFree(t.ws);
+	delete s;
+}
+
+int cordic_seq_create(const cordic_config *cfg, cordic_seq **out)
+{
+	if (!cfg || !out)
+		return CORDIC_ERR_ARGS;
+	if (cfg->mode != CORDIC_SP2R && cfg->mode != CORDIC_SR2P)
+		return CORDIC_ERR_MODE;
+	cordic_seq *s = new (std::nothrow) cordic_seq;
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	s->cfg = *cfg;
+	SeqState &t = s->st;
+	auto zalloc = [](auto **p, size_t bytes) {
+		return hipMalloc((void **)p, bytes) == hipSuccess
+			&& hipMemset(*p, 0, bytes) == hipSuccess;
+	};
+	bool ok = zalloc(&t.violations, 8);
+	for (int k = 0; k < 2 && ok; k++)
+		ok = zalloc(&t.c[k], 4) && zalloc(&t.px[k], 4) && zalloc(&t.py[k], 4)
+			&& zalloc(&t.pph[k], 4) && zalloc(&t.paux[k], 4)
+			&& zalloc(&t.l0[k], 4) && zalloc(&t.l1[k], 4)
+			&& zalloc(&t.la[k], 4);
+	if (!ok) {
+		cordic_seq_destroy(s);
+		return CORDIC_ERR_DEVICE;
+	}
+	*out = s;
+	return CORDIC_OK;
+}
+
+size_t cordic_seq_workspace(size_t ticks) { return seq_workspace_bytes(ticks); }
+
+int cordic_seq_reserve(cordic_seq *s, size_t max_ticks)
+{
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	const size_t need = seq_workspace_bytes(max_ticks);
+	if (need <= s->st.ws_bytes)
+		return CORDIC_OK;
+	if (hipDeviceSynchronize() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	if (s->st.ws) (void)hipFree(s->st.ws);
+	s->st.ws = nullptr;
+	s->st.ws_bytes = 0;
+	if (hipMalloc(&s->st.ws, need) != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	s->st.ws_bytes = need;
+	return CORDIC_OK;
+}
+
+int cordic_seq_ticks(cordic_seq *s, size_t ticks, const uint8_t *d_stb,
+		const uint8_t *d_reset, const uint8_t *d_aux, const int32_t *d_xval,
+		const int32_t *d_yval, const uint32_t *d_phase, int32_t *d_out0,
+		int32_t *d_out1, uint8_t *d_busy, uint8_t *d_done, uint8_t *d_oaux,
+		void *stream)
+{
+	if (!s)
+		return CORDIC_ERR_ARGS;
+	if (int rc = cordic_seq_reserve(s, ticks))
+		return rc;
+	return launch_seq_ticks(s->cfg, s->st, ticks, d_stb, d_reset, d_aux, d_xval,
+			d_yval, d_phase, d_out0, d_out1, d_busy, d_done, d_oaux,
+			stream);
+}
+
+int cordic_seq_violations(cordic_seq *s, uint64_t *count)
+{
+	if (!s || !count)
+		return CORDIC_ERR_ARGS;
+	unsigned long long v = 0;
+	if (hipDeviceSynchronize() != hipSuccess
+			|| hipMemcpy(&v, s->st.violations, 8, hipMemcpyDeviceToHost)
+				!= hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	*count = v;
+	return CORDIC_OK;
+}
+
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
 {
 	if (!cfg)

@@ -108,6 +108,27 @@ int	launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 		const uint8_t *ce, const uint8_t *reset, const uint8_t *aux,
 		const int32_t *x, const int32_t *y, const uint32_t *phase,
 		int32_t *o0, int32_t *o1, uint8_t *oaux, void *stream);
+// handshake view of the sequential cores: cordic_stream.hip
+struct SeqState {
+	void	*ws = nullptr;
+	size_t	ws_bytes = 0;
+	// device-resident, double buffered: clocks left until the sample in
+	// flight loads (0 = idle), that sample, and the output registers
+	uint32_t *c[2] = {nullptr, nullptr};
+	int32_t	 *px[2] = {nullptr, nullptr}, *py[2] = {nullptr, nullptr};
+	uint32_t *pph[2] = {nullptr, nullptr};
+	uint8_t	 *paux[2] = {nullptr, nullptr};
+	int32_t	 *l0[2] = {nullptr, nullptr}, *l1[2] = {nullptr, nullptr};
+	uint8_t	 *la[2] = {nullptr, nullptr};
+	unsigned long long *violations = nullptr;
+	int	cur = 0;
+};
+size_t	seq_workspace_bytes(size_t ticks);
+int	launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
+		const uint8_t *stb, const uint8_t *reset, const uint8_t *aux,
+		const int32_t *x, const int32_t *y, const uint32_t *phase,
+		int32_t *o0, int32_t *o1, uint8_t *busy, uint8_t *done,
+		uint8_t *oaux, void *stream);
 int	launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream);
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,

@@ -426,4 +426,301 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 
+
+// ===================================================== sequential cores
+//
+// rtl/seqcordic.v:226-327 / rtl/seqpolar.v:211-307: the i_stb / o_busy /
+// o_done handshake, as a bench that keeps to the protocol sees it.  With
+// C = CLOCKS_PER_OUTPUT and c = clocks left until the result registers load
+// (0 = idle), one clock is
+//     load   = (c == 1)                 o_xval/o_yval/o_aux load, reset or not
+//     reset  : c' = 0
+//     idle   : i_stb ? accept, c' = C-1 : c' = 0
+//     busy   : c' = c-1, o_done = load; i_stb ignored -- except ON the load
+//              clock, where the RTL keeps `idle` low and runs its datapath
+//              again over its own result: counted as a violation, not
+//              reproduced
+//     o_busy = (c' != 0)
+// a finite-state machine over the clock stream.  It is run in three passes:
+// every tile of clocks is simulated from each of the <= 67 possible entry
+// states (one thread each), a single wave chains the tiles' entry states, and
+// one thread per tile replays its tile from the true entry state writing the
+// per-clock flags.  From there on the data path is the pipelined cores': scan
+// the accept / load flags, gather the sample behind every clock's output
+// registers, run the core's batch kernel, patch in the values carried from
+// earlier calls.  Pinned by tests/golden/seq_traces.json (vsim.py traces of
+// the emitted RTL).
+namespace {
+
+constexpr int kFsmTile = 1024;		// clocks per tile
+constexpr int kFsmStates = 72;		// >= max CLOCKS_PER_OUTPUT (64 + 3)
+enum : uint32_t { EV_ACCEPT = 1, EV_LOAD = 2, EV_DONE = 4, EV_BUSY = 8, EV_VIOL = 16 };
+
+__device__ __forceinline__ uint32_t fsm_step(uint32_t &c, bool stb, bool rst,
+		uint32_t C)
+{
+	uint32_t ev = 0;
+	const bool completing = (c == 1);
+	if (completing)
+		ev |= EV_LOAD;
+	if (rst) {
+		c = 0;
+	} else if (c == 0) {
+		if (stb) {
+			c = C - 1;
+			ev |= EV_ACCEPT;
+		}
+	} else {
+		if (completing)
+			ev |= EV_DONE | (stb ? EV_VIOL : 0u);
+		c -= 1;
+	}
+	if (c != 0)
+		ev |= EV_BUSY;
+	return ev;
+}
+
+// pass 1: exit state of every tile for every entry state
+__global__ __launch_bounds__(128) void seq_fsm_tables(const uint8_t *stb,
+		const uint8_t *rst, uint32_t T, uint32_t C, uint8_t *gtab)
+{
+	const uint32_t tile = blockIdx.x;
+	if (threadIdx.x >= C)
+		return;
+	uint32_t c = threadIdx.x;
+	const uint32_t lo = tile * kFsmTile;
+	const uint32_t hi = (lo + kFsmTile < T) ? lo + kFsmTile : T;
+	for (uint32_t t = lo; t < hi; t++)
+		(void)fsm_step(c, stb[t] != 0, rst && rst[t] != 0, C);
+	gtab[(size_t)tile * kFsmStates + threadIdx.x] = (uint8_t)c;
+}
+
+// pass 2 (one wave): entry state of every tile; entry[ntiles] = exit state
+__global__ __launch_bounds__(64) void seq_fsm_spine(const uint8_t *gtab,
+		uint32_t ntiles, const uint32_t *c_in, uint8_t *entry,
+		uint32_t *c_out)
+{
+	__shared__ uint8_t chunk[64 * kFsmStates];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0)
+		carry = *c_in;
+	__syncthreads();
+	for (uint32_t base = 0; base < ntiles; base += 64) {
+		const uint32_t cnt = (ntiles - base < 64) ? ntiles - base : 64;
+		for (uint32_t i = threadIdx.x; i < cnt * kFsmStates; i += 64)
+			chunk[i] = gtab[(size_t)base * kFsmStates + i];
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t c = carry;
+			for (uint32_t k = 0; k < cnt; k++) {
+				entry[base + k] = (uint8_t)c;
+				c = chunk[k * kFsmStates + c];
+			}
+			carry = c;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		entry[ntiles] = (uint8_t)carry;
+		*c_out = carry;
+	}
+}
+
+// pass 3: per-clock flags from the true entry states
+__global__ __launch_bounds__(64) void seq_fsm_emit(const uint8_t *stb,
+		const uint8_t *rst, uint32_t T, uint32_t C, const uint8_t *entry,
+		uint32_t ntiles, uint8_t *accept, uint8_t *load, uint8_t *busy,
+		uint8_t *done, unsigned long long *violations)
+{
+	const uint32_t tile = blockIdx.x * 64 + threadIdx.x;
+	if (tile >= ntiles)
+		return;
+	uint32_t c = entry[tile];
+	const uint32_t lo = tile * kFsmTile;
+	const uint32_t hi = (lo + kFsmTile < T) ? lo + kFsmTile : T;
+	uint32_t viol = 0;
+	for (uint32_t t = lo; t < hi; t++) {
+		const uint32_t ev = fsm_step(c, stb[t] != 0, rst && rst[t] != 0, C);
+		accept[t] = (ev & EV_ACCEPT) ? 1 : 0;
+		load[t] = (ev & EV_LOAD) ? 1 : 0;
+		if (busy) busy[t] = (ev & EV_BUSY) ? 1 : 0;
+		if (done) done[t] = (ev & EV_DONE) ? 1 : 0;
+		viol += (ev & EV_VIOL) ? 1u : 0u;
+	}
+	if (viol)
+		atomicAdd(violations, (unsigned long long)viol);
+}
+
+struct SeqView {
+	const int32_t *x, *y;
+	const uint32_t *phase;		// NULL for seqpolar
+	const uint8_t *aux;
+	const int32_t *px, *py;		// sample in flight when the block starts
+	const uint32_t *pph;
+	const uint8_t *paux;
+	const uint32_t *A;		// accepts in [0, t]
+	const int32_t *R;		// last load clock <= t, or -1
+	const uint32_t *pos;		// clock of the k-th accept
+	uint32_t T;
+};
+
+// the sample whose result the output registers hold after clock t
+__global__ __launch_bounds__(kBlock) void seq_gather(SeqView v, int32_t *gx,
+		int32_t *gy, uint32_t *gph, uint8_t *held, uint8_t *oaux)
+{
+	const uint32_t stride = gridDim.x * kBlock;
+	for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < v.T; t += stride) {
+		const int32_t r = v.R[t];
+		int32_t x = 0, y = 0;
+		uint32_t ph = 0;
+		uint8_t ax = 0, h = 1;
+		if (r >= 0) {
+			h = 0;
+			const uint32_t k = v.A[r];	// accepts before the load
+			if (k == 0) {
+				x = *v.px; y = *v.py; ph = *v.pph; ax = *v.paux;
+			} else {
+				const uint32_t s = v.pos[k - 1];
+				x = v.x[s]; y = v.y[s];
+				ph = v.phase ? v.phase[s] : 0u;
+				ax = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
+			}
+		}
+		gx[t] = x; gy[t] = y;
+		if (gph) gph[t] = ph;
+		held[t] = h;
+		oaux[t] = ax;
+	}
+}
+
+// clocks before the first load of this block: the registers still hold what
+// the previous call left in them
+__global__ __launch_bounds__(kBlock) void seq_fix_held(uint32_t T,
+		const uint8_t *held, const int32_t *l0, const int32_t *l1,
+		const uint8_t *la, int32_t *o0, int32_t *o1, uint8_t *oaux)
+{
+	const uint32_t stride = gridDim.x * kBlock;
+	for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < T; t += stride)
+		if (held[t]) {
+			o0[t] = *l0; o1[t] = *l1; oaux[t] = *la;
+		}
+}
+
+__global__ void seq_carry(SeqView v, const int32_t *o0, const int32_t *o1,
+		const uint8_t *oaux, int32_t *npx, int32_t *npy, uint32_t *npph,
+		uint8_t *npaux, int32_t *nl0, int32_t *nl1, uint8_t *nla)
+{
+	const uint32_t acc = v.A[v.T - 1];
+	if (acc == 0) {
+		*npx = *v.px; *npy = *v.py; *npph = *v.pph; *npaux = *v.paux;
+	} else {
+		const uint32_t s = v.pos[acc - 1];
+		*npx = v.x[s]; *npy = v.y[s];
+		*npph = v.phase ? v.phase[s] : 0u;
+		*npaux = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
+	}
+	*nl0 = o0[v.T - 1]; *nl1 = o1[v.T - 1]; *nla = oaux[v.T - 1];
+}
+
+} // namespace
+
+size_t seq_workspace_bytes(size_t T)
+{
+	const size_t ntiles = (T + kFsmTile - 1) / kFsmTile;
+	const size_t stiles = (T + kScanTile - 1) / kScanTile;
+	// accept, load, held, oaux (1 byte each), A, R, pos, gx, gy, gph (4 each),
+	// FSM tables and entry states, scan tile arrays
+	return T * 28 + ntiles * (kFsmStates + 1) + stiles * 8 + 512;
+}
+
+int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
+		const uint8_t *stb, const uint8_t *reset, const uint8_t *aux,
+		const int32_t *x, const int32_t *y, const uint32_t *phase,
+		int32_t *o0, int32_t *o1, uint8_t *busy, uint8_t *done,
+		uint8_t *oaux, void *stream)
+{
+	(void)hipGetLastError();
+	if (T == 0)
+		return CORDIC_OK;
+	if (T >= (1ull << 31))
+		return CORDIC_ERR_ARGS;
+	const bool rot = (cfg.mode == CORDIC_SP2R);
+	if (!rot && cfg.mode != CORDIC_SR2P)
+		return CORDIC_ERR_MODE;
+	if (!stb || !x || !y || !o0 || !o1 || (rot && !phase))
+		return CORDIC_ERR_ARGS;
+	const uint32_t C = (uint32_t)cfg.clocks_per_output;
+	if (C < 2 || C > (uint32_t)kFsmStates)
+		return CORDIC_ERR_UNSUPPORTED;
+	if (seq_workspace_bytes(T) > s.ws_bytes)
+		return CORDIC_ERR_ARGS;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const uint32_t n = (uint32_t)T;
+	const uint32_t ntiles = (n + kFsmTile - 1) / kFsmTile;
+	const uint32_t stiles = (n + kScanTile - 1) / kScanTile;
+
+	char *w = static_cast<char *>(s.ws);
+	auto take = [&](size_t bytes) {
+		char *p = w;
+		w += (bytes + 15) & ~(size_t)15;
+		return p;
+	};
+	int32_t *gx = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+	int32_t *gy = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+	uint32_t *gph = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+	uint32_t *A = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+	int32_t *R = reinterpret_cast<int32_t *>(take((size_t)n * 4));
+	uint32_t *pos = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+	uint8_t *accept = reinterpret_cast<uint8_t *>(take(n));
+	uint8_t *load = reinterpret_cast<uint8_t *>(take(n));
+	uint8_t *held = reinterpret_cast<uint8_t *>(take(n));
+	uint8_t *aux_ws = reinterpret_cast<uint8_t *>(take(n));
+	uint8_t *gtab = reinterpret_cast<uint8_t *>(take((size_t)ntiles * kFsmStates));
+	uint8_t *entry = reinterpret_cast<uint8_t *>(take((size_t)ntiles + 1));
+	uint32_t *tile_adv = reinterpret_cast<uint32_t *>(take((size_t)stiles * 4));
+	int32_t *tile_last = reinterpret_cast<int32_t *>(take((size_t)stiles * 4));
+	uint8_t *oa = oaux ? oaux : aux_ws;
+
+	const int cur = s.cur, nxt = cur ^ 1;
+	hipLaunchKernelGGL(seq_fsm_tables, dim3(ntiles), dim3(128), 0, st, stb,
+			reset, n, C, gtab);
+	hipLaunchKernelGGL(seq_fsm_spine, dim3(1), dim3(64), 0, st, gtab, ntiles,
+			s.c[cur], entry, s.c[nxt]);
+	hipLaunchKernelGGL(seq_fsm_emit, dim3((ntiles + 63) / 64), dim3(64), 0, st,
+			stb, reset, n, C, entry, ntiles, accept, load, busy, done,
+			s.violations);
+	TickFlags f{accept, load};	// "advancing" = accept, "reset" = load
+	hipLaunchKernelGGL(stream_tile_totals, dim3(stiles), dim3(kScanThreads), 0,
+			st, f, n, tile_adv, tile_last);
+	hipLaunchKernelGGL(stream_tile_spine, dim3(1), dim3(kScanThreads), 0, st,
+			tile_adv, tile_last, stiles);
+	hipLaunchKernelGGL(stream_tile_apply, dim3(stiles), dim3(kScanThreads), 0,
+			st, f, n, tile_adv, tile_last, A, R, pos);
+	SeqView v{x, y, rot ? phase : nullptr, aux, s.px[cur], s.py[cur],
+			s.pph[cur], s.paux[cur], A, R, pos, n};
+	hipLaunchKernelGGL(seq_gather, dim3(grid_1d(n)), dim3(kBlock), 0, st, v, gx,
+			gy, rot ? gph : nullptr, held, oa);
+	if (hipGetLastError() != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	int rc;
+	if (rot) {
+		RotatorJob j;
+		j.x = gx; j.y = gy; j.phase = gph;
+		j.ox = o0; j.oy = o1; j.n = n;
+		rc = launch_rotator(cfg, Feed::PhaseArray_XYArray, j, stream);
+	} else {
+		rc = launch_topolar(cfg, n, gx, gy, o0, reinterpret_cast<uint32_t *>(o1),
+				stream);
+	}
+	if (rc != CORDIC_OK)
+		return rc;
+	hipLaunchKernelGGL(seq_fix_held, dim3(grid_1d(n)), dim3(kBlock), 0, st, n,
+			held, s.l0[cur], s.l1[cur], s.la[cur], o0, o1, oa);
+	hipLaunchKernelGGL(seq_carry, dim3(1), dim3(1), 0, st, v, o0, o1, oa,
+			s.px[nxt], s.py[nxt], s.pph[nxt], s.paux[nxt], s.l0[nxt],
+			s.l1[nxt], s.la[nxt]);
+	s.cur = nxt;
+	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
+}
+
 } // namespace cordic_amd

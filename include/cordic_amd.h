@@ -371,8 +371,7 @@ int	cordic_quad_lookup(const cordic_quad *core, size_t n,
  * and the i_aux -> o_aux delay line (rtl/cordic.v:100-105,118-124,244-252,
  * 304-313; rtl/topolar.v likewise) are reproduced exactly.  State carries
  * over from call to call.  Modes: CORDIC_P2R, CORDIC_R2P (the sequential
- * cores have no i_ce pipeline: use the batch calls, which return their o_done
- * values).
+ * cores have no i_ce pipeline: see cordic_seq_* below).
  *
  *   d_ce, d_reset, d_aux : one byte per clock (non-zero = asserted); NULL
  *                          means i_ce = 1 / i_reset = 0 / i_aux = 0 throughout.
@@ -398,6 +397,34 @@ int	cordic_stream_ticks(cordic_stream *s, size_t ticks,
 		const int32_t *d_xval, const int32_t *d_yval,
 		const uint32_t *d_phase,
 		int32_t *d_out0, int32_t *d_out1, uint8_t *d_oaux, void *stream);
+
+/* The SEQUENTIAL cores' handshake (rtl/seqcordic.v:226-327,
+ * rtl/seqpolar.v:211-307; bench/cpp/cordic_tb.cpp:146-159) in the same
+ * block-of-clocks form.  With C = cfg.clocks_per_output: a sample is taken on
+ * a clock with i_stb while the core is idle; o_busy then reads 1 for C-1
+ * clocks; on the clock C-1 after the accept o_done reads 1 (for that clock
+ * only) and o_xval/o_yval (o_mag/o_phase) and o_aux load; i_reset drops a
+ * sample in flight and clears o_done, the output registers keep their values.
+ * i_stb while busy is ignored, as in the RTL -- except on the very clock that
+ * completes a sample, where the RTL re-runs its datapath over its own result:
+ * such clocks are counted (cordic_seq_violations) and treated as ignored.
+ *   d_stb : one byte per clock (required); d_reset, d_aux, d_busy, d_done,
+ *   d_oaux may be NULL.  p2r: d_phase required, outputs o_xval / o_yval;
+ *   r2p: d_phase NULL, outputs o_mag / o_phase.  Modes CORDIC_SP2R, CORDIC_SR2P.
+ */
+typedef struct cordic_seq cordic_seq;
+int	cordic_seq_create(const cordic_config *cfg, cordic_seq **s);
+void	cordic_seq_destroy(cordic_seq *s);
+size_t	cordic_seq_workspace(size_t ticks);
+int	cordic_seq_reserve(cordic_seq *s, size_t max_ticks);
+int	cordic_seq_ticks(cordic_seq *s, size_t ticks,
+		const uint8_t *d_stb, const uint8_t *d_reset, const uint8_t *d_aux,
+		const int32_t *d_xval, const int32_t *d_yval,
+		const uint32_t *d_phase,
+		int32_t *d_out0, int32_t *d_out1,
+		uint8_t *d_busy, uint8_t *d_done, uint8_t *d_oaux, void *stream);
+/* off-protocol i_stb clocks seen so far (synchronises the device) */
+int	cordic_seq_violations(cordic_seq *s, uint64_t *count);
 
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,

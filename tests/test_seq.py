@@ -1,0 +1,133 @@
+"""Handshake view of the sequential cores (cordic_seq).
+
+tests/golden/seq_traces.json: clock-by-clock port traces of the emitted
+seqcordic / seqpolar RTL (vsim.py) under random i_stb / i_reset / i_aux.  CPU:
+the clock-level model (seq_model.py, on top of the oracle) reproduces them.
+GPU: cordic_seq_ticks reproduces them, fed in blocks of arbitrary length, and
+equals the model on long random traces; off-protocol i_stb is counted."""
+import json
+import os
+import shlex
+
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+from seq_model import SeqModel
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "seq_traces.json")))
+MODE = {"sp2r": ca.SP2R, "sr2p": ca.SR2P}
+KEYS = ("o_busy", "o_done", "o_aux")
+
+
+def configs(args):
+    a = shlex.split(args)
+    get = lambda f, d: int(a[a.index(f) + 1]) if f in a else d  # noqa: E731
+    return (MODE[a[a.index("-t") + 1]], get("-i", -1), get("-o", -1),
+            get("-x", 2), get("-p", -1), get("-n", -1))
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_handshake_model_reproduces_rtl_traces(name):
+    g = GOLD[name]
+    ocfg = O.config_cli(*configs(g["args"]))
+    assert ocfg.clocks_per_output == g["CLOCKS_PER_OUTPUT"]
+    rot = "phase" in g
+    m = SeqModel(ocfg, rot)
+    o0, o1, oa, busy, done = m.run(g["stb"], g["x"], g["y"], g.get("phase"),
+                                   g["reset"], g["aux"])
+    k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+    assert o0.tolist() == g[k0] and o1.tolist() == g[k1]
+    assert oa.tolist() == g["o_aux"]
+    assert busy.tolist() == g["o_busy"] and done.tolist() == g["o_done"]
+    assert m.violations == 0
+
+
+def _gpu_run(seq, rot, stb, x, y, ph, rs, aux, cuts):
+    import torch
+    dev = "cuda:0"
+
+    def d32(a):
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)
+                                .astype(np.uint32).view(np.int32)).to(dev)
+
+    def d8(a):
+        return None if a is None else torch.from_numpy(
+            np.ascontiguousarray(a, dtype=np.uint8)).to(dev)
+    n = len(stb)
+    dx, dy, dph = d32(x), d32(y), (d32(ph) if rot else None)
+    dstb, drs, dax = d8(stb), d8(rs), d8(aux)
+    o0 = torch.zeros(n, dtype=torch.int32, device=dev)
+    o1 = torch.zeros(n, dtype=torch.int32, device=dev)
+    ob, od, oa = (torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(3))
+    edges = [0] + list(cuts) + [n]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b <= a:
+            continue
+        sl = slice(a, b)
+        seq.ticks(dstb[sl], dx[sl], dy[sl], dph[sl] if rot else None, o0[sl],
+                  o1[sl], ob[sl], od[sl], oa[sl],
+                  reset=None if drs is None else drs[sl],
+                  aux=None if dax is None else dax[sl], n=b - a)
+    torch.cuda.synchronize()
+    r1 = o1.cpu().numpy()
+    r1 = r1.astype(np.int64) if rot else r1.view(np.uint32).astype(np.int64)
+    return (o0.cpu().numpy().astype(np.int64), r1, oa.cpu().numpy(),
+            ob.cpu().numpy(), od.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_gpu_seq_reproduces_rtl_traces(name):
+    g = GOLD[name]
+    cfg = ca.Config.from_cli(*configs(g["args"]))
+    rot = "phase" in g
+    k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+    n = len(g["stb"])
+    for cuts in ([], [1, 2, 5, 6, 17, 18, 40, n // 3, n // 3 + 1, n // 2,
+                      n - 20, n - 1]):
+        s = ca.Seq(cfg)
+        r = _gpu_run(s, rot, g["stb"], g["x"], g["y"], g.get("phase"),
+                     g["reset"], g["aux"], cuts)
+        assert r[0].tolist() == g[k0] and r[1].tolist() == g[k1]
+        assert r[2].tolist() == g["o_aux"]
+        assert r[3].tolist() == g["o_busy"] and r[4].tolist() == g["o_done"]
+        assert s.violations == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,iw,ow,pw,ns", [
+    (ca.SP2R, 13, 13, -1, -1), (ca.SR2P, 13, 13, -1, -1),
+    (ca.SP2R, 32, 32, 32, 16), (ca.SR2P, 24, 24, -1, 20)])
+@pytest.mark.parametrize("density", [1.0, 0.2, 0.01])
+def test_gpu_seq_long_random_trace_equals_model(mode, iw, ow, pw, ns, density):
+    cfg = ca.Config.from_cli(mode, iw, ow, 2, pw, ns)
+    ocfg = O.config_cli(mode, iw, ow, 2, pw, ns)
+    rot = mode == ca.SP2R
+    rng = np.random.RandomState(9)
+    n = 30000                   # ~30 FSM tiles, 15 scan tiles
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x, y = rng.randint(lo, hi, n), rng.randint(lo, hi, n)
+    ph = rng.randint(0, 1 << cfg.pw, n, dtype=np.int64)
+    aux = rng.randint(0, 2, n).astype(np.uint8)
+    stb = (rng.rand(n) < density).astype(np.uint8)
+    rs = (rng.randint(0, 2500, n) == 0).astype(np.uint8)
+    cuts = [3, 1024, 1025, 2048 + 7, 15000, 15001, 29990]
+    # off-protocol strobes are ignored and counted, exactly as the model does
+    m = SeqModel(ocfg, rot)
+    want = m.run(stb, x, y, ph, rs, aux)
+    s = ca.Seq(cfg)
+    got = _gpu_run(s, rot, stb, x, y, ph, rs, aux, cuts)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert s.violations == m.violations
+    if density == 1.0:
+        assert m.violations > 0     # back-to-back i_stb hits every load clock
+
+
+@pytest.mark.gpu
+def test_seq_refuses_pipelined_cores():
+    with pytest.raises(ca.CordicError):
+        ca.Seq(ca.Config.from_cli(ca.P2R, 13, 13))
