@@ -54,5 +54,48 @@ def main():
                               "Mclocks_per_s": n / ms / 1e3}))
 
 
+def seq_rate():
+    dev = "cuda:0"
+    n = 1 << 26
+    for name, cli in (("cfg5 sp2r", (ca.SP2R, 32, 32, 2, 32, 16)),
+                      ("seq cfg3 sr2p", (ca.SR2P, 24, 24, 2, -1, 20))):
+        cfg = ca.Config.from_cli(*cli)
+        rot = cli[0] == ca.SP2R
+        g = torch.Generator(device=dev).manual_seed(2)
+        x = torch.empty(n, dtype=torch.int32, device=dev)
+        y = torch.empty(n, dtype=torch.int32, device=dev)
+        ph = torch.empty(n, dtype=torch.int32, device=dev)
+        lim = 1 << (cfg.iw - 1)
+        x.random_(-lim, lim - 1, generator=g)
+        y.random_(-lim, lim - 1, generator=g)
+        ph.random_(-2**31, 2**31 - 1, generator=g)
+        o0 = torch.empty(n, dtype=torch.int32, device=dev)
+        o1 = torch.empty(n, dtype=torch.int32, device=dev)
+        ob, od, oa = (torch.empty(n, dtype=torch.uint8, device=dev)
+                      for _ in range(3))
+        for label, p in (("i_stb every clock (1 result per %d clocks)"
+                          % cfg.c.clocks_per_output, 1.0),
+                         ("i_stb on 2 % of the clocks", 0.02)):
+            stb = (torch.rand(n, device=dev, generator=g) < p).to(torch.uint8)
+            s = ca.Seq(cfg)
+            for _ in range(2):
+                s.ticks(stb, x, y, ph if rot else None, o0, o1, ob, od, oa)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            k = 10
+            for _ in range(k):
+                s.ticks(stb, x, y, ph if rot else None, o0, o1, ob, od, oa)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / k
+            print(json.dumps({"core": name, "activity": label, "clocks": n,
+                              "ms_per_block": ms,
+                              "Mclocks_per_s": n / ms / 1e3,
+                              "results_per_block": int(od.sum().item())}))
+
+
 if __name__ == "__main__":
+    seq_rate()
     main()
