@@ -480,6 +480,35 @@ __device__ __forceinline__ uint32_t fsm_step(uint32_t &c, bool stb, bool rst,
 	return ev;
 }
 
+// 16 clocks of a byte-per-clock port array in one load when the array allows
+// it (tiles start at multiples of 1024 clocks, so only the base matters)
+struct Pins16 {
+	uint32_t w[4];
+	__device__ __forceinline__ bool bit(int k) const
+	{
+		return ((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0;
+	}
+};
+__device__ __forceinline__ Pins16 load16(const uint8_t *p, uint32_t t,
+		uint32_t hi, bool vec)
+{
+	Pins16 r{{0, 0, 0, 0}};
+	if (!p)
+		return r;
+	if (vec && t + 16 <= hi) {
+		const u32x4 v = *reinterpret_cast<const u32x4 *>(p + t);
+		r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3];
+	} else {
+		for (int k = 0; k < 16 && t + k < hi; k++)
+			r.w[k >> 2] |= (uint32_t)(p[t + k] != 0) << ((k & 3) * 8);
+	}
+	return r;
+}
+__device__ __forceinline__ bool aligned16p(const void *p)
+{
+	return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
 // pass 1: exit state of every tile for every entry state
 __global__ __launch_bounds__(128) void seq_fsm_tables(const uint8_t *stb,
 		const uint8_t *rst, uint32_t T, uint32_t C, uint8_t *gtab)
@@ -490,8 +519,14 @@ __global__ __launch_bounds__(128) void seq_fsm_tables(const uint8_t *stb,
 	uint32_t c = threadIdx.x;
 	const uint32_t lo = tile * kFsmTile;
 	const uint32_t hi = (lo + kFsmTile < T) ? lo + kFsmTile : T;
-	for (uint32_t t = lo; t < hi; t++)
-		(void)fsm_step(c, stb[t] != 0, rst && rst[t] != 0, C);
+	const bool vs = aligned16p(stb), vr = aligned16p(rst);
+	for (uint32_t t = lo; t < hi; t += 16) {
+		const Pins16 ps = load16(stb, t, hi, vs), pr = load16(rst, t, hi, vr);
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			if (t + k < hi)
+				(void)fsm_step(c, ps.bit(k), pr.bit(k), C);
+	}
 	gtab[(size_t)tile * kFsmStates + threadIdx.x] = (uint8_t)c;
 }
 
@@ -527,6 +562,20 @@ __global__ __launch_bounds__(64) void seq_fsm_spine(const uint8_t *gtab,
 }
 
 // pass 3: per-clock flags from the true entry states
+__device__ __forceinline__ void store16(uint8_t *p, uint32_t t, uint32_t hi,
+		bool vec, const uint32_t (&w)[4])
+{
+	if (!p)
+		return;
+	if (vec && t + 16 <= hi) {
+		u32x4 v = {w[0], w[1], w[2], w[3]};
+		*reinterpret_cast<u32x4 *>(p + t) = v;
+	} else {
+		for (int k = 0; k < 16 && t + k < hi; k++)
+			p[t + k] = (uint8_t)((w[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+	}
+}
+
 __global__ __launch_bounds__(64) void seq_fsm_emit(const uint8_t *stb,
 		const uint8_t *rst, uint32_t T, uint32_t C, const uint8_t *entry,
 		uint32_t ntiles, uint8_t *accept, uint8_t *load, uint8_t *busy,
@@ -538,14 +587,29 @@ __global__ __launch_bounds__(64) void seq_fsm_emit(const uint8_t *stb,
 	uint32_t c = entry[tile];
 	const uint32_t lo = tile * kFsmTile;
 	const uint32_t hi = (lo + kFsmTile < T) ? lo + kFsmTile : T;
+	const bool vs = aligned16p(stb), vr = aligned16p(rst);
+	const bool vb = aligned16p(busy), vd = aligned16p(done);
 	uint32_t viol = 0;
-	for (uint32_t t = lo; t < hi; t++) {
-		const uint32_t ev = fsm_step(c, stb[t] != 0, rst && rst[t] != 0, C);
-		accept[t] = (ev & EV_ACCEPT) ? 1 : 0;
-		load[t] = (ev & EV_LOAD) ? 1 : 0;
-		if (busy) busy[t] = (ev & EV_BUSY) ? 1 : 0;
-		if (done) done[t] = (ev & EV_DONE) ? 1 : 0;
-		viol += (ev & EV_VIOL) ? 1u : 0u;
+	for (uint32_t t = lo; t < hi; t += 16) {
+		const Pins16 ps = load16(stb, t, hi, vs), pr = load16(rst, t, hi, vr);
+		uint32_t wa[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+		uint32_t wb[4] = {0, 0, 0, 0}, wd[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (t + k < hi) {
+				const uint32_t ev = fsm_step(c, ps.bit(k), pr.bit(k), C);
+				const int sh = (k & 3) * 8;
+				wa[k >> 2] |= ((ev & EV_ACCEPT) ? 1u : 0u) << sh;
+				wl[k >> 2] |= ((ev & EV_LOAD) ? 1u : 0u) << sh;
+				wb[k >> 2] |= ((ev & EV_BUSY) ? 1u : 0u) << sh;
+				wd[k >> 2] |= ((ev & EV_DONE) ? 1u : 0u) << sh;
+				viol += (ev & EV_VIOL) ? 1u : 0u;
+			}
+		}
+		store16(accept, t, hi, true, wa);	// workspace: always aligned
+		store16(load, t, hi, true, wl);
+		store16(busy, t, hi, vb, wb);
+		store16(done, t, hi, vd, wd);
 	}
 	if (viol)
 		atomicAdd(violations, (unsigned long long)viol);
