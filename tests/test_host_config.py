@@ -173,3 +173,35 @@ def test_live_stage_counts_and_wrap_analysis():
         assert cfg.needs_wrap == 0
     # ... tiny ones can (truncation noise is comparable to full scale)
     assert ca.Config.from_core(ca.P2R, 6, 1, 1, 1, 8).needs_wrap == 1
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    """No CPU fallback: on a machine without a GPU every entry point that
+    needs the device returns CORDIC_ERR_DEVICE instead of computing anything
+    on the host.  (Skipped where a GPU is present.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = ca.Config.from_cli(ca.P2R, 13, 13)
+    with pytest.raises(ca.CordicError) as e:
+        ca.Plan(cfg)
+    assert e.value.status == ca.ERR_DEVICE
+    with pytest.raises(ca.CordicError) as e:
+        ca.Stream(cfg)
+    assert e.value.status == ca.ERR_DEVICE
+    with pytest.raises(ca.CordicError) as e:
+        ca.Seq(ca.Config.from_cli(ca.SP2R, 13, 13))
+    assert e.value.status == ca.ERR_DEVICE
+    with pytest.raises(ca.CordicError) as e:
+        ca.Quad(ow=13, pw=18)
+    assert e.value.status == ca.ERR_DEVICE
+    with pytest.raises(ca.CordicError) as e:
+        ca.Table(ca.TBL, -1, 13, 17)
+    assert e.value.status == ca.ERR_DEVICE
+    x = np.zeros(8, dtype=np.int32)
+    with pytest.raises(ca.CordicError) as e:
+        ca.p2r_host(cfg, x, x, x.view(np.uint32))
+    assert e.value.status == ca.ERR_DEVICE
+    # a launch on (null) device pointers must not pretend to succeed either
+    rc = ca.lib().cordic_p2r_const(cfg.ref, 8, 1, 0, 16, 16, 16, None)
+    assert rc == ca.ERR_DEVICE
