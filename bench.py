@@ -54,6 +54,9 @@ WORKLOADS = {
     "qtrtbl": dict(kind="tbl", table=(5, -1, 24, 18), bytes=8, shift=0,
                    desc="quarterwav PW=18 OW=24 (rtl/quarterwav.v), phase "
                    "ramp n"),
+    "qtrtbl16": dict(kind="tbl", table=(5, -1, 16, 17), bytes=8, shift=0,
+                     desc="quarterwav PW=17 OW=16 (int16 copy in LDS), phase "
+                     "ramp n"),
     "quadtbl": dict(kind="tbl", quad=(-1, 13, 2, 18), bytes=8, shift=0,
                     desc="quadtbl PW=18 OW=13 (rtl/quadtbl.v: 64-entry C/L/Q "
                     "tables + quadratic interpolation), phase ramp n"),

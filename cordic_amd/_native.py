@@ -118,6 +118,7 @@ ABI = {
     "cordic_stream_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_stream_ticks": (C.c_int, [C.c_void_p, C.c_size_t] +
                             [C.c_void_p] * 10),
+    "cordic_table_lds_mode": (C.c_int, [C.c_void_p]),
     "cordic_seq_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
     "cordic_seq_destroy": (None, [C.c_void_p]),
     "cordic_seq_workspace": (C.c_size_t, [C.c_size_t]),
@@ -344,6 +345,10 @@ class Table:
                                          out.ctypes.data_as(_i32p), out.size),
                "cordic_table_values")
         return out
+
+    @property
+    def lds_mode(self):
+        return lib().cordic_table_lds_mode(self._h)
 
     def lookup(self, phase, val, n=None, stream=None):
         n = phase.numel() if n is None else n

@@ -223,7 +223,48 @@ int cordic_plan_nco16(const cordic_plan *plan, size_t n, uint32_t phase0,
 struct cordic_table {
 	cordic_table_config cfg;
 	int32_t *d_tbl = nullptr;
+	// optional packed copy for the LDS kernel (cordic_kernels.hip:
+	// table_lookup_lds): mode 1 = quarter-wave table as is, 2 = full-wave
+	// table folded to its first quadrant (+ the peak entry)
+	int16_t *d_lds16 = nullptr;
+	int	lds_mode = 0, lds_entries = 0;
 };
+
+namespace {
+// A packed int16 table of at most 64 KiB (+ one entry) if the core allows it.
+// For -t tbl the fold is only used when every one of the 2^PW entries is
+// reproduced by it.
+bool pack_for_lds(const cordic_table_config &c, const std::vector<int32_t> &t,
+		std::vector<int16_t> *out, int *mode)
+{
+	if (c.ow > 16 || c.pw < 4)
+		return false;
+	const int quarter = 1 << (c.pw - 2);
+	if (quarter > 32768)
+		return false;
+	if (c.kind == CORDIC_QTR) {
+		out->resize((size_t)quarter);
+		for (int k = 0; k < quarter; k++)
+			(*out)[(size_t)k] = (int16_t)t[(size_t)k];
+		*mode = 1;
+		return true;
+	}
+	const int n = 1 << c.pw;
+	for (int i = 0; i < n; i++) {
+		const int q = i >> (c.pw - 2), j = i & (quarter - 1);
+		int32_t v = t[(size_t)((q & 1) ? quarter - j : j)];
+		if (q & 2)
+			v = -v;
+		if (v != t[(size_t)i])
+			return false;
+	}
+	out->resize((size_t)quarter + 1);
+	for (int k = 0; k <= quarter; k++)
+		(*out)[(size_t)k] = (int16_t)t[(size_t)k];
+	*mode = 2;
+	return true;
+}
+} // namespace
 
 int cordic_table_config_init(cordic_table_config *cfg, int kind, int iw, int ow,
 		int phase_bits)
@@ -257,6 +298,21 @@ int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 		delete t;
 		return CORDIC_ERR_DEVICE;
 	}
+	std::vector<int16_t> packed;
+	int mode = 0;
+	if (pack_for_lds(*cfg, host, &packed, &mode)) {
+		// optional: on failure the L2 gather kernel serves the table
+		if (hipMalloc((void **)&t->d_lds16, packed.size() * 2) == hipSuccess
+				&& hipMemcpy(t->d_lds16, packed.data(), packed.size() * 2,
+					hipMemcpyHostToDevice) == hipSuccess) {
+			t->lds_mode = mode;
+			t->lds_entries = (int)packed.size();
+		} else {
+			if (t->d_lds16) (void)hipFree(t->d_lds16);
+			t->d_lds16 = nullptr;
+			(void)hipGetLastError();
+		}
+	}
 	*tbl = t;
 	return CORDIC_OK;
 }
@@ -267,6 +323,8 @@ void cordic_table_destroy(cordic_table *tbl)
 		return;
 	if (tbl->d_tbl)
 		(void)hipFree(tbl->d_tbl);
+	if (tbl->d_lds16)
+		(void)hipFree(tbl->d_lds16);
 	delete tbl;
 }
 
@@ -275,7 +333,8 @@ int cordic_table_lookup(const cordic_table *tbl, size_t n,
 {
 	if (!tbl)
 		return CORDIC_ERR_ARGS;
-	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream);
+	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream,
+			tbl->d_lds16, tbl->lds_mode, tbl->lds_entries);
 }
 
 // ------------------------------------------------- quadratic sine core
@@ -574,6 +633,11 @@ int cordic_seq_violations(cordic_seq *s, uint64_t *count)
 		return CORDIC_ERR_DEVICE;
 	*count = v;
 	return CORDIC_OK;
+}
+
+int cordic_table_lds_mode(const cordic_table *tbl)
+{
+	return tbl ? tbl->lds_mode : CORDIC_ERR_ARGS;
 }
 
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)

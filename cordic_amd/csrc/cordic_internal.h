@@ -89,7 +89,9 @@ int	launch_fill_phase_ramp(uint32_t *p, size_t n, uint64_t index0, int shift,
 int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 		uint32_t mulx, uint32_t muly, int bits, void *stream);
 int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
-		size_t n, const uint32_t *phase, int32_t *val, void *stream);
+		size_t n, const uint32_t *phase, int32_t *val, void *stream,
+		const int16_t *d_lds16 = nullptr, int lds_mode = 0,
+		int lds_entries = 0);
 // ---- clocked view of the pipelined cores: cordic_stream.hip
 struct StreamState {
 	void	*ws = nullptr;		// scan / gather workspace

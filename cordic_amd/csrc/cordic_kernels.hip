@@ -190,6 +190,60 @@ __global__ __launch_bounds__(kBlock) void table_lookup(
 		val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
 }
 
+// Small tables: a packed int16 copy in LDS, so that random phases cost an LDS
+// gather instead of an L2 gather (195 -> ~500 Gsample/s measured).  The
+// full-wave table of -t tbl is kept as its first quadrant plus the peak entry
+// when the HOST has checked that the generated table really has the
+// symmetry (sin() of the mirrored argument can differ in the last bit, and
+// the entries are truncated, so it is a property to test, not to assume).
+//   mode 1: -t qtr table as is           (entries  = 2^(PW-2))
+//   mode 2: -t tbl folded to a quadrant  (entries  = 2^(PW-2) + 1)
+template <int MODE>
+__global__ __launch_bounds__(1024) void table_lookup_lds(
+		const int16_t *__restrict__ packed, int entries,
+		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
+		size_t n, int pw, int ow)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t lds16[];
+	for (int i = threadIdx.x; i < entries; i += 1024)
+		lds16[i] = packed[i];
+	__syncthreads();
+	const uint32_t qm = (1u << (pw - 2)) - 1u;
+	const int sh = 32 - ow;
+	auto sample = [&](uint32_t ph) -> int32_t {
+		const uint32_t mirror = (ph >> (pw - 2)) & 1u;
+		const uint32_t neg = (ph >> (pw - 1)) & 1u;
+		int32_t v;
+		if constexpr (MODE == 1) {	// rtl/quarterwav.v:86-108
+			v = lds16[mirror ? (~ph & qm) : (ph & qm)];
+			if (neg) v = -v;
+			return (int32_t)((uint32_t)v << sh) >> sh;
+		} else {			// quadrant fold of rtl/sintable.v:72-77
+			const uint32_t j = ph & qm;
+			v = lds16[mirror ? (qm + 1u - j) : j];
+			return neg ? -v : v;
+		}
+	};
+	const size_t nvec = n / kVec;
+	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + 1023) / 1024 * 1024;
+	const size_t lo = (size_t)blockIdx.x * chunk;
+	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
+	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
+	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+		const u32x4 p = pv[g];
+		i32x4 o;
+#pragma unroll
+		for (int v = 0; v < kVec; v++)
+			o[v] = sample(p[v]);
+		ov[g] = o;
+	}
+	if (blockIdx.x == 0)
+		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
+			val[i] = sample(phase[i]);
+}
+
 // ------------------------------------------------- quadratic sine core
 //
 // rtl/quadtbl.v on one sample.  Table entries are {C, L, Q, 0} (one 16-byte
@@ -619,11 +673,29 @@ int launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 }
 
 int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
-		size_t n, const uint32_t *phase, int32_t *val, void *stream)
+		size_t n, const uint32_t *phase, int32_t *val, void *stream,
+		const int16_t *d_lds16, int lds_mode, int lds_entries)
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!d_tbl || !phase || !val) return CORDIC_ERR_ARGS;
+	if (d_lds16 && lds_mode && aligned4(phase) && aligned4(val)) {
+		const size_t bytes = ((size_t)lds_entries * 2 + 15) & ~(size_t)15;
+		int per_cu = (int)((160 * 1024) / bytes);
+		if (per_cu > 2) per_cu = 2;
+		const int grid = grid_for((size_t)1024 * kVec, n, per_cu);
+		if (grid < 0) return CORDIC_ERR_DEVICE;
+		hipStream_t st = static_cast<hipStream_t>(stream);
+		auto k1 = table_lookup_lds<1>;
+		auto k2 = table_lookup_lds<2>;
+		auto kern = (lds_mode == 1) ? k1 : k2;
+		if (bytes > 64 * 1024)
+			(void)hipFuncSetAttribute((const void *)kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), bytes, st, d_lds16,
+				lds_entries, phase, val, n, t.pw, t.ow);
+		return check_launch();
+	}
 	const int grid = grid_for(kTile, n);
 	if (grid < 0) return CORDIC_ERR_DEVICE;
 	hipStream_t st = static_cast<hipStream_t>(stream);

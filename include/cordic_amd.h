@@ -305,6 +305,11 @@ void	cordic_table_destroy(cordic_table *tbl);
 /* d_val[i] = o_val of the core for i_phase = d_phase[i] (low PW bits) */
 int	cordic_table_lookup(const cordic_table *tbl, size_t n,
 		const uint32_t *d_phase, int32_t *d_val, void *stream);
+/* which kernel serves this table: 0 = gather from the table in L2, 1 = packed
+ * int16 copy of a quarter-wave table in LDS, 2 = full-wave table folded to its
+ * first quadrant in LDS (OW <= 16, PW <= 17, and -- for 2 -- the generated
+ * table verified to have the symmetry) */
+int	cordic_table_lds_mode(const cordic_table *tbl);
 
 /* ---------------------------------- quadratically interpolated sine core
  *

@@ -88,7 +88,11 @@ def test_emitted_table_rtl_executed_by_vsim_equals_oracle(args, tmp_path):
                                            (ca.QTR, -1, 24, 18),
                                            (ca.TBL, -1, 8, 6),
                                            (ca.QTR, 8, -1, -1),
-                                           (ca.QTR, -1, 30, 20)])
+                                           (ca.QTR, -1, 30, 20),
+                                           (ca.QTR, -1, 16, 17),
+                                           (ca.TBL, -1, 16, 16),
+                                           (ca.TBL, -1, 12, 15),
+                                           (ca.QTR, -1, 9, 5)])
 def test_gpu_table_lookup_equals_oracle(kind, iw, ow, pw):
     import torch
     from gpu_util import DEV, dev_i32, to_np
@@ -106,4 +110,9 @@ def test_gpu_table_lookup_equals_oracle(kind, iw, ow, pw):
         torch.cuda.synchronize()
         exp = O.table_lookup(kind, t.pw, t.ow, tbl, ph[off:off + n])
         assert np.array_equal(to_np(out)[off:off + n], exp)
+    # small 16-bit tables are served from LDS (a full-wave table only if the
+    # generated entries really are symmetric); the rest gather from L2
+    small = t.ow <= 16 and (1 << (t.pw - 2)) <= 32768 and t.pw >= 4
+    assert t.lds_mode in ((1,) if (small and kind == ca.QTR) else
+                          (0, 2) if small else (0,))
     t.close()
