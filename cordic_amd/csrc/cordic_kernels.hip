@@ -164,30 +164,29 @@ __device__ __forceinline__ int32_t table_sample(const int32_t *__restrict__ tbl,
 }
 
 template <bool QUARTER>
-__global__ __launch_bounds__(kBlock) void table_lookup(
+__global__ __launch_bounds__(1024) void table_lookup(
 		const int32_t *__restrict__ tbl, const uint32_t *__restrict__ phase,
 		int32_t *__restrict__ val, size_t n, int pw, int ow)
 {
+	// 1024-thread blocks, one contiguous chunk each (see quad_lookup)
 	const size_t nvec = n / kVec;
-	const size_t stride = (size_t)gridDim.x * kBlock;
-	const bool vec_ok = ((reinterpret_cast<uintptr_t>(phase)
-			| reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
-	size_t done = 0;
-	if (vec_ok) {
-		for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-				g += stride) {
-			const u32x4 p = reinterpret_cast<const u32x4 *>(phase)[g];
-			i32x4 o;
+	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + 1023) / 1024 * 1024;
+	const size_t lo = (size_t)blockIdx.x * chunk;
+	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
+	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
+	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+		const u32x4 p = pv[g];
+		i32x4 o;
 #pragma unroll
-			for (int v = 0; v < kVec; v++)
-				o[v] = table_sample<QUARTER>(tbl, p[v], pw, ow);
-			reinterpret_cast<i32x4 *>(val)[g] = o;
-		}
-		done = nvec * kVec;
+		for (int v = 0; v < kVec; v++)
+			o[v] = table_sample<QUARTER>(tbl, p[v], pw, ow);
+		ov[g] = o;
 	}
-	for (size_t i = done + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-			i += stride)
-		val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
+	if (blockIdx.x == 0)
+		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
+			val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
 }
 
 // Small tables: a packed int16 copy in LDS, so that random phases cost an LDS
@@ -287,39 +286,39 @@ __device__ __forceinline__ int32_t quad_sample(const i32x4 e, uint32_t ph,
 
 // The tables are small (the generator stops growing them at one LSB of fit
 // error: at most 2^10 entries for the widest core it can write, 16 KiB
-// packed), so every block keeps its own copy in LDS.
-__global__ __launch_bounds__(kBlock) void quad_lookup(
+// packed), so every block keeps its own copy in LDS.  1024-thread blocks,
+// each sweeping one contiguous chunk: measured ~5 % faster than a grid-stride
+// of 256-thread blocks for this 4 B in / 4 B out stream.
+__global__ __launch_bounds__(1024) void quad_lookup(
 		const i32x4 *__restrict__ tab, QuadParams qp,
 		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
 		size_t n)
 {
 	extern __shared__ __attribute__((aligned(16))) i32x4 lds_tab[];
-	for (int i = threadIdx.x; i < (1 << qp.lgtbl); i += kBlock)
+	for (int i = threadIdx.x; i < (1 << qp.lgtbl); i += 1024)
 		lds_tab[i] = tab[i];
 	__syncthreads();
 	const i32x4 *t = lds_tab;
 	const uint32_t imask = (1u << qp.lgtbl) - 1u;
 	const int ish = qp.dxbits - 1;
 	const size_t nvec = n / kVec;
-	const size_t stride = (size_t)gridDim.x * kBlock;
-	const bool vec_ok = ((reinterpret_cast<uintptr_t>(phase)
-			| reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
-	size_t done = 0;
-	if (vec_ok) {
-		for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec;
-				g += stride) {
-			const u32x4 p = reinterpret_cast<const u32x4 *>(phase)[g];
-			i32x4 o;
+	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + 1023) / 1024 * 1024;
+	const size_t lo = (size_t)blockIdx.x * chunk;
+	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
+	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
+	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+		const u32x4 p = pv[g];
+		i32x4 o;
 #pragma unroll
-			for (int v = 0; v < kVec; v++)
-				o[v] = quad_sample(t[(p[v] >> ish) & imask], p[v], qp);
-			reinterpret_cast<i32x4 *>(val)[g] = o;
-		}
-		done = nvec * kVec;
+		for (int v = 0; v < kVec; v++)
+			o[v] = quad_sample(t[(p[v] >> ish) & imask], p[v], qp);
+		ov[g] = o;
 	}
-	for (size_t i = done + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-			i += stride)
-		val[i] = quad_sample(t[(phase[i] >> ish) & imask], phase[i], qp);
+	if (blockIdx.x == 0)
+		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
+			val[i] = quad_sample(t[(phase[i] >> ish) & imask], phase[i], qp);
 }
 
 // mix(): a 64-bit finaliser over (global index, word) so that the digest is
@@ -679,7 +678,8 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!d_tbl || !phase || !val) return CORDIC_ERR_ARGS;
-	if (d_lds16 && lds_mode && aligned4(phase) && aligned4(val)) {
+	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
+	if (d_lds16 && lds_mode) {
 		const size_t bytes = ((size_t)lds_entries * 2 + 15) & ~(size_t)15;
 		int per_cu = (int)((160 * 1024) / bytes);
 		if (per_cu > 2) per_cu = 2;
@@ -696,14 +696,14 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 				lds_entries, phase, val, n, t.pw, t.ow);
 		return check_launch();
 	}
-	const int grid = grid_for(kTile, n);
+	const int grid = grid_for((size_t)1024 * kVec, n, 2);
 	if (grid < 0) return CORDIC_ERR_DEVICE;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (t.kind == CORDIC_QTR)
-		hipLaunchKernelGGL(table_lookup<true>, dim3(grid), dim3(kBlock), 0,
+		hipLaunchKernelGGL(table_lookup<true>, dim3(grid), dim3(1024), 0,
 				st, d_tbl, phase, val, n, t.pw, t.ow);
 	else
-		hipLaunchKernelGGL(table_lookup<false>, dim3(grid), dim3(kBlock), 0,
+		hipLaunchKernelGGL(table_lookup<false>, dim3(grid), dim3(1024), 0,
 				st, d_tbl, phase, val, n, t.pw, t.ow);
 	return check_launch();
 }
@@ -714,7 +714,8 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
 	if (!d_tables || !phase || !val) return CORDIC_ERR_ARGS;
-	const int grid = grid_for(kTile, n);
+	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
+	const int grid = grid_for((size_t)1024 * kVec, n, 2);
 	if (grid < 0) return CORDIC_ERR_DEVICE;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	QuadParams qp{q.pw, q.ow, q.xtra, q.ww, q.lgtbl, q.dxbits, q.cbits, q.lbits};
@@ -722,7 +723,7 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 	const size_t bytes = (size_t)q.entries * sizeof(i32x4);
 	if (bytes > 64 * 1024)
 		return CORDIC_ERR_UNSUPPORTED;
-	hipLaunchKernelGGL(quad_lookup, dim3(grid), dim3(kBlock), bytes, st, tab,
+	hipLaunchKernelGGL(quad_lookup, dim3(grid), dim3(1024), bytes, st, tab,
 			qp, phase, val, n);
 	return check_launch();
 }

@@ -3,8 +3,8 @@
 # rocprofv3 stats + PMC for the new kernels.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/bench_r01b
-for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl quadtbl quadtbl24; do for i in ramp random; do
-timeout 300 python bench.py --workload $w --input $i --no-cpu-baseline > gpurun_out/bench_r01b/${w}_$i.json 2> gpurun_out/b.err; python - <<PY
+for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 quadtbl quadtbl24; do for i in ramp random; do
+timeout 300 python bench.py --workload $w --input $i --no-cpu-baseline --no-other-paths > gpurun_out/bench_r01b/${w}_$i.json 2> gpurun_out/b.err; python - <<PY
 import json
 try:
     d=json.load(open("gpurun_out/bench_r01b/${w}_$i.json"))
@@ -14,7 +14,7 @@ except Exception as e:
     print("$w $i FAILED", e, open("gpurun_out/b.err").read()[-600:])
 PY
 done; done
-bash tools/profile_r01.sh cfg1 > gpurun_out/prof_cfg1.log 2>&1
-bash tools/profile_r01.sh quadtbl > gpurun_out/prof_quadtbl.log 2>&1
-bash tools/profile_r01.sh cfg2 > gpurun_out/prof_cfg2.log 2>&1
-tail -3 gpurun_out/prof_cfg1.log gpurun_out/prof_quadtbl.log gpurun_out/prof_cfg2.log
+
+
+
+
