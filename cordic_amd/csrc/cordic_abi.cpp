@@ -27,7 +27,7 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		return CORDIC_ERR_MODE;
 	cordic_plan *p = new (std::nothrow) cordic_plan;
 	if (!p)
-		return CORDIC_ERR_ARGS;
+		return CORDIC_ERR_NOMEM;
 	p->cfg = *cfg;
 	std::vector<uint32_t> words(4 + 4096 * 4 + 4096 * 2);
 	const size_t nw = build_seed_table(*cfg, CORDIC_SEED_STAGES, words.data(), words.size());
@@ -289,7 +289,7 @@ int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 		return rc;
 	cordic_table *t = new (std::nothrow) cordic_table;
 	if (!t)
-		return CORDIC_ERR_ARGS;
+		return CORDIC_ERR_NOMEM;
 	t->cfg = *cfg;
 	if (hipMalloc((void **)&t->d_tbl, host.size() * 4) != hipSuccess ||
 	    hipMemcpy(t->d_tbl, host.data(), host.size() * 4,
@@ -386,7 +386,7 @@ int cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core)
 	}
 	cordic_quad *h = new (std::nothrow) cordic_quad;
 	if (!h)
-		return CORDIC_ERR_ARGS;
+		return CORDIC_ERR_NOMEM;
 	h->cfg = *cfg;
 	if (hipMalloc((void **)&h->d_tab, packed.size() * 4) != hipSuccess ||
 	    hipMemcpy(h->d_tab, packed.data(), packed.size() * 4,
@@ -448,7 +448,7 @@ int cordic_stream_create(const cordic_config *cfg, cordic_stream **out)
 		return CORDIC_ERR_MODE;
 	cordic_stream *s = new (std::nothrow) cordic_stream;
 	if (!s)
-		return CORDIC_ERR_ARGS;
+		return CORDIC_ERR_NOMEM;
 	s->cfg = *cfg;
 	const int L = cfg->nstages + 2;
 	s->latency = L;
@@ -566,7 +566,7 @@ int cordic_seq_create(const cordic_config *cfg, cordic_seq **out)
 		return CORDIC_ERR_MODE;
 	cordic_seq *s = new (std::nothrow) cordic_seq;
 	if (!s)
-		return CORDIC_ERR_ARGS;
+		return CORDIC_ERR_NOMEM;
 	s->cfg = *cfg;
 	SeqState &t = s->st;
 	auto zalloc = [](auto **p, size_t bytes) {

@@ -507,6 +507,7 @@ const char *status_text(int s)
 	case CORDIC_ERR_ARGS:		return "bad argument";
 	case CORDIC_ERR_DEVICE:		return "HIP runtime error";
 	case CORDIC_ERR_CONTAINER:	return "port wider than the 16-bit sample container";
+	case CORDIC_ERR_NOMEM:		return "out of host memory";
 	default:			return "unknown status";
 	}
 }

@@ -70,8 +70,9 @@ enum cordic_status {
 					   or never raises o_done              */
 	CORDIC_ERR_ARGS		= -7,	/* NULL pointer / bad command line     */
 	CORDIC_ERR_DEVICE	= -8,	/* HIP runtime error (no GPU, launch)  */
-	CORDIC_ERR_CONTAINER	= -9	/* a port is wider than the 16-bit
+	CORDIC_ERR_CONTAINER	= -9,	/* a port is wider than the 16-bit
 					   sample container of a *16 call      */
+	CORDIC_ERR_NOMEM	= -10	/* host allocation failed              */
 };
 
 /* flags (cordic_config.flags) -- implementation selectors for A/B work */
