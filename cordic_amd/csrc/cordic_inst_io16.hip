@@ -43,6 +43,12 @@ bool seed16(int nlive, int grid, hipStream_t st, const CoreParams &kp,
 		? rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true, Io16,
 				true>
 		: rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true, Io16>;
+	// the stage counts 16-bit cores usually have: static instances
+	// (-i 16 -o 16 -p 16: 13 live stages; -p 18..20: 16)
+	if (kp.post_mul == 0 && nlive == 13)
+		kern = rotator_seeded<Narrow32, 13, kSeedStages, FEED, false, Io16>;
+	if (kp.post_mul == 0 && nlive == 16)
+		kern = rotator_seeded<Narrow32, 16, kSeedStages, FEED, false, Io16>;
 	if (lds_bytes > 64 * 1024)
 		(void)hipFuncSetAttribute((const void *)kern,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
