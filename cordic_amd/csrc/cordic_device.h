@@ -703,24 +703,31 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				y = (T)((U)y - (U)sx);
 			}
 		}
-		// 16-byte seed entry {x word, y word, off + 2^29, low bits}:
-		//  Narrow32: the words are x and y themselves;
-		//  WideLJ  : the words are the HIGH words of x << LJ, y << LJ; their
-		//            low words only carry 32-LJ (<= 3) bits at the top,
-		//            packed as x_lo | (y_lo >> 3) into the fourth word.
+		// 16-byte seed entry.
+		//  Narrow32: {x, y, off + 2^29, 0}.
+		//  WideLJ  : {x~ lo, x~ hi, y~ lo, y~ hi} with x~ = x << LJ, so that
+		//            one ds_read_b128 lands in the two register pairs of the
+		//            stage chain.  The low LJ (>= 29) bits of x~ and y~ are
+		//            zero and NOTHING downstream looks at them -- every stage
+		//            adds a multiple of 2^LJ and shifts the high word, the
+		//            rounding adds a multiple of 2^LJ and drops at least
+		//            LJ+1 bits -- so the low 29 bits of x~ lo carry
+		//            (off + 2^29) mod 2^29.  That is enough: the residual
+		//            after M >= 2 stages is far below 2^28 in magnitude.
 		uint32_t *d = lds_seeds + (size_t)e * 4;
 		if constexpr (C::lj != 0) {
 			const uint64_t xs = (uint64_t)(int64_t)x << C::lj;
 			const uint64_t ys = (uint64_t)(int64_t)y << C::lj;
-			d[0] = (uint32_t)(xs >> 32);
-			d[1] = (uint32_t)(ys >> 32);
-			d[3] = (uint32_t)xs | ((uint32_t)ys >> 3);
+			d[0] = (uint32_t)xs | (leafmeta[2 * j + 1] & 0x1fffffffu);
+			d[1] = (uint32_t)(xs >> 32);
+			d[2] = (uint32_t)ys;
+			d[3] = (uint32_t)(ys >> 32);
 		} else {
 			d[0] = (uint32_t)x;
 			d[1] = (uint32_t)y;
+			d[2] = leafmeta[2 * j + 1];		// off + 2^29
 			d[3] = 0;
 		}
-		d[2] = leafmeta[2 * j + 1];		// off + 2^29
 	}
 	__syncthreads();
 
@@ -733,7 +740,13 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	const uint32_t bshift = (uint32_t)sa.S - 4;	// bucket -> byte offset
 	const uint32_t seed_base = (uint32_t)sa.nbuckets * 16u;
 	const uint32_t qstride = (uint32_t)L * 16u;
-	const char *ldsb = reinterpret_cast<const char *>(lds);
+	// LDS is addressed by byte offset: this kernel has no static LDS, so the
+	// dynamic array starts at LDS address 0 and the per-sample address needs
+	// no base added to it (the add of the array's link-time address was one
+	// VALU instruction per read).  Checked once per wave.
+	typedef const __attribute__((address_space(3))) u32x4 lds_entry;
+	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
+		__builtin_trap();
 
 	// Work distribution: every (persistent) block sweeps its own contiguous
 	// chunk.  This kernel runs at HBM speed, and an arithmetic-free kernel
@@ -786,35 +799,31 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			const uint32_t pb = P[v] + 0x20000000u;
-			qoff[v] = (pb >> 30) * qstride + seed_base;
+			qoff[v] = __umul24(pb >> 30, qstride) + seed_base;
 			r[v] = pb & 0x3fffffffu;		// p0 + 2^29
-			bk[v] = *reinterpret_cast<const u32x4 *>(
-					ldsb + ((r[v] >> bshift) & ~15u));
+			bk[v] = *(lds_entry *)(uintptr_t)((r[v] >> bshift) & ~15u);
 		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			// r >= bound  <=>  (bound-1) - r < 0
 			const uint32_t j16 = (bk[v][2] + ((bk[v][0] - r[v]) >> 31)
 						+ ((bk[v][1] - r[v]) >> 31)) << 4;
-			se[v] = *reinterpret_cast<const u32x4 *>(ldsb + qoff[v] + j16);
+			se[v] = *(lds_entry *)(uintptr_t)(qoff[v] + j16);
 		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			if constexpr (C::lj != 0) {
-				constexpr uint32_t lowmask = ~((1u << C::lj) - 1u);
-				x[v] = (int64_t)(((uint64_t)se[v][0] << 32)
-						| (se[v][3] & lowmask));
-				y[v] = (int64_t)(((uint64_t)se[v][1] << 32)
-						| (se[v][3] << 3));
+				x[v] = (int64_t)(((uint64_t)se[v][1] << 32) | se[v][0]);
+				y[v] = (int64_t)(((uint64_t)se[v][3] << 32) | se[v][2]);
+				// residual = (r - off) mod 2^29, sign extended; carried
+				// as sext(residual) << 31 = sext(t) << 28
+				const int32_t t = (int32_t)((r[v] - se[v][0]) << 3);
+				p[v] = (int64_t)((uint64_t)(int64_t)t << 28);
 			} else {
 				x[v] = (int64_t)se[v][0];
 				y[v] = (int64_t)se[v][1];
+				p[v] = (int64_t)(r[v] - se[v][2]);
 			}
-			const uint32_t pm = r[v] - se[v][2];	// residual after M stages
-			if constexpr (C::lj != 0)
-				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)pm << 31);
-			else
-				p[v] = (int64_t)pm;
 		}
 
 		i32x4 rx, ry;
