@@ -712,8 +712,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		//            adds a multiple of 2^LJ and shifts the high word, the
 		//            rounding adds a multiple of 2^LJ and drops at least
 		//            LJ+1 bits -- so the low 29 bits of x~ lo carry
-		//            (off + 2^29) mod 2^29.  That is enough: the residual
-		//            after M >= 2 stages is far below 2^28 in magnitude.
+		//            (off + 2^29) mod 2^29.  That is enough: the host builds
+		//            a table only if every residual fits 29 bits signed
+		//            (cordic_plan.cpp).
 		uint32_t *d = lds_seeds + (size_t)e * 4;
 		if constexpr (C::lj != 0) {
 			const uint64_t xs = (uint64_t)(int64_t)x << C::lj;

@@ -82,6 +82,17 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	const size_t L = leaves.size();
 	if (L == 0 || L > 4096)
 		return 0;
+	// The left-justified kernels keep only (off + 2^29) mod 2^29 per leaf and
+	// recover the residual p_M = p0 - off as a 29-bit signed number
+	// (cordic_device.h: rotator_seeded), so every residual has to fit.  It
+	// does by a wide margin for any real arctan table (|p_M| <= a_{M-1}); it
+	// does not for degenerate ones (e.g. PW = 3, where every angle after the
+	// first truncates to zero): those cores run the full recurrence.
+	for (const Leaf &lf : leaves) {
+		const int64_t lim = ((int64_t)1 << 28) - 1;
+		if (lf.lo - lf.off < -lim || lf.hi - 1 - lf.off > lim)
+			return 0;
+	}
 
 	// largest bucket (2^S phase units) holding at most two leaf boundaries
 	int S = 26;

@@ -70,3 +70,16 @@ def test_ineligible_cores_have_no_table():
     assert ca.seed_table(ca.Config.from_cli(ca.R2P, 13, 13, 2)) is None
     assert ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 3, 32, 16)) is None  # WW 36
     assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 10 stages
+
+
+def test_degenerate_angle_tables_are_not_seeded():
+    """PW = 3: every angle after the first truncates to zero, so the residual
+    after the seed stages can be as large as the folded phase itself -- more
+    than the 29-bit field the left-justified kernels keep.  Such cores must
+    not get a seed table (they run the full recurrence); found by the fuzz
+    (sp2r -i 9 -o 31 -x 3 -p 3 -n 33)."""
+    cfg = ca.Config.from_cli(ca.SP2R, 9, 31, 3, 3, 33)
+    assert cfg.ww == 35 and cfg.nlive == 31
+    assert ca.seed_table(cfg) is None
+    # while ordinary cores of the same width are
+    assert ca.seed_table(ca.Config.from_cli(ca.SP2R, 9, 31, 3, 24, 33)) is not None

@@ -48,7 +48,15 @@ for t in range(ncfg):
         plan = ca.Plan(cfg)
         a = gpu_plan_p2r(plan, x0, y0, ph)
         b = O.rotate(ocfg, x0, y0, ph)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (t, "plan")
+        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            bad = np.nonzero((a[0] != b[0]) | (a[1] != b[1]))[0]
+            raise SystemExit("plan mismatch: cli=%r ww=%d nlive=%d x0=%d y0=%d n=%d "
+                             "first bad %d phase=%#x gpu=(%d,%d) oracle=(%d,%d) "
+                             "(%d bad)" % ((mode, iw, ow, xtra, pw, ns), cfg.ww,
+                                           cfg.nlive, x0, y0, n, bad[0],
+                                           int(ph[bad[0]]), a[0][bad[0]],
+                                           a[1][bad[0]], b[0][bad[0]],
+                                           b[1][bad[0]], bad.size))
         fcw, p0, i0 = int(rng.randint(1 << 32)), int(rng.randint(1 << 32)), int(rng.randint(1 << 40))
         a = gpu_plan_nco(plan, n, p0, fcw, i0, x0, y0)
         b = O.nco(ocfg, n, p0 & 0xffffffff, fcw, i0, x0, y0)
