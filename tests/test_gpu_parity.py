@@ -68,6 +68,8 @@ BASELINE_P2R = {
     "cfg2": (ca.P2R, 32, 32, 2, 32, 16),
     "cfg4": (ca.P2R, 32, 32, 2, 32, 24),
     "cfg5_seq": (ca.SP2R, 32, 32, 2, 32, 16),
+    # PW = 3: angle table degenerates (found by tools/fuzz_gpu.py); no seeds
+    "degenerate_pw3": (ca.SP2R, 9, 31, 3, 3, 33),
     "rtl_cordic": (ca.P2R, 13, 13, 2, -1, -1),
     "rtl_seqcordic": (ca.SP2R, 13, 13, 2, -1, -1),
 }
@@ -487,6 +489,21 @@ def test_plan_for_ineligible_core_still_works():
     a = gpu_plan_p2r(plan, 2**31 - 1, 0, ph)
     b = O.rotate(ocfg, 2**31 - 1, 0, ph)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_plan_for_degenerate_angle_table():
+    """sp2r -i 9 -o 31 -x 3 -p 3 -n 33 (found by tools/fuzz_gpu.py): with a
+    3-bit phase every angle after the first is zero, the residual after the
+    seed stages does not shrink, and the core must not be seeded."""
+    cfg, ocfg = both(ca.SP2R, 9, 31, 3, 3, 33)
+    plan = ca.Plan(cfg)
+    assert plan.seed_info["stages"] == 0
+    rng = np.random.RandomState(4)
+    _, _, ph = rand_inputs(rng, 9, 3, 20003)
+    for x0, y0 in ((55, -256), (255, 0), (-256, -256)):
+        a = gpu_plan_p2r(plan, x0, y0, ph)
+        b = O.rotate(ocfg, x0, y0, ph)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 # ------------------------------------------------ BASELINE sizes, properties
