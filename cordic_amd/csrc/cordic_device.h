@@ -44,6 +44,11 @@ constexpr int kTile = kBlock * kVec;	// samples per block per pass
 constexpr int kSeedBlock = CORDIC_SEED_BLOCK;	// waves of a block share one table
 constexpr int kSeedStages = CORDIC_SEED_STAGES;	// M: stages replaced by the table
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+typedef int16_t i16x4 __attribute__((ext_vector_type(4)));
+
 // Kernel-argument block: wave-uniform, so hipcc keeps it in SGPRs (s_load).
 struct CoreParams {
 	uint32_t angle[CORDIC_AMD_MAX_STAGES];	// left-justified arctan table
@@ -261,6 +266,23 @@ template <int LJ> struct LjConst {
 	static constexpr int first = 32 - LJ;	// first k served by this form
 };
 
+// Left-justify the PW-bit phase words of a lane.  v_lshlrev_b32 is a half-rate
+// instruction and PW = 32 (shift by 0) is the common case, so the shift sits
+// behind a wave-uniform branch; it is written in asm because the compiler
+// knows that a shift by zero is the identity and would fold the branch away.
+__device__ __forceinline__ void left_justify(const u32x4 in, uint32_t (&P)[4],
+		int sh)
+{
+#pragma unroll
+	for (int v = 0; v < 4; v++)
+		P[v] = in[v];
+	if (sh != 0) {
+#pragma unroll
+		for (int v = 0; v < 4; v++)
+			asm("v_lshlrev_b32 %0, %1, %0" : "+v"(P[v]) : "s"(sh));
+	}
+}
+
 // (a & c) | b  and  (a & c) ^ b  as one v_bitop3_b32 each (truth tables with
 // src0 = 0xF0, src1 = 0xCC, src2 = 0xAA): two instructions at 3.3 cycles
 // instead of and + or + xor.  Constants live in VGPRs (VOP3 takes no literal
@@ -414,10 +436,6 @@ __device__ __forceinline__ void apply_unit_gain(V &v, const CoreParams &kp)
 
 // ------------------------------------------------------- memory accessors
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-typedef int16_t i16x4 __attribute__((ext_vector_type(4)));
 
 // Memory containers of the sample arrays.  Io32: int32 / uint32 per value
 // (any port width).  Io16: int16 / uint16 per value for cores whose ports are
@@ -576,9 +594,7 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			for (int v = 1; v < kVec; v++)
 				P[v] = P[v - 1] + kp.fcw;
 		} else {
-#pragma unroll
-			for (int v = 0; v < kVec; v++)
-				P[v] = tph[v] << kp.pw_shl;
+			left_justify(tph, P, kp.pw_shl);
 		}
 
 		int64_t x[kVec], y[kVec], p[kVec];
@@ -787,9 +803,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			for (int v = 1; v < kVec; v++)
 				P[v] = P[v - 1] + kp.fcw;
 		} else {
-#pragma unroll
-			for (int v = 0; v < kVec; v++)
-				P[v] = tph[v] << kp.pw_shl;
+			left_justify(tph, P, kp.pw_shl);
 		}
 
 		// three passes so that the four bucket reads, then the four seed
