@@ -24,12 +24,21 @@
  *        (reference rtl/topolar.v:59-64, bench/cpp/topolar_tb.cpp:127-187)
  *                                                     -> cordic_r2p
  *
+ *  4. around the path, the same generator's other cores and the benches'
+ *     clocking:  -t tbl / -t qtr (sw/sintable.cpp)       -> cordic_table_*
+ *                -t qtbl (sw/quadtbl.cpp, rtl/quadtbl.v)  -> cordic_quad_*
+ *                i_ce / i_reset / i_aux per clock         -> cordic_stream_*
+ *                i_stb / o_busy / o_done per clock        -> cordic_seq_*
+ *                16-bit sample arrays                     -> cordic_*16
+ *
  * Plain pointers and sizes only; no torch / C++ types cross this boundary.
  * All batch entry points take DEVICE pointers (HBM resident) and a HIP stream
  * handle passed as void* (NULL = the null stream); they enqueue work and
  * return without synchronising.  The *_host variants take host pointers and
- * do the PCIe copies themselves.  Every function is re-entrant; the config is
- * an immutable POD the caller owns.
+ * do the PCIe copies themselves.  The stateless functions are re-entrant and
+ * the config is an immutable POD the caller owns; plan / table / quad handles
+ * are read-only after creation and may be shared between threads; a stream or
+ * seq handle carries state and belongs to one caller at a time.
  *
  * Results are bit-exact to the arithmetic of the Verilog the reference
  * generator emits for the same parameters.
