@@ -293,41 +293,52 @@ __global__ __launch_bounds__(kBlock) void stream_fix_phase(uint32_t T,
 	}
 }
 
-// new history = the last L advancing samples of (old history ++ this block)
-__global__ void stream_carry(StreamView v, int32_t *nx, int32_t *ny,
-		uint32_t *nph, uint8_t *naux, uint32_t *nepoch)
+// new history = the last L advancing samples of (old history ++ this block).
+// In place: one block of at least L threads, every thread reads what its slot
+// needs, then all write (so the object has a single set of state buffers and a
+// captured graph of cordic_stream_ticks can be replayed).
+__global__ __launch_bounds__(128) void stream_carry(StreamView v, int32_t *nx,
+		int32_t *ny, uint32_t *nph, uint8_t *naux, uint32_t *nepoch)
 {
 	const int H = v.L;
 	const uint32_t adv = v.A ? v.A[v.T - 1] : v.T;	// advancing clocks here
-	for (int j = threadIdx.x; j < H; j += blockDim.x) {
+	const int j = threadIdx.x;
+	int32_t x = 0, y = 0;
+	uint32_t ph = 0, e = 0;
+	uint8_t ax = 0;
+	if (j < H) {
 		// ordinal (1-based, this block) of history slot j
 		const int64_t k = (int64_t)adv - H + 1 + j;
 		if (k >= 1) {
 			const uint32_t s = v.pos ? v.pos[k - 1] : (uint32_t)(k - 1);
-			nx[j] = v.x[s]; ny[j] = v.y[s];
-			nph[j] = v.phase ? v.phase[s] : 0u;
-			naux[j] = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
+			x = v.x[s]; y = v.y[s];
+			ph = v.phase ? v.phase[s] : 0u;
+			ax = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
 		} else {
 			const int64_t o = H + k - 1;	// slot of the old history
 			if (o >= 0) {
-				nx[j] = v.hx[o]; ny[j] = v.hy[o];
-				nph[j] = v.hph[o]; naux[j] = v.haux[o];
-			} else {
-				nx[j] = 0; ny[j] = 0; nph[j] = 0; naux[j] = 0;
+				x = v.hx[o]; y = v.hy[o];
+				ph = v.hph[o]; ax = v.haux[o];
 			}
 		}
 	}
-	if (threadIdx.x == 0) {
+	if (j == 0) {
 		const int32_t r = v.R ? v.R[v.T - 1] : -1;
-		uint32_t e;
 		if (r >= 0) {
 			e = adv - v.A[r];
 		} else {
 			const uint32_t e0 = *v.epoch;
 			e = (e0 >= kEpochSat || adv >= kEpochSat) ? kEpochSat : e0 + adv;
 		}
-		*nepoch = (e > kEpochSat) ? kEpochSat : e;
+		if (e > kEpochSat)
+			e = kEpochSat;
 	}
+	__syncthreads();
+	if (j < H) {
+		nx[j] = x; ny[j] = y; nph[j] = ph; naux[j] = ax;
+	}
+	if (j == 0)
+		*nepoch = e;
 }
 
 int grid_1d(size_t n)
@@ -395,7 +406,7 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 				0, st, f, n, tile_adv, tile_last, A, R, pos);
 	}
 
-	const int cur = s.cur, nxt = cur ^ 1;
+	const int cur = 0, nxt = 0;		// state is updated in place
 	StreamView v{x, y, rot ? phase : nullptr, aux, s.hx[cur], s.hy[cur],
 			s.hph[cur], s.haux[cur], s.epoch[cur], A, R, pos, n,
 			cfg.nstages + 2};
@@ -420,9 +431,8 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 	}
 	if (rc != CORDIC_OK)
 		return rc;
-	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(64), 0, st, v, s.hx[nxt],
+	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(128), 0, st, v, s.hx[nxt],
 			s.hy[nxt], s.hph[nxt], s.haux[nxt], s.epoch[nxt]);
-	s.cur = nxt;
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 
@@ -674,16 +684,21 @@ __global__ void seq_carry(SeqView v, const int32_t *o0, const int32_t *o1,
 		const uint8_t *oaux, int32_t *npx, int32_t *npy, uint32_t *npph,
 		uint8_t *npaux, int32_t *nl0, int32_t *nl1, uint8_t *nla)
 {
+	// single thread, in place: read, then write
 	const uint32_t acc = v.A[v.T - 1];
-	if (acc == 0) {
-		*npx = *v.px; *npy = *v.py; *npph = *v.pph; *npaux = *v.paux;
-	} else {
+	int32_t x = *v.px, y = *v.py;
+	uint32_t ph = *v.pph;
+	uint8_t ax = *v.paux;
+	if (acc != 0) {
 		const uint32_t s = v.pos[acc - 1];
-		*npx = v.x[s]; *npy = v.y[s];
-		*npph = v.phase ? v.phase[s] : 0u;
-		*npaux = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
+		x = v.x[s]; y = v.y[s];
+		ph = v.phase ? v.phase[s] : 0u;
+		ax = v.aux ? (uint8_t)(v.aux[s] != 0) : (uint8_t)0;
 	}
-	*nl0 = o0[v.T - 1]; *nl1 = o1[v.T - 1]; *nla = oaux[v.T - 1];
+	const int32_t a = o0[v.T - 1], b = o1[v.T - 1];
+	const uint8_t c = oaux[v.T - 1];
+	*npx = x; *npy = y; *npph = ph; *npaux = ax;
+	*nl0 = a; *nl1 = b; *nla = c;
 }
 
 } // namespace
@@ -745,7 +760,7 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 	int32_t *tile_last = reinterpret_cast<int32_t *>(take((size_t)stiles * 4));
 	uint8_t *oa = oaux ? oaux : aux_ws;
 
-	const int cur = s.cur, nxt = cur ^ 1;
+	const int cur = 0, nxt = 0;		// state is updated in place
 	hipLaunchKernelGGL(seq_fsm_tables, dim3(ntiles), dim3(128), 0, st, stb,
 			reset, n, C, gtab);
 	hipLaunchKernelGGL(seq_fsm_spine, dim3(1), dim3(64), 0, st, gtab, ntiles,
@@ -783,7 +798,6 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 	hipLaunchKernelGGL(seq_carry, dim3(1), dim3(1), 0, st, v, o0, o1, oa,
 			s.px[nxt], s.py[nxt], s.pph[nxt], s.paux[nxt], s.l0[nxt],
 			s.l1[nxt], s.la[nxt]);
-	s.cur = nxt;
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 

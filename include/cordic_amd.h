@@ -397,7 +397,10 @@ int	cordic_quad_lookup(const cordic_quad *core, size_t n,
  * A freshly created stream is in the reset state.  The call needs
  * cordic_stream_workspace(T) bytes of device scratch; cordic_stream_reserve
  * allocates it up front, otherwise the first call that needs more allocates
- * (and thereby synchronises).
+ * (and thereby synchronises).  Once reserved a call only enqueues kernels, and
+ * the pipeline state sits in one set of device buffers that the kernels update
+ * in place, so a HIP graph captured around it can be replayed block after
+ * block (the same holds for cordic_seq_ticks).
  */
 typedef struct cordic_stream cordic_stream;
 int	cordic_stream_create(const cordic_config *cfg, cordic_stream **s);

@@ -142,3 +142,67 @@ def test_gpu_stream_long_random_trace_equals_model(mode, iw, ow, pw, ns, flags):
 def test_stream_refuses_sequential_cores():
     with pytest.raises(ca.CordicError):
         ca.Stream(ca.Config.from_cli(ca.SP2R, 13, 13))
+
+
+@pytest.mark.gpu
+def test_clocked_views_replay_from_a_captured_graph():
+    """cordic_stream_ticks / cordic_seq_ticks only enqueue once their scratch
+    is reserved, and their state lives in one set of device buffers updated in
+    place: a captured graph can be replayed, block after block."""
+    import torch
+    from seq_model import SeqModel
+    dev = "cuda:0"
+    n = 5000
+    rng = np.random.RandomState(12)
+    cfg = ca.Config.from_cli(ca.P2R, 13, 13)
+    ocfg = O.config_cli(ca.P2R, 13, 13)
+    scfg = ca.Config.from_cli(ca.SP2R, 13, 13)
+    socfg = O.config_cli(ca.SP2R, 13, 13)
+    t32 = lambda: torch.zeros(n, dtype=torch.int32, device=dev)   # noqa: E731
+    t8 = lambda: torch.zeros(n, dtype=torch.uint8, device=dev)    # noqa: E731
+    x, y, ph, o0, o1, q0, q1 = (t32() for _ in range(7))
+    ce, rs, ax, oa, stb, qb, qd, qa = (t8() for _ in range(8))
+    s, q = ca.Stream(cfg), ca.Seq(scfg)
+    s.reserve(n)
+    q.ticks(stb, x, y, ph, q0, q1, qb, qd, qa, reset=rs, aux=ax)   # reserves
+    s.ticks(x, y, ph, o0, o1, oa, ce=ce, reset=rs, aux=ax)
+    torch.cuda.synchronize()
+    s.reset()
+    q = ca.Seq(scfg)
+    q.ticks(stb, x, y, ph, q0, q1, qb, qd, qa, reset=rs, aux=ax)
+    torch.cuda.synchronize()
+    q = ca.Seq(scfg)
+    lib_reserve = ca.lib().cordic_seq_reserve
+    assert lib_reserve(q._h, n) == 0
+    s.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s.ticks(x, y, ph, o0, o1, oa, ce=ce, reset=rs, aux=ax)
+        q.ticks(stb, x, y, ph, q0, q1, qb, qd, qa, reset=rs, aux=ax)
+    # capture does not execute: both objects are still in their reset state
+    pm, sm = PipeModel(ocfg, True), SeqModel(socfg, True)
+    for block in range(3):
+        hx = rng.randint(-4096, 4096, n)
+        hy = rng.randint(-4096, 4096, n)
+        hp = rng.randint(0, 1 << cfg.pw, n)
+        hce = (rng.randint(0, 3, n) != 0).astype(np.uint8)
+        hrs = (rng.randint(0, 900, n) == 0).astype(np.uint8)
+        hax = rng.randint(0, 2, n).astype(np.uint8)
+        hstb = (rng.randint(0, 4, n) == 0).astype(np.uint8)
+        for t, h in ((x, hx), (y, hy), (ph, hp)):
+            t.copy_(torch.from_numpy(h.astype(np.int32)))
+        for t, h in ((ce, hce), (rs, hrs), (ax, hax), (stb, hstb)):
+            t.copy_(torch.from_numpy(h))
+        g.replay()
+        torch.cuda.synchronize()
+        m0, m1, ma = pm.run(hx, hy, hp, hce, hrs, hax)
+        assert np.array_equal(o0.cpu().numpy(), m0)
+        assert np.array_equal(o1.cpu().numpy(), m1)
+        assert np.array_equal(oa.cpu().numpy(), ma)
+        w0, w1, wa, wb, wd = sm.run(hstb, hx, hy, hp, hrs, hax)
+        assert np.array_equal(q0.cpu().numpy(), w0)
+        assert np.array_equal(q1.cpu().numpy(), w1)
+        assert np.array_equal(qa.cpu().numpy(), wa)
+        assert np.array_equal(qb.cpu().numpy(), wb)
+        assert np.array_equal(qd.cpu().numpy(), wd)
