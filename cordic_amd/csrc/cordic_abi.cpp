@@ -428,15 +428,9 @@ void cordic_stream_destroy(cordic_stream *s)
 	if (!s)
 		return;
 	StreamState &t = s->st;
-	for (int k = 0; k < 2; k++) {
-		if (t.hx[k]) (void)hipFree(t.hx[k]);
-		if (t.hy[k]) (void)hipFree(t.hy[k]);
-		if (t.hph[k]) (void)hipFree(t.hph[k]);
-		if (t.haux[k]) (void)hipFree(t.haux[k]);
-		if (t.epoch[k]) (void)hipFree(t.epoch[k]);
-	}
-	if (t.born_phase) (void)hipFree(t.born_phase);
-	if (t.ws) (void)hipFree(t.ws);
+	void *ptrs[] = { t.hx, t.hy, t.hph, t.haux, t.epoch, t.born_phase, t.ws };
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
 	delete s;
 }
 
@@ -453,19 +447,13 @@ int cordic_stream_create(const cordic_config *cfg, cordic_stream **out)
 	const int L = cfg->nstages + 2;
 	s->latency = L;
 	StreamState &t = s->st;
-	bool ok = true;
-	for (int k = 0; k < 2 && ok; k++) {
-		ok = hipMalloc((void **)&t.hx[k], L * 4) == hipSuccess
-			&& hipMalloc((void **)&t.hy[k], L * 4) == hipSuccess
-			&& hipMalloc((void **)&t.hph[k], L * 4) == hipSuccess
-			&& hipMalloc((void **)&t.haux[k], L) == hipSuccess
-			&& hipMalloc((void **)&t.epoch[k], 4) == hipSuccess
-			&& hipMemset(t.hx[k], 0, L * 4) == hipSuccess
-			&& hipMemset(t.hy[k], 0, L * 4) == hipSuccess
-			&& hipMemset(t.hph[k], 0, L * 4) == hipSuccess
-			&& hipMemset(t.haux[k], 0, L) == hipSuccess
-			&& hipMemset(t.epoch[k], 0, 4) == hipSuccess;
-	}
+	auto zalloc = [](auto **p, size_t bytes) {
+		return hipMalloc((void **)p, bytes) == hipSuccess
+			&& hipMemset(*p, 0, bytes) == hipSuccess;
+	};
+	bool ok = zalloc(&t.hx, (size_t)L * 4) && zalloc(&t.hy, (size_t)L * 4)
+		&& zalloc(&t.hph, (size_t)L * 4) && zalloc(&t.haux, (size_t)L)
+		&& zalloc(&t.epoch, 4);
 	// rtl/topolar.v:235-243 on cleared registers: the phase accumulator of a
 	// stage born at reset still collects angle[i] of every live stage it
 	// passes; after e enabled clocks the output register shows the one born
@@ -518,7 +506,7 @@ int cordic_stream_reset(cordic_stream *s, void *stream)
 {
 	if (!s)
 		return CORDIC_ERR_ARGS;
-	return (hipMemsetAsync(s->st.epoch[s->st.cur], 0, 4,
+	return (hipMemsetAsync(s->st.epoch, 0, 4,
 			static_cast<hipStream_t>(stream)) == hipSuccess)
 		? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
@@ -547,14 +535,10 @@ void cordic_seq_destroy(cordic_seq *s)
 	if (!s)
 		return;
 	SeqState &t = s->st;
-	for (int k = 0; k < 2; k++) {
-		void *ptrs[] = { t.c[k], t.px[k], t.py[k], t.pph[k], t.paux[k],
-				 t.l0[k], t.l1[k], t.la[k] };
-		for (void *p : ptrs)
-			if (p) (void)hipFree(p);
-	}
-	if (t.violations) (void)hipFree(t.violations);
-	if (t.ws) (void)hipFree(t.ws);
+	void *ptrs[] = { t.c, t.px, t.py, t.pph, t.paux, t.l0, t.l1, t.la,
+			 t.violations, t.ws };
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
 	delete s;
 }
 
@@ -573,12 +557,10 @@ int cordic_seq_create(const cordic_config *cfg, cordic_seq **out)
 		return hipMalloc((void **)p, bytes) == hipSuccess
 			&& hipMemset(*p, 0, bytes) == hipSuccess;
 	};
-	bool ok = zalloc(&t.violations, 8);
-	for (int k = 0; k < 2 && ok; k++)
-		ok = zalloc(&t.c[k], 4) && zalloc(&t.px[k], 4) && zalloc(&t.py[k], 4)
-			&& zalloc(&t.pph[k], 4) && zalloc(&t.paux[k], 4)
-			&& zalloc(&t.l0[k], 4) && zalloc(&t.l1[k], 4)
-			&& zalloc(&t.la[k], 4);
+	const bool ok = zalloc(&t.violations, 8) && zalloc(&t.c, 4)
+		&& zalloc(&t.px, 4) && zalloc(&t.py, 4) && zalloc(&t.pph, 4)
+		&& zalloc(&t.paux, 4) && zalloc(&t.l0, 4) && zalloc(&t.l1, 4)
+		&& zalloc(&t.la, 4);
 	if (!ok) {
 		cordic_seq_destroy(s);
 		return CORDIC_ERR_DEVICE;

@@ -96,14 +96,13 @@ int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 struct StreamState {
 	void	*ws = nullptr;		// scan / gather workspace
 	size_t	ws_bytes = 0;
-	// the L = NSTAGES+2 samples inside the pipeline (double buffered) and
-	// the number of advancing clocks since the last reset, all on the device
-	int32_t	 *hx[2] = {nullptr, nullptr}, *hy[2] = {nullptr, nullptr};
-	uint32_t *hph[2] = {nullptr, nullptr};
-	uint8_t	 *haux[2] = {nullptr, nullptr};
-	uint32_t *epoch[2] = {nullptr, nullptr};
+	// the L = NSTAGES+2 samples inside the pipeline and the number of
+	// advancing clocks since the last reset; on the device, updated in place
+	int32_t	 *hx = nullptr, *hy = nullptr;
+	uint32_t *hph = nullptr;
+	uint8_t	 *haux = nullptr;
+	uint32_t *epoch = nullptr;
 	uint32_t *born_phase = nullptr;	// topolar: o_phase of a cleared stage
-	int	cur = 0;
 };
 size_t	stream_workspace_bytes(size_t ticks);
 int	launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
@@ -114,16 +113,15 @@ int	launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 struct SeqState {
 	void	*ws = nullptr;
 	size_t	ws_bytes = 0;
-	// device-resident, double buffered: clocks left until the sample in
+	// device-resident, updated in place: clocks left until the sample in
 	// flight loads (0 = idle), that sample, and the output registers
-	uint32_t *c[2] = {nullptr, nullptr};
-	int32_t	 *px[2] = {nullptr, nullptr}, *py[2] = {nullptr, nullptr};
-	uint32_t *pph[2] = {nullptr, nullptr};
-	uint8_t	 *paux[2] = {nullptr, nullptr};
-	int32_t	 *l0[2] = {nullptr, nullptr}, *l1[2] = {nullptr, nullptr};
-	uint8_t	 *la[2] = {nullptr, nullptr};
+	uint32_t *c = nullptr;
+	int32_t	 *px = nullptr, *py = nullptr;
+	uint32_t *pph = nullptr;
+	uint8_t	 *paux = nullptr;
+	int32_t	 *l0 = nullptr, *l1 = nullptr;
+	uint8_t	 *la = nullptr;
 	unsigned long long *violations = nullptr;
-	int	cur = 0;
 };
 size_t	seq_workspace_bytes(size_t ticks);
 int	launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,

@@ -406,10 +406,8 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 				0, st, f, n, tile_adv, tile_last, A, R, pos);
 	}
 
-	const int cur = 0, nxt = 0;		// state is updated in place
-	StreamView v{x, y, rot ? phase : nullptr, aux, s.hx[cur], s.hy[cur],
-			s.hph[cur], s.haux[cur], s.epoch[cur], A, R, pos, n,
-			cfg.nstages + 2};
+	StreamView v{x, y, rot ? phase : nullptr, aux, s.hx, s.hy, s.hph, s.haux,
+			s.epoch, A, R, pos, n, cfg.nstages + 2};
 	hipLaunchKernelGGL(stream_gather, dim3(grid_1d(n)), dim3(kBlock), 0, st, v,
 			gx, gy, rot ? gph : nullptr, born, oaux);
 	if (hipGetLastError() != hipSuccess)
@@ -431,8 +429,8 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 	}
 	if (rc != CORDIC_OK)
 		return rc;
-	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(128), 0, st, v, s.hx[nxt],
-			s.hy[nxt], s.hph[nxt], s.haux[nxt], s.epoch[nxt]);
+	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(128), 0, st, v, s.hx, s.hy,
+			s.hph, s.haux, s.epoch);		// in place
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 
@@ -760,11 +758,10 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 	int32_t *tile_last = reinterpret_cast<int32_t *>(take((size_t)stiles * 4));
 	uint8_t *oa = oaux ? oaux : aux_ws;
 
-	const int cur = 0, nxt = 0;		// state is updated in place
 	hipLaunchKernelGGL(seq_fsm_tables, dim3(ntiles), dim3(128), 0, st, stb,
 			reset, n, C, gtab);
 	hipLaunchKernelGGL(seq_fsm_spine, dim3(1), dim3(64), 0, st, gtab, ntiles,
-			s.c[cur], entry, s.c[nxt]);
+			s.c, entry, s.c);			// in place
 	hipLaunchKernelGGL(seq_fsm_emit, dim3((ntiles + 63) / 64), dim3(64), 0, st,
 			stb, reset, n, C, entry, ntiles, accept, load, busy, done,
 			s.violations);
@@ -775,8 +772,8 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 			tile_adv, tile_last, stiles);
 	hipLaunchKernelGGL(stream_tile_apply, dim3(stiles), dim3(kScanThreads), 0,
 			st, f, n, tile_adv, tile_last, A, R, pos);
-	SeqView v{x, y, rot ? phase : nullptr, aux, s.px[cur], s.py[cur],
-			s.pph[cur], s.paux[cur], A, R, pos, n};
+	SeqView v{x, y, rot ? phase : nullptr, aux, s.px, s.py, s.pph, s.paux, A,
+			R, pos, n};
 	hipLaunchKernelGGL(seq_gather, dim3(grid_1d(n)), dim3(kBlock), 0, st, v, gx,
 			gy, rot ? gph : nullptr, held, oa);
 	if (hipGetLastError() != hipSuccess)
@@ -794,10 +791,9 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 	if (rc != CORDIC_OK)
 		return rc;
 	hipLaunchKernelGGL(seq_fix_held, dim3(grid_1d(n)), dim3(kBlock), 0, st, n,
-			held, s.l0[cur], s.l1[cur], s.la[cur], o0, o1, oa);
-	hipLaunchKernelGGL(seq_carry, dim3(1), dim3(1), 0, st, v, o0, o1, oa,
-			s.px[nxt], s.py[nxt], s.pph[nxt], s.paux[nxt], s.l0[nxt],
-			s.l1[nxt], s.la[nxt]);
+			held, s.l0, s.l1, s.la, o0, o1, oa);
+	hipLaunchKernelGGL(seq_carry, dim3(1), dim3(1), 0, st, v, o0, o1, oa, s.px,
+			s.py, s.pph, s.paux, s.l0, s.l1, s.la);	// in place
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 
