@@ -141,3 +141,63 @@ def test_gpu_exhaustive_checked_in_core_and_bench_criterion():
                                              np.arange(n, dtype=np.uint32)))
     want = np.sin(np.arange(n) * (2 * math.pi / n)) * ((1 << 12) - 1)
     assert np.abs(want - got).max() <= abs(core.tbl_err) + 2.0
+
+
+GEN = os.path.join(O.ORACLE_DIR, "_ref", "gencordic")
+
+
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref not built")
+def test_fresh_random_quadtbl_cores_against_the_live_generator(tmp_path):
+    """Beyond the committed goldens: random -o / -x / -p, the real generator
+    run on the spot, its Verilog executed by vsim.py -- the oracle and the
+    product's host layer must agree with localparams, tables and samples, and
+    refuse exactly the cores whose RTL cannot elaborate."""
+    import subprocess
+    import vsim
+    rng = np.random.RandomState(int.from_bytes(os.urandom(4), "little"))
+    done = 0
+    for trial in range(40):
+        ow = int(rng.randint(3, 27))
+        xtra = int(rng.randint(0, 4))
+        pw = int(rng.choice([-1, int(rng.randint(8, 33))]))
+        args = ["-t", "qtbl", "-o", str(ow), "-x", str(xtra)] + (
+            ["-p", str(pw)] if pw > 0 else [])
+        vf = tmp_path / ("q%d.v" % trial)
+        r = subprocess.run([GEN, "-a", "-c"] + args + ["-f", str(vf)],
+                           capture_output=True, text=True)
+        ok_ref = r.returncode == 0 and vf.exists()
+        lp = {}
+        if ok_ref:
+            lp = {k: int(v) for k, v in re.findall(
+                r"\b(PW|OW|XTRA|LGTBL|QBITS|LBITS|CBITS)\s*=\s*(\d+)",
+                vf.read_text())}
+            if lp["CBITS"] < lp["OW"] + lp["XTRA"] or \
+                    lp["PW"] - lp["LGTBL"] + 1 < 2:
+                ok_ref = False          # emitted, but cannot elaborate
+        try:
+            q = ca.Quad(-1, ow, xtra, pw, device=False)
+        except ca.CordicError:
+            with pytest.raises(ValueError):
+                O.quad_cli(-1, ow, xtra, pw)
+            assert not ok_ref, (args, lp)
+            continue
+        assert ok_ref, (args, r.stderr[-300:])
+        oq = O.quad_cli(-1, ow, xtra, pw)
+        for obj in (q, oq):
+            assert (obj.pw, obj.ow, obj.xtra, obj.lgtbl, obj.qbits, obj.lbits,
+                    obj.cbits) == (lp["PW"], lp["OW"], lp["XTRA"], lp["LGTBL"],
+                                   lp["QBITS"], lp["LBITS"], lp["CBITS"]), args
+        ot = O.quad_tables(oq)
+        for a, b in zip(q.tables(), ot):
+            assert np.array_equal(a, b)
+        m = vsim.Module(vf.read_text(), readmem_dir=str(tmp_path))
+        ph = rng.randint(0, 1 << lp["PW"], 200, dtype=np.int64)
+        ph[:4] = [0, (1 << lp["PW"]) - 1, 1 << (lp["PW"] - 2),
+                  3 << (lp["PW"] - 2)]
+        res = vsim.run_pipelined(m, [dict(i_phase=int(p)) for p in ph])
+        want = [x["o_sin"] for x in res]
+        assert O.quad_lookup(oq, ot, ph.astype(np.uint32)).tolist() == want, args
+        done += 1
+        if done >= 6:
+            break
+    assert done >= 3
