@@ -206,3 +206,94 @@ def test_clocked_views_replay_from_a_captured_graph():
         assert np.array_equal(qa.cpu().numpy(), wa)
         assert np.array_equal(qb.cpu().numpy(), wb)
         assert np.array_equal(qd.cpu().numpy(), wd)
+
+
+GEN = os.path.join(O.ORACLE_DIR, "_ref", "gencordic")
+
+
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref not built")
+def test_fresh_random_cores_clocked_by_vsim_match_the_models(tmp_path):
+    """Beyond the committed traces: random pipelined AND sequential cores from
+    the live generator, clocked by vsim.py under random activity, against the
+    register model / the handshake model."""
+    import re
+    import subprocess
+    import vsim
+    from seq_model import SeqModel
+    rng = np.random.RandomState(int.from_bytes(os.urandom(4), "little"))
+    done = {"pipe": 0, "seq": 0}
+    names = {ca.P2R: "p2r", ca.R2P: "r2p", ca.SP2R: "sp2r", ca.SR2P: "sr2p"}
+    for trial in range(60):
+        mode = int(rng.choice([ca.P2R, ca.R2P, ca.SP2R, ca.SR2P]))
+        kind = "pipe" if mode in (ca.P2R, ca.R2P) else "seq"
+        if done[kind] >= 2:
+            if all(v >= 2 for v in done.values()):
+                break
+            continue
+        iw, ow = int(rng.randint(4, 20)), int(rng.randint(4, 20))
+        xtra, pw = int(rng.randint(1, 4)), int(rng.randint(8, 25))
+        ns = int(rng.randint(4, 22))
+        try:
+            ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
+        except ValueError:
+            continue
+        args = ["-a", "-t", names[mode], "-i", str(iw), "-o", str(ow), "-x",
+                str(xtra), "-p", str(pw), "-n", str(ns)]
+        vf = tmp_path / ("c%d.v" % trial)
+        subprocess.run([GEN] + args + ["-c", "-f", str(vf)], check=True,
+                       capture_output=True)
+        text = vf.read_text().replace("// }}}\talways", "// }}}\n\talways")
+        m = vsim.Module(text)
+        rot = mode in (ca.P2R, ca.SP2R)
+        n = 500
+        lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+        x, y = rng.randint(lo, hi, n), rng.randint(lo, hi, n)
+        ph = rng.randint(0, 1 << pw, n, dtype=np.int64)
+        aux = rng.randint(0, 2, n).astype(np.uint8)
+        rs = (rng.randint(0, 120, n) == 0).astype(np.uint8)
+        outs = ["o_xval", "o_yval"] if rot else ["o_mag", "o_phase"]
+        got = {k: [] for k in outs + ["o_aux"]}
+        if kind == "pipe":
+            ce = (rng.randint(0, 3, n) != 0).astype(np.uint8)
+            for t in range(n):
+                pins = dict(i_xval=int(x[t]), i_yval=int(y[t]), i_ce=int(ce[t]),
+                            i_reset=int(rs[t]), i_aux=int(aux[t]))
+                if rot:
+                    pins["i_phase"] = int(ph[t])
+                m.tick(**pins)
+                for k in outs:
+                    v = m.out(k)
+                    got[k].append(v & ((1 << pw) - 1) if k == "o_phase" else v)
+                got["o_aux"].append(int(m.get("o_aux")))
+            w0, w1, wa = PipeModel(ocfg, rot).run(x, y, ph, ce, rs, aux)
+        else:
+            cpo = ocfg.clocks_per_output
+            stb = (rng.rand(n) < rng.choice([1.0, 0.3, 0.05])).astype(np.uint8)
+            got.update(o_busy=[], o_done=[])
+            left = 0
+            for t in range(n):
+                if left == 1 and not rs[t]:
+                    stb[t] = 0          # keep to the protocol on this clock
+                pins = dict(i_xval=int(x[t]), i_yval=int(y[t]),
+                            i_stb=int(stb[t]), i_reset=int(rs[t]),
+                            i_aux=int(aux[t]))
+                if rot:
+                    pins["i_phase"] = int(ph[t])
+                idle = not m.get("o_busy")
+                m.tick(**pins)
+                left = 0 if rs[t] else (
+                    (cpo - 1 if (stb[t] and idle) else 0) if left == 0
+                    else left - 1)
+                for k in outs:
+                    v = m.out(k)
+                    got[k].append(v & ((1 << pw) - 1) if k == "o_phase" else v)
+                for k in ("o_aux", "o_busy", "o_done"):
+                    got[k].append(int(m.get(k)))
+            w0, w1, wa, wb, wd = SeqModel(ocfg, rot).run(stb, x, y, ph, rs, aux)
+            assert wb.tolist() == got["o_busy"], args
+            assert wd.tolist() == got["o_done"], args
+        assert w0.tolist() == got[outs[0]], args
+        assert w1.tolist() == got[outs[1]], args
+        assert wa.tolist() == got["o_aux"], args
+        done[kind] += 1
+    assert done["pipe"] >= 1 and done["seq"] >= 1
