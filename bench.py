@@ -519,6 +519,31 @@ def main():
         dist.gather(ab, outs, dst=0)
         barrier()
         gather_ms = (time.perf_counter() - t1) * 1e3
+        del outs, ab
+        # end to end, pipelined: one step computed in 8 chunks, every chunk's
+        # outputs sent to rank 0 on a side stream while the next chunk is
+        # being computed (cordic_amd/shard.py:pipelined_gather)
+        gather_pipelined = None
+        if w["kind"] == "p2r":
+            from cordic_amd.shard import pipelined_gather
+            a3, b3 = torch.zeros_like(a), torch.zeros_like(b)
+            comm = torch.cuda.Stream(device=dev)
+
+            def compute_chunk(lo, hi):
+                plan.p2r_const(x0, y0, phase[lo:hi], a3[lo:hi], b3[lo:hi])
+            barrier()
+            t1 = time.perf_counter()
+            got = pipelined_gather(compute_chunk, [a3, b3], chunks=8, dst=0,
+                                   comm_stream=comm)
+            barrier()
+            ms = (time.perf_counter() - t1) * 1e3
+            ok = bool(torch.equal(a3, a) and torch.equal(b3, b))
+            if rank == 0:
+                ok = ok and bool(torch.equal(got[0][0], a)
+                                 and torch.equal(got[1][0], b))
+            gather_pipelined = {"ms_compute_and_gather": ms, "chunks": 8,
+                                "outputs_identical": ok}
+            del got, a3, b3
 
     if rank == 0:
         total = float(world) * n * args.steps
@@ -581,6 +606,8 @@ def main():
             out["full_recurrence_kernel"] = full
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
+            if gather_pipelined is not None:
+                out["gather_pipelined"] = gather_pipelined
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         if world == 1 and args.workload == "cfg2" and not args.no_other_paths:

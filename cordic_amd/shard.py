@@ -9,7 +9,10 @@ data path.  The only collectives are after the fact:
   * reduce_digest(): all-reduce (sum mod 2^64) of per-shard digests -- digests
     are position-aware and additive, so the sum equals the digest of the whole;
   * gather_to_root(): collect the output shards on one rank (RCCL gather over
-    xGMI on GPUs, gloo on CPU) when a single consumer needs them.
+    xGMI on GPUs, gloo on CPU) when a single consumer needs them;
+  * pipelined_gather(): the same, chunk by chunk, each chunk's gather enqueued
+    as soon as that chunk has been computed, so that the transfer of chunk k
+    overlaps the computation of chunk k+1.
 
 The reference has no counterpart (single process); this
 is new work for the 8-GPU configuration of BASELINE.json.
@@ -60,3 +63,66 @@ def gather_to_root(shard, n_total, dst=0, group=None):
     if rank != dst:
         return None
     return torch.cat([o[:c] for o, c in zip(outs, counts)])
+
+
+def chunk_ranges(n, chunks):
+    """`chunks` contiguous [start, stop) pieces of range(n), sizes differing by
+    at most one (the first n % chunks pieces are the longer ones); empty
+    pieces are dropped."""
+    out = []
+    for k in range(chunks):
+        a, c = shard_range(n, k, chunks)
+        if c:
+            out.append((a, a + c))
+    return out
+
+
+def pipelined_gather(compute_chunk, shards, chunks=8, dst=0, group=None,
+                     comm_stream=None):
+    """Compute and collect equally sized 1-D output shards chunk by chunk.
+
+    compute_chunk(start, stop) enqueues the computation of samples
+    [start, stop) of every tensor in `shards` (same length n on every rank) on
+    the CURRENT stream.  After each chunk its slices are gathered on rank
+    `dst` asynchronously -- on `comm_stream` when given (a CUDA/HIP side
+    stream that first waits for the chunk's kernels), so the transfer runs
+    while the next chunk is being computed.  Returns, on `dst`, one list per
+    shard tensor holding every rank's full-length copy (rank order), and None
+    elsewhere.  Every rank must call it with the same n and chunking.
+    """
+    n = shards[0].numel()
+    pieces = chunk_ranges(n, chunks)
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    gathered = None
+    if rank == dst:
+        gathered = [[torch.empty_like(t) for _ in range(world)] for t in shards]
+    works = []
+    for a, b in pieces:
+        compute_chunk(a, b)
+        if not live:
+            if gathered is not None:
+                for t, g in zip(shards, gathered):
+                    g[0][a:b].copy_(t[a:b])
+            continue
+        ctx = None
+        if comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()                       # chunk's kernels, current stream
+            comm_stream.wait_event(ev)
+            ctx = torch.cuda.stream(comm_stream)
+            ctx.__enter__()
+        try:
+            for i, t in enumerate(shards):
+                outs = None
+                if rank == dst:
+                    outs = [g[a:b] for g in gathered[i]]
+                works.append(dist.gather(t[a:b], outs, dst=dst, group=group,
+                                         async_op=True))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+    for w in works:
+        w.wait()
+    return gathered

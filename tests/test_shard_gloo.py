@@ -10,7 +10,7 @@ import textwrap
 
 import numpy as np
 
-from cordic_amd.shard import shard_range
+from cordic_amd.shard import chunk_ranges, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,13 +27,23 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_chunk_ranges_cover_without_overlap():
+    for n in (0, 1, 5, 8, 4099, 1 << 30):
+        for k in (1, 3, 8, 16):
+            pieces = chunk_ranges(n, k)
+            assert [a for a, _ in pieces[1:]] == [b for _, b in pieces[:-1]]
+            assert (pieces[0][0], pieces[-1][1]) == (0, n) if n else not pieces
+            assert all(b > a for a, b in pieces)
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
     import numpy as np, torch, torch.distributed as dist
     import oracle_lib as O
     from gpu_util import cpu_digest
-    from cordic_amd.shard import shard_range, reduce_digest, gather_to_root
+    from cordic_amd.shard import (shard_range, reduce_digest, gather_to_root,
+                                  pipelined_gather)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = 100003
@@ -46,6 +56,22 @@ WORKER = textwrap.dedent("""
     total = reduce_digest(local)
     gx = gather_to_root(torch.from_numpy(ox), N)
     gy = gather_to_root(torch.from_numpy(oy), N)
+    # equal shards computed and collected chunk by chunk (the bench's --gather)
+    M = 4099
+    gph = ((np.arange(M, dtype=np.uint64) + np.uint64(rank * M))
+           & np.uint64(0xffffffff)).astype(np.uint32)
+    px, py = torch.zeros(M, dtype=torch.int32), torch.zeros(M, dtype=torch.int32)
+    def compute(a, b):
+        cx, cy = O.rotate(cfg, 2**31 - 1, 0, gph[a:b])
+        px[a:b] = torch.from_numpy(cx); py[a:b] = torch.from_numpy(cy)
+    got = pipelined_gather(compute, [px, py], chunks=7)
+    if rank == 0:
+        allph = (np.arange(world * M, dtype=np.uint64) & np.uint64(0xffffffff)).astype(np.uint32)
+        wx, wy = O.rotate(cfg, 2**31 - 1, 0, allph)
+        assert np.array_equal(torch.cat(got[0]).numpy(), wx)
+        assert np.array_equal(torch.cat(got[1]).numpy(), wy)
+    else:
+        assert got is None
     if rank == 0:
         ph_all = (np.arange(N, dtype=np.uint64) & np.uint64(0xffffffff)).astype(np.uint32)
         rx, ry = O.rotate(cfg, 2**31 - 1, 0, ph_all)
