@@ -281,6 +281,14 @@ __global__ __launch_bounds__(kBlock) void stream_gather(StreamView v,
 	}
 }
 
+__global__ __launch_bounds__(kBlock) void stream_shift_aux(const uint8_t *aux,
+		uint8_t *oaux, uint32_t n)
+{
+	const uint32_t stride = gridDim.x * kBlock;
+	for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n; t += stride)
+		oaux[t] = (uint8_t)(aux[t] != 0);
+}
+
 // topolar: o_phase of the clocks whose output register holds a cleared stage
 __global__ __launch_bounds__(kBlock) void stream_fix_phase(uint32_t T,
 		const uint8_t *born, const uint32_t *born_phase, uint32_t *ophase)
@@ -406,10 +414,20 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 				0, st, f, n, tile_adv, tile_last, A, R, pos);
 	}
 
+	const int L = cfg.nstages + 2;
 	StreamView v{x, y, rot ? phase : nullptr, aux, s.hx, s.hy, s.hph, s.haux,
-			s.epoch, A, R, pos, n, cfg.nstages + 2};
-	hipLaunchKernelGGL(stream_gather, dim3(grid_1d(n)), dim3(kBlock), 0, st, v,
-			gx, gy, rot ? gph : nullptr, born, oaux);
+			s.epoch, A, R, pos, n, L};
+	// Every clock enabled: from clock L-1 on the output register holds
+	// f(input of clock t-L+1) whatever came before the block, so the bulk is
+	// the batch kernel on the caller's arrays displaced by L-1 samples (the
+	// vector kernels take element-aligned pointers); only the first L-1
+	// clocks need the history.
+	const bool direct = (A == nullptr) && n > (uint32_t)(L - 1);
+	const uint32_t head = direct ? (uint32_t)(L - 1) : n;
+	StreamView hv = v;
+	hv.T = head;
+	hipLaunchKernelGGL(stream_gather, dim3(grid_1d(head)), dim3(kBlock), 0, st,
+			hv, gx, gy, rot ? gph : nullptr, born, oaux);
 	if (hipGetLastError() != hipSuccess)
 		return CORDIC_ERR_DEVICE;
 
@@ -417,18 +435,35 @@ int launch_stream_ticks(const cordic_config &cfg, StreamState &s, size_t T,
 	if (rot) {
 		RotatorJob j;
 		j.x = gx; j.y = gy; j.phase = gph;
-		j.ox = o0; j.oy = o1; j.n = n;
+		j.ox = o0; j.oy = o1; j.n = head;
 		rc = launch_rotator(cfg, Feed::PhaseArray_XYArray, j, stream);
+		if (rc == CORDIC_OK && direct) {
+			RotatorJob b;
+			b.x = x; b.y = y; b.phase = phase;
+			b.ox = o0 + head; b.oy = o1 + head; b.n = n - head;
+			rc = launch_rotator(cfg, Feed::PhaseArray_XYArray, b, stream);
+		}
 	} else {
-		rc = launch_topolar(cfg, n, gx, gy, o0, reinterpret_cast<uint32_t *>(o1),
-				stream);
+		rc = launch_topolar(cfg, head, gx, gy, o0,
+				reinterpret_cast<uint32_t *>(o1), stream);
 		if (rc == CORDIC_OK)
-			hipLaunchKernelGGL(stream_fix_phase, dim3(grid_1d(n)),
-					dim3(kBlock), 0, st, n, born, s.born_phase,
+			hipLaunchKernelGGL(stream_fix_phase, dim3(grid_1d(head)),
+					dim3(kBlock), 0, st, head, born, s.born_phase,
 					reinterpret_cast<uint32_t *>(o1));
+		if (rc == CORDIC_OK && direct)
+			rc = launch_topolar(cfg, n - head, x, y, o0 + head,
+					reinterpret_cast<uint32_t *>(o1) + head, stream);
 	}
 	if (rc != CORDIC_OK)
 		return rc;
+	if (direct && oaux) {
+		// o_aux[t] = i_aux[t-L+1]
+		if (aux)
+			hipLaunchKernelGGL(stream_shift_aux, dim3(grid_1d(n - head)),
+					dim3(kBlock), 0, st, aux, oaux + head, n - head);
+		else if (hipMemsetAsync(oaux + head, 0, n - head, st) != hipSuccess)
+			return CORDIC_ERR_DEVICE;
+	}
 	hipLaunchKernelGGL(stream_carry, dim3(1), dim3(128), 0, st, v, s.hx, s.hy,
 			s.hph, s.haux, s.epoch);		// in place
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
