@@ -74,6 +74,31 @@ WORKLOADS = {
 MODE = {"p2r": 0, "r2p": 1, "sp2r": 2, "sr2p": 3}
 
 
+def _usable_cpus():
+    """Hardware threads this process may actually use: the affinity mask, cut
+    down to the cgroup CPU quota (the gpurun boxes show 256 CPUs but grant
+    16 CPU-seconds per second; 256 busy threads under that quota measured
+    half the rate of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(workload, seconds=12.0):
     """The oracle (a restatement of the reference RTL, NOT reference code:
     the reference has no CPU compute path) timed on
@@ -89,7 +114,7 @@ def cpu_baseline(workload, seconds=12.0):
     m, iw, ow, xtra, pw, ns = w["cli"]
     ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
     L = O.lib()
-    cores = os.cpu_count() or 1
+    cores = _usable_cpus()
     kind = 1 if w["kind"] == "r2p" else 0
     mul = 0x01234567 if w["kind"] == "nco" else (1 << w.get("shift", 0))
     x0 = (1 << (iw - 1)) - 1
@@ -111,6 +136,7 @@ def cpu_baseline(workload, seconds=12.0):
                                                       seconds),
         "value_1thread": one / 1e6,
         "cpu": _cpu_model(),
+        "cpus_visible": os.cpu_count(),
     }
 
 
