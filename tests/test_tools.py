@@ -152,3 +152,28 @@ def test_cordic_tb_quadtbl_report():
     assert "MNVAL: 0x%08x" % (int(out.min()) & 0xffffffff) in r.stdout
     sfdr = float(re.search(r"SFDR = +([\d.]+)", r.stdout).group(1))
     assert sfdr > 80.0
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/cordic_amd.h must compile as C, not only as C++: the boundary
+    is a C ABI (examples/sincos.c is a C99 caller)."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "cordic_amd.h"\nint main(void) { cordic_config c; '
+                   'return cordic_config_init(&c, CORDIC_P2R, 13, 13, 2, -1, -1); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic",
+                        "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs():
+    exe = os.path.join(ROOT, "tools", "sincos")
+    if not os.path.exists(exe):
+        pytest.skip("tools/sincos not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "phase 0: (2385, 0)" in r.stdout        # SURVEY 8c structural value
+    r = subprocess.run([exe, "-i", "32", "-o", "32", "-p", "32", "-n", "16"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
