@@ -28,6 +28,10 @@ namespace cordic_amd {
 // The scale factor is evaluated first and x multiplied by it, as there.
 uint32_t arctan_entry(unsigned k, int phase_bits)
 {
+	// the library helpers (cordic_angles, cordic_calc_stages) are callable
+	// with any integer; the reference shifts by PW-2 unguarded
+	if (phase_bits < 2 || phase_bits > 62)
+		return 0;
 	const double scale = (4.0 * (double)(1ul << (phase_bits - 2)))
 				/ (M_PI * 2.0);
 	double x = std::atan2(1., std::pow(2, k + 1));
@@ -39,7 +43,8 @@ uint32_t arctan_entry(unsigned k, int phase_bits)
 double rotation_gain(int nstages)
 {
 	double g = 1.0;
-	for (int k = 0; k < nstages; k++)
+	// the factor is exactly 1.0 from k = 27 on: no need to follow a huge count
+	for (int k = 0; k < nstages && k < 1024; k++)
 		g = g * std::sqrt(1.0 + std::pow(2.0, -2. * (k + 1)));
 	return g;
 }
@@ -67,6 +72,11 @@ uint32_t core_gain_annihilator(const cordic_config &c)
 // sw/cordiclib.cpp:82-109.
 double phase_variance(int nstages, int phase_bits)
 {
+	// exported as a library helper: any integers may arrive
+	if (phase_bits < 1 || phase_bits > 63)
+		return std::nan("");
+	if (nstages < 0)
+		nstages = 0;
 	const double rad_to_phase = (double)(1ul << (phase_bits - 1)) / M_PI;
 	double var = 1. / 12.;
 	for (unsigned k = 0; k < (unsigned)nstages; k++) {
@@ -84,7 +94,7 @@ double phase_variance(int nstages, int phase_bits)
 double quantization_variance(int nstages, int xtrabits, int dropped_bits)
 {
 	double v = std::pow(2, 2 * xtrabits) / 12.;
-	for (int k = 0; k < nstages; k++)
+	for (int k = 0; k < nstages && k < 4096; k++)
 		v = (1 + std::pow(4, -k - 1)) * v + 1. / 3.;
 	if (dropped_bits > 0)
 		v = std::pow(2, -2 * dropped_bits) * v + 1 / 12.;
@@ -95,7 +105,7 @@ double quantization_variance(int nstages, int xtrabits, int dropped_bits)
 int next_lg(unsigned vl)
 {
 	int lg = 0;
-	for (unsigned r = 1; r < vl; r <<= 1)
+	for (unsigned r = 1; r != 0 && r < vl; r <<= 1)
 		lg++;
 	return lg;
 }
@@ -118,6 +128,8 @@ int stages_for(int phase_bits, int working_width /* <0: unbounded */)
 // 254-263 (the code uses 2^w - 1, not the 2^(w-1) - 1 of its comment).
 int phase_bits_for(int width)
 {
+	if (width < 0) width = 0;
+	if (width > 62) width = 62;
 	int pb = 3;
 	for (; pb < 64; pb++) {
 		const double a = (2.0 * M_PI / (double)(1ul << pb));

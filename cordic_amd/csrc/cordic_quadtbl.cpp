@@ -239,8 +239,8 @@ int quad_build_from_cli(cordic_quad_config *q, int iw, int ow, int xtra,
 		ow = iw;
 	if (iw <= 0 || ow <= 0)
 		iw = ow = 24;					// DEFAULT_BITWIDTH
-	if (iw > 32 || ow > 32)
-		return CORDIC_ERR_WIDTH;
+	if (ow > 32)
+		return CORDIC_ERR_WIDTH;	// -i only feeds the default of -p below
 	const int nxtra = xtra + 1;
 	const int ww = ((ow > iw) ? ow : iw) + nxtra;
 	if (phase_bits <= 0) {
