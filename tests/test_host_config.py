@@ -205,3 +205,51 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     # a launch on (null) device pointers must not pretend to succeed either
     rc = ca.lib().cordic_p2r_const(cfg.ref, 8, 1, 0, 16, 16, 16, None)
     assert rc == ca.ERR_DEVICE
+
+
+def test_product_and_oracle_accept_and_refuse_the_same_parameters():
+    """Random parameter sets, valid and not: the host layer and the oracle
+    must agree on which ones exist, and on what they derive from those."""
+    rng = np.random.RandomState(77)
+    accepted = 0
+    for _ in range(2500):
+        mode = int(rng.randint(-1, 6))
+        iw, ow = int(rng.randint(-3, 40)), int(rng.randint(-3, 40))
+        xtra, pw = int(rng.randint(-2, 40)), int(rng.randint(-2, 40))
+        ns = int(rng.randint(-2, 70))
+        try:
+            c = ca.Config.from_cli(mode, iw, ow, xtra, pw, ns)
+        except ca.CordicError:
+            with pytest.raises(ValueError):
+                O.config_cli(mode, iw, ow, xtra, pw, ns)
+        else:
+            o = O.config_cli(mode, iw, ow, xtra, pw, ns)
+            assert (c.iw, c.ow, c.ww, c.pw, c.nstages) == (o.iw, o.ow, o.ww,
+                                                            o.pw, o.nstages)
+            assert c.angles == list(o.angle[: o.nstages])
+            accepted += 1
+        try:
+            q = ca.Quad(iw, ow, xtra, pw, device=False)
+        except ca.CordicError:
+            with pytest.raises(ValueError):
+                O.quad_cli(iw, ow, xtra, pw)
+        else:
+            oq = O.quad_cli(iw, ow, xtra, pw)
+            assert (q.pw, q.lgtbl, q.cbits, q.lbits, q.qbits) == (
+                oq.pw, oq.lgtbl, oq.cbits, oq.lbits, oq.qbits)
+        for kind in (ca.TBL, ca.QTR):
+            try:
+                t = ca.Table(kind, iw, ow, pw, device=False)
+            except ca.CordicError:
+                with pytest.raises(ValueError):
+                    O.table_config(kind, iw, ow, pw)
+            else:
+                assert (t.pw, t.ow) == O.table_config(kind, iw, ow, pw)
+        # the exported helpers take any integers
+        L = ca.lib()
+        L.cordic_calc_stages(pw)
+        L.cordic_calc_stages_ww(iw, pw)
+        L.cordic_calc_phase_bits(ow)
+        L.cordic_phase_variance(ns, pw)
+        L.cordic_gain_annihilator(ns)
+    assert accepted > 300
