@@ -177,3 +177,27 @@ def test_c_example_runs():
     r = subprocess.run([exe, "-i", "32", "-o", "32", "-p", "32", "-n", "16"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
+    """tools/host_selftest.cpp: the host-only sources compiled with
+    -fsanitize=address,undefined and driven with random / hostile parameters,
+    undersized buffers and random command lines."""
+    exe = tmp_path / "host_selftest"
+    csrc = os.path.join(ROOT, "cordic_amd", "csrc")
+    r = subprocess.run(
+        ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined",
+         "-fno-sanitize-recover=all", "-fwrapv", "-ffp-contract=off",
+         "-I", os.path.join(ROOT, "include"), "-I", csrc,
+         os.path.join(ROOT, "tools", "host_selftest.cpp"),
+         os.path.join(csrc, "cordic_config.cpp"),
+         os.path.join(csrc, "cordic_plan.cpp"),
+         os.path.join(csrc, "cordic_quadtbl.cpp"), "-o", str(exe)],
+        capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), "7"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "host selftest ok" in r.stdout
