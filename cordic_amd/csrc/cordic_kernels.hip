@@ -566,12 +566,27 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 
 // ----------------------------------------------------------------- launchers
 
+// A cordic_config is a caller-owned POD: refuse one whose fields cannot have
+// come out of cordic_config_init* before any kernel indexes with them.
+static bool config_sane(const cordic_config &c)
+{
+	const bool rot = (c.mode == CORDIC_P2R || c.mode == CORDIC_SP2R);
+	const int in_shl = rot ? (c.ww - c.iw - 1) : (c.ww - c.iw - 2);
+	return c.iw >= 1 && c.iw <= 32 && c.ow >= 1 && c.ow <= 32
+		&& c.ww >= c.ow && c.ww <= 64 && in_shl >= 0
+		&& c.pw >= 3 && c.pw <= 32
+		&& c.nstages >= 1 && c.nstages <= CORDIC_AMD_MAX_STAGES
+		&& c.nlive >= 0 && c.nlive <= c.nstages;
+}
+
 int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		void *stream)
 {
 	clear_stale_error();
 	if (cfg.mode != CORDIC_P2R && cfg.mode != CORDIC_SP2R)
 		return CORDIC_ERR_MODE;
+	if (!config_sane(cfg))
+		return CORDIC_ERR_ARGS;
 	if (job.n == 0)
 		return CORDIC_OK;
 	if (!job.ox || !job.oy)
@@ -595,6 +610,8 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 	clear_stale_error();
 	if (cfg.mode != CORDIC_R2P && cfg.mode != CORDIC_SR2P)
 		return CORDIC_ERR_MODE;
+	if (!config_sane(cfg))
+		return CORDIC_ERR_ARGS;
 	if (n == 0)
 		return CORDIC_OK;
 	if (!x || !y || !mag || !phase)

@@ -253,3 +253,18 @@ def test_product_and_oracle_accept_and_refuse_the_same_parameters():
         L.cordic_phase_variance(ns, pw)
         L.cordic_gain_annihilator(ns)
     assert accepted > 300
+
+
+def test_corrupt_config_is_refused_before_any_launch():
+    """The config is a POD the caller owns; fields that cannot have come out
+    of cordic_config_init* are refused (CORDIC_ERR_ARGS) ahead of the device."""
+    good = ca.Config.from_cli(ca.P2R, 13, 13)
+    for field, bad in (("nstages", 100), ("nlive", 65), ("ww", 70), ("pw", 40),
+                       ("iw", 0), ("ow", 33), ("ww", 12), ("nlive", -1)):
+        c = good.with_flags(0)
+        setattr(c.c, field, bad)
+        rc = ca.lib().cordic_p2r_const(c.ref, 8, 1, 0, 16, 16, 16, None)
+        assert rc == ca.ERR_ARGS, (field, bad, rc)
+    r = ca.Config.from_cli(ca.R2P, 13, 13).with_flags(0)
+    r.c.nstages = 0
+    assert ca.lib().cordic_r2p(r.ref, 8, 16, 16, 16, 16, None) == ca.ERR_ARGS
