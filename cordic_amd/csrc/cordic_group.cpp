@@ -1,0 +1,500 @@
+// cordic_group.cpp -- multi-GPU jobs behind the C ABI (include/cordic_amd.h,
+// "multi-GPU jobs"; BASELINE.json configs[3]).
+//
+// One host process drives `nlocal` shards, one HIP device each: hipSetDevice,
+// a plan of the core bound to that device, a compute stream and a copy stream.
+// Shards are contiguous blocks of the GLOBAL sample index and generate their
+// own inputs, so the data path has no collective; what crosses devices is
+// (a) 8-byte digests, summed on the host, and (b) optionally the results on
+// their way to one consumer device, chunk-pipelined behind the compute with
+// hipMemcpyPeerAsync (SDMA over xGMI: no CUs, no RCCL kernels competing with
+// the CORDIC kernels for the VALUs).
+//
+// The reference has nothing of the kind (bench/cpp/cordic_tb.cpp:127-178 steps
+// one model from one thread), so there is no reference text to follow here.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "cordic_amd.h"
+#include "cordic_internal.h"
+
+using namespace cordic_amd;
+
+namespace {
+
+constexpr int kMaxMarks = 256;
+constexpr int kMaxChunks = 64;
+
+struct Shard {
+	int	device = 0;
+	int	index = 0;		// global shard index
+	hipStream_t compute = nullptr, copy = nullptr;
+	cordic_plan *plan = nullptr;
+	void	*buf[4] = {nullptr, nullptr, nullptr, nullptr};	// in0 in1 out0 out1
+	uint64_t cap = 0;		// words allocated per array
+	int	inputs = 0;
+	uint64_t *d_digest = nullptr;
+	hipEvent_t marks[kMaxMarks] = {};
+	hipEvent_t piece[kMaxChunks] = {};
+};
+
+// restores the caller's current device on every exit path
+struct DeviceScope {
+	int prev = -1;
+	DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+	~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+bool ok(hipError_t e) { return e == hipSuccess; }
+
+} // namespace
+
+struct cordic_group {
+	cordic_config cfg;
+	int	first = 0, total = 1;
+	std::vector<Shard> shards;
+	// result forwarding
+	int	root = -1;
+	int32_t	*g0 = nullptr, *g1 = nullptr;
+	int	chunks = 1;
+};
+
+namespace {
+
+void shard_span(uint64_t n, int s, int total, uint64_t *start, uint64_t *count)
+{
+	const uint64_t base = n / (uint64_t)total, rem = n % (uint64_t)total;
+	const uint64_t us = (uint64_t)s;
+	*start = us * base + (us < rem ? us : rem);
+	*count = base + (us < rem ? 1 : 0);
+}
+
+void release(Shard &s)
+{
+	if (!ok(hipSetDevice(s.device)))
+		return;
+	for (void *&p : s.buf) {
+		if (p) (void)hipFree(p);
+		p = nullptr;
+	}
+	if (s.d_digest) (void)hipFree(s.d_digest);
+	if (s.plan) cordic_plan_destroy(s.plan);
+	for (hipEvent_t &e : s.marks) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t &e : s.piece) if (e) (void)hipEventDestroy(e);
+	if (s.compute) (void)hipStreamDestroy(s.compute);
+	if (s.copy) (void)hipStreamDestroy(s.copy);
+	s = Shard{};
+}
+
+int ensure(cordic_group *g, uint64_t n_total, int inputs)
+{
+	for (Shard &s : g->shards) {
+		uint64_t start, cnt;
+		shard_span(n_total, s.index, g->total, &start, &cnt);
+		if (cnt <= s.cap && inputs <= s.inputs)
+			continue;
+		if (!ok(hipSetDevice(s.device)))
+			return CORDIC_ERR_DEVICE;
+		// earlier jobs may still be running on the old arrays
+		if (!ok(hipStreamSynchronize(s.compute)) || !ok(hipStreamSynchronize(s.copy)))
+			return CORDIC_ERR_DEVICE;
+		const uint64_t cap = cnt > s.cap ? cnt : s.cap;
+		const int nin = inputs > s.inputs ? inputs : s.inputs;
+		for (int a = 0; a < 4; a++) {
+			const bool wanted = (a >= 2) || (a < nin);
+			if (s.buf[a] && cap > s.cap) {
+				(void)hipFree(s.buf[a]);
+				s.buf[a] = nullptr;
+			}
+			if (wanted && !s.buf[a] &&
+			    !ok(hipMalloc(&s.buf[a], (cap ? cap : 1) * 4)))
+				return CORDIC_ERR_DEVICE;
+		}
+		s.cap = cap;
+		s.inputs = nin;
+	}
+	return CORDIC_OK;
+}
+
+// Run `launch(shard, offset, count)` over every local shard, whole or -- with
+// forwarding set -- piece by piece, each piece followed by its peer copies.
+template <typename F>
+int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
+{
+	if (!g)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	if (int rc = ensure(g, n_total, inputs))
+		return rc;
+	const int chunks = (g->root >= 0) ? g->chunks : 1;
+	// piece-major, so that every device has work queued before the first
+	// copy is issued
+	for (int c = 0; c < chunks; c++) {
+		for (Shard &s : g->shards) {
+			uint64_t start, cnt;
+			shard_span(n_total, s.index, g->total, &start, &cnt);
+			// pieces start on 4096-sample boundaries of the shard, so the
+			// vector kernels keep their 16-byte accesses
+			uint64_t psize = (cnt + (uint64_t)chunks - 1) / (uint64_t)chunks;
+			psize = (psize + 4095) & ~(uint64_t)4095;
+			const uint64_t a = (uint64_t)c * psize;
+			if (a >= cnt)
+				continue;
+			const uint64_t len = (cnt - a < psize) ? cnt - a : psize;
+			if (!ok(hipSetDevice(s.device)))
+				return CORDIC_ERR_DEVICE;
+			if (int rc = launch(s, start, a, len))
+				return rc;
+			if (g->root < 0)
+				continue;
+			if (!s.piece[c] && !ok(hipEventCreateWithFlags(&s.piece[c],
+					hipEventDisableTiming)))
+				return CORDIC_ERR_DEVICE;
+			if (!ok(hipEventRecord(s.piece[c], s.compute)) ||
+			    !ok(hipStreamWaitEvent(s.copy, s.piece[c], 0)))
+				return CORDIC_ERR_DEVICE;
+			const size_t bytes = (size_t)len * 4;
+			int32_t *o0 = static_cast<int32_t *>(s.buf[2]) + a;
+			int32_t *o1 = static_cast<int32_t *>(s.buf[3]) + a;
+			if (!ok(hipMemcpyPeerAsync(g->g0 + start + a, g->root, o0,
+					s.device, bytes, s.copy)) ||
+			    !ok(hipMemcpyPeerAsync(g->g1 + start + a, g->root, o1,
+					s.device, bytes, s.copy)))
+				return CORDIC_ERR_DEVICE;
+		}
+	}
+	return CORDIC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int cordic_device_count(void)
+{
+	int n = 0;
+	if (!ok(hipGetDeviceCount(&n))) {
+		(void)hipGetLastError();
+		return CORDIC_ERR_DEVICE;
+	}
+	return n;
+}
+
+void cordic_group_destroy(cordic_group *grp)
+{
+	if (!grp)
+		return;
+	DeviceScope scope;
+	for (Shard &s : grp->shards)
+		release(s);
+	delete grp;
+}
+
+int cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices,
+		int first_shard, int total_shards, cordic_group **out)
+{
+	if (!cfg || !out || nlocal < 1 || total_shards < 1 || first_shard < 0
+			|| first_shard + nlocal > total_shards)
+		return CORDIC_ERR_ARGS;
+	const int ndev = cordic_device_count();
+	if (ndev <= 0)
+		return CORDIC_ERR_DEVICE;
+	for (int i = 0; i < nlocal; i++) {
+		const int d = devices ? devices[i] : i;
+		if (d < 0 || d >= ndev)
+			return CORDIC_ERR_DEVICE;	// fewer GPUs than shards asked for
+	}
+	cordic_group *g = new (std::nothrow) cordic_group;
+	if (!g)
+		return CORDIC_ERR_NOMEM;
+	g->cfg = *cfg;
+	g->first = first_shard;
+	g->total = total_shards;
+	DeviceScope scope;
+	g->shards.resize((size_t)nlocal);
+	int rc = CORDIC_OK;
+	for (int i = 0; i < nlocal && rc == CORDIC_OK; i++) {
+		Shard &s = g->shards[(size_t)i];
+		s.device = devices ? devices[i] : i;
+		s.index = first_shard + i;
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipStreamCreateWithFlags(&s.compute, hipStreamNonBlocking)) ||
+		    !ok(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking)) ||
+		    !ok(hipMalloc((void **)&s.d_digest, 8))) {
+			rc = CORDIC_ERR_DEVICE;
+			break;
+		}
+		// the "generation" step of the core, once per device
+		rc = cordic_plan_create(cfg, &s.plan);
+	}
+	if (rc != CORDIC_OK) {
+		cordic_group_destroy(g);
+		return rc;
+	}
+	*out = g;
+	return CORDIC_OK;
+}
+
+int cordic_group_size(const cordic_group *grp)
+{
+	return grp ? (int)grp->shards.size() : CORDIC_ERR_ARGS;
+}
+
+int cordic_group_range(const cordic_group *grp, uint64_t n_total, int shard,
+		uint64_t *start, uint64_t *count)
+{
+	if (!grp || shard < 0 || shard >= grp->total || !start || !count)
+		return CORDIC_ERR_ARGS;
+	shard_span(n_total, shard, grp->total, start, count);
+	return CORDIC_OK;
+}
+
+int cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs)
+{
+	if (!grp || inputs < 0 || inputs > 2)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	return ensure(grp, n_total, inputs);
+}
+
+int cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	if (int rc = ensure(grp, n_total, 1))
+		return rc;
+	for (Shard &s : grp->shards) {
+		uint64_t start, cnt;
+		shard_span(n_total, s.index, grp->total, &start, &cnt);
+		if (!ok(hipSetDevice(s.device)))
+			return CORDIC_ERR_DEVICE;
+		if (int rc = cordic_fill_phase_ramp(static_cast<uint32_t *>(s.buf[0]),
+				(size_t)cnt, start, shift, s.compute))
+			return rc;
+	}
+	return CORDIC_OK;
+}
+
+int cordic_group_fill_iq_ramp(cordic_group *grp, uint64_t n_total, uint32_t mulx,
+		uint32_t muly, int bits)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	if (int rc = ensure(grp, n_total, 2))
+		return rc;
+	for (Shard &s : grp->shards) {
+		uint64_t start, cnt;
+		shard_span(n_total, s.index, grp->total, &start, &cnt);
+		if (!ok(hipSetDevice(s.device)))
+			return CORDIC_ERR_DEVICE;
+		if (int rc = cordic_fill_iq_ramp(static_cast<int32_t *>(s.buf[0]),
+				static_cast<int32_t *>(s.buf[1]), (size_t)cnt, start,
+				mulx, muly, bits, s.compute))
+			return rc;
+	}
+	return CORDIC_OK;
+}
+
+int cordic_group_p2r_const(cordic_group *grp, uint64_t n_total, int32_t xval,
+		int32_t yval)
+{
+	return for_each_piece(grp, n_total, 1,
+		[&](Shard &s, uint64_t, uint64_t a, uint64_t len) {
+			return cordic_plan_p2r_const(s.plan, (size_t)len, xval, yval,
+				static_cast<const uint32_t *>(s.buf[0]) + a,
+				static_cast<int32_t *>(s.buf[2]) + a,
+				static_cast<int32_t *>(s.buf[3]) + a, s.compute);
+		});
+}
+
+int cordic_group_nco(cordic_group *grp, uint64_t n_total, uint32_t phase0,
+		uint32_t fcw, int32_t xval, int32_t yval)
+{
+	return for_each_piece(grp, n_total, 0,
+		[&](Shard &s, uint64_t start, uint64_t a, uint64_t len) {
+			return cordic_plan_nco(s.plan, (size_t)len, phase0, fcw,
+				start + a, xval, yval,
+				static_cast<int32_t *>(s.buf[2]) + a,
+				static_cast<int32_t *>(s.buf[3]) + a, s.compute);
+		});
+}
+
+int cordic_group_r2p(cordic_group *grp, uint64_t n_total)
+{
+	return for_each_piece(grp, n_total, 2,
+		[&](Shard &s, uint64_t, uint64_t a, uint64_t len) {
+			return cordic_r2p(cordic_plan_config(s.plan), (size_t)len,
+				static_cast<const int32_t *>(s.buf[0]) + a,
+				static_cast<const int32_t *>(s.buf[1]) + a,
+				static_cast<int32_t *>(s.buf[2]) + a,
+				static_cast<uint32_t *>(s.buf[3]) + a, s.compute);
+		});
+}
+
+int cordic_group_sync(cordic_group *grp)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	for (Shard &s : grp->shards) {
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipStreamSynchronize(s.compute)) ||
+		    !ok(hipStreamSynchronize(s.copy)))
+			return CORDIC_ERR_DEVICE;
+	}
+	return CORDIC_OK;
+}
+
+int cordic_group_digest(cordic_group *grp, uint64_t n_total, uint64_t *digest)
+{
+	if (!grp || !digest)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	for (Shard &s : grp->shards) {
+		uint64_t start, cnt;
+		shard_span(n_total, s.index, grp->total, &start, &cnt);
+		if (cnt > s.cap)
+			return CORDIC_ERR_ARGS;		// no such job has run
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipMemsetAsync(s.d_digest, 0, 8, s.compute)))
+			return CORDIC_ERR_DEVICE;
+		int rc = cordic_digest_u32(static_cast<const uint32_t *>(s.buf[2]),
+				(size_t)cnt, start, s.d_digest, s.compute);
+		if (rc == CORDIC_OK)
+			rc = cordic_digest_u32(static_cast<const uint32_t *>(s.buf[3]),
+				(size_t)cnt, start + ((uint64_t)1 << 40), s.d_digest,
+				s.compute);
+		if (rc != CORDIC_OK)
+			return rc;
+	}
+	uint64_t sum = 0;
+	for (Shard &s : grp->shards) {
+		uint64_t v = 0;
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipStreamSynchronize(s.compute)) ||
+		    !ok(hipMemcpy(&v, s.d_digest, 8, hipMemcpyDeviceToHost)))
+			return CORDIC_ERR_DEVICE;
+		sum += v;			// shards add, mod 2^64
+	}
+	*digest = sum;
+	return CORDIC_OK;
+}
+
+int cordic_group_set_gather(cordic_group *grp, int root_device, int32_t *d_out0,
+		int32_t *d_out1, int chunks)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	if (root_device < 0) {
+		grp->root = -1;
+		grp->g0 = grp->g1 = nullptr;
+		grp->chunks = 1;
+		return CORDIC_OK;
+	}
+	if (!d_out0 || !d_out1 || chunks < 1 || chunks > kMaxChunks
+			|| root_device >= cordic_device_count())
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	// let the copy engines move device to device directly over xGMI; where
+	// peer access cannot be enabled hipMemcpyPeerAsync still works (staged)
+	for (Shard &s : grp->shards) {
+		if (s.device == root_device)
+			continue;
+		int can = 0;
+		if (ok(hipDeviceCanAccessPeer(&can, s.device, root_device)) && can
+				&& ok(hipSetDevice(s.device))) {
+			const hipError_t e = hipDeviceEnablePeerAccess(root_device, 0);
+			if (e != hipSuccess)
+				(void)hipGetLastError();	// already enabled is fine
+		}
+	}
+	grp->root = root_device;
+	grp->g0 = d_out0;
+	grp->g1 = d_out1;
+	grp->chunks = chunks;
+	return CORDIC_OK;
+}
+
+int cordic_group_mark(cordic_group *grp, int slot)
+{
+	if (!grp || slot < 0 || slot >= kMaxMarks)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	for (Shard &s : grp->shards) {
+		if (!ok(hipSetDevice(s.device)))
+			return CORDIC_ERR_DEVICE;
+		if (!s.marks[slot] && !ok(hipEventCreate(&s.marks[slot])))
+			return CORDIC_ERR_DEVICE;
+		if (!ok(hipEventRecord(s.marks[slot], s.compute)))
+			return CORDIC_ERR_DEVICE;
+	}
+	return CORDIC_OK;
+}
+
+int cordic_group_elapsed(cordic_group *grp, int slot_a, int slot_b, float *max_ms,
+		float *per_shard_ms)
+{
+	if (!grp || !max_ms || slot_a < 0 || slot_a >= kMaxMarks || slot_b < 0
+			|| slot_b >= kMaxMarks)
+		return CORDIC_ERR_ARGS;
+	DeviceScope scope;
+	float worst = 0.f;
+	for (size_t i = 0; i < grp->shards.size(); i++) {
+		Shard &s = grp->shards[i];
+		if (!s.marks[slot_a] || !s.marks[slot_b])
+			return CORDIC_ERR_ARGS;
+		float ms = 0.f;
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipEventSynchronize(s.marks[slot_b])) ||
+		    !ok(hipEventElapsedTime(&ms, s.marks[slot_a], s.marks[slot_b])))
+			return CORDIC_ERR_DEVICE;
+		if (per_shard_ms)
+			per_shard_ms[i] = ms;
+		if (ms > worst)
+			worst = ms;
+	}
+	*max_ms = worst;
+	return CORDIC_OK;
+}
+
+int cordic_group_buffers(const cordic_group *grp, int local_shard, int *device,
+		void **in0, void **in1, void **out0, void **out1, uint64_t *count)
+{
+	if (!grp || local_shard < 0 || local_shard >= (int)grp->shards.size())
+		return CORDIC_ERR_ARGS;
+	const Shard &s = grp->shards[(size_t)local_shard];
+	if (device) *device = s.device;
+	if (in0) *in0 = s.buf[0];
+	if (in1) *in1 = s.buf[1];
+	if (out0) *out0 = s.buf[2];
+	if (out1) *out1 = s.buf[3];
+	if (count) *count = s.cap;
+	return CORDIC_OK;
+}
+
+int cordic_group_read(cordic_group *grp, int local_shard, int array,
+		uint64_t offset, uint64_t count, void *host_dst)
+{
+	if (!grp || local_shard < 0 || local_shard >= (int)grp->shards.size()
+			|| array < 0 || array > 3 || !host_dst)
+		return CORDIC_ERR_ARGS;
+	Shard &s = grp->shards[(size_t)local_shard];
+	if (!s.buf[array] || offset > s.cap || count > s.cap - offset)
+		return CORDIC_ERR_ARGS;
+	if (count == 0)
+		return CORDIC_OK;
+	DeviceScope scope;
+	if (!ok(hipSetDevice(s.device)) ||
+	    !ok(hipStreamSynchronize(s.compute)) ||
+	    !ok(hipMemcpy(host_dst, static_cast<const uint32_t *>(s.buf[array])
+			+ offset, (size_t)count * 4, hipMemcpyDeviceToHost)))
+		return CORDIC_ERR_DEVICE;
+	return CORDIC_OK;
+}
+
+} // extern "C"

@@ -444,6 +444,87 @@ int	cordic_seq_ticks(cordic_seq *s, size_t ticks,
 /* off-protocol i_stb clocks seen so far (synchronises the device) */
 int	cordic_seq_violations(cordic_seq *s, uint64_t *count);
 
+/* ---------------------------------------------------------- multi-GPU jobs
+ *
+ * SURVEY.md 8(e) / BASELINE.json configs[3]: samples are independent (every
+ * pipeline register of the reference core is per sample, rtl/cordic.v:231-283;
+ * the NCO phase is the closed form phase0 + n*fcw), so a job of n_total
+ * samples splits into contiguous blocks by GLOBAL sample index.  The reference
+ * has no counterpart (one Verilated model stepped by one thread,
+ * bench/cpp/cordic_tb.cpp:127-178); this is the host side of the 8-GPU
+ * configuration, in C++ behind the C ABI.
+ *
+ * A cordic_group is `nlocal` shards driven by THIS host process, one HIP
+ * device each (hipSetDevice per shard, one plan, one compute stream and one
+ * copy stream per shard), out of `total_shards` shards of the whole job:
+ *   - one process driving every GPU of a node:  first_shard 0, nlocal ==
+ *     total_shards == number of devices (no process group at all);
+ *   - one process per GPU (torch.distributed.run / mpirun): nlocal 1,
+ *     first_shard = rank, total_shards = world size; the processes only ever
+ *     exchange the 8-byte digests.
+ * Shard s owns [s*n/S + min(s, n%S), ...) -- sizes differ by at most one -- and
+ * GENERATES ITS OWN INPUTS from the global index: no scatter, no collective on
+ * the data path.  The group owns the resident buffers of its shards (in0, in1,
+ * out0, out1: one 32-bit word per sample each).  Job calls only enqueue;
+ * cordic_group_sync waits.  devices == NULL means ordinals 0..nlocal-1; an
+ * ordinal may be listed twice (two shards sharing one GPU -- how the
+ * single-GPU tests exercise the multi-shard logic).
+ */
+typedef struct cordic_group cordic_group;
+
+int	cordic_device_count(void);	/* visible HIP devices, or a negative status */
+int	cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices,
+		int first_shard, int total_shards, cordic_group **grp);
+void	cordic_group_destroy(cordic_group *grp);
+int	cordic_group_size(const cordic_group *grp);	/* nlocal */
+/* global range of shard `shard` (0 .. total_shards-1) of an n_total job */
+int	cordic_group_range(const cordic_group *grp, uint64_t n_total, int shard,
+		uint64_t *start, uint64_t *count);
+/* (re)allocate the shards' buffers for jobs of n_total samples with `inputs`
+ * (0, 1 or 2) input arrays; job calls do this implicitly on first use */
+int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
+/* in0[i] = ((start+i) << shift) mod 2^32            (cordic_fill_phase_ramp) */
+int	cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift);
+/* in0 / in1 = the deterministic I/Q ramps of cordic_fill_iq_ramp            */
+int	cordic_group_fill_iq_ramp(cordic_group *grp, uint64_t n_total,
+		uint32_t mulx, uint32_t muly, int bits);
+/* out0, out1 = cordic_plan_p2r_const(in0 as i_phase)                        */
+int	cordic_group_p2r_const(cordic_group *grp, uint64_t n_total, int32_t xval,
+		int32_t yval);
+/* out0, out1 = cordic_plan_nco with index0 = the shard's global start       */
+int	cordic_group_nco(cordic_group *grp, uint64_t n_total, uint32_t phase0,
+		uint32_t fcw, int32_t xval, int32_t yval);
+/* out0 = o_mag, out1 = o_phase of cordic_r2p(in0, in1)                      */
+int	cordic_group_r2p(cordic_group *grp, uint64_t n_total);
+int	cordic_group_sync(cordic_group *grp);
+/* Sum over the local shards of cordic_digest_u32(out0, start) +
+ * cordic_digest_u32(out1, start + 2^40): position aware, so the digests of all
+ * shards of a job add up (mod 2^64) to the digest of the same job computed in
+ * one piece.  Synchronises. */
+int	cordic_group_digest(cordic_group *grp, uint64_t n_total, uint64_t *digest);
+/* Forwarding of results to one consumer ("the final gather"): while set, every
+ * job call computes its shard in `chunks` pieces and, as soon as a piece has
+ * been computed, copies it into d_out0 / d_out1 (device memory of HIP device
+ * root_device, n_total words each, at the piece's GLOBAL offset) on the
+ * shard's copy stream -- hipMemcpyPeerAsync, i.e. the SDMA engines over xGMI,
+ * so the transfer of piece k overlaps the computation of piece k+1 and costs
+ * no CUs.  Only meaningful when this process holds every shard.  root_device
+ * < 0 clears it. */
+int	cordic_group_set_gather(cordic_group *grp, int root_device,
+		int32_t *d_out0, int32_t *d_out1, int chunks);
+/* Timing marks: `slot` (0..255) is recorded on every local shard's compute
+ * stream; elapsed = max over the local shards of the time between two marks
+ * (synchronises), per_shard_ms (may be NULL) receives nlocal values. */
+int	cordic_group_mark(cordic_group *grp, int slot);
+int	cordic_group_elapsed(cordic_group *grp, int slot_a, int slot_b,
+		float *max_ms, float *per_shard_ms);
+/* Shard-local views for callers that consume the results in place, and a
+ * host read-back for checks: array 0..3 = in0, in1, out0, out1. */
+int	cordic_group_buffers(const cordic_group *grp, int local_shard, int *device,
+		void **in0, void **in1, void **out0, void **out1, uint64_t *count);
+int	cordic_group_read(cordic_group *grp, int local_shard, int array,
+		uint64_t offset, uint64_t count, void *host_dst);
+
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,

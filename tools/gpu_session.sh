@@ -1,0 +1,55 @@
+#!/bin/bash
+# gpu_session.sh -- the one script behind every `gpurun` call of this repo.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <task> [<task> ...]'
+# Each task appends to gpurun_out/<task>.log; summaries worth keeping are
+# copied by hand into profiles/.  Tasks:
+#   env        toolchain probe (verilator / iverilog / yosys), rocm-smi clocks
+#   tests      pytest -m gpu
+#   smoke      __graft_entry__.smoke()
+#   bench      python bench.py (default line)           [BENCH_ARGS=...]
+#   hbm        tools/hbm_probe2 streaming-pattern sweep  [HBM_ARGS=...]
+#   valu       tools/valu_microbench
+#   prof:<w>   rocprofv3 stats + PMC passes of bench.py --workload <w>
+#   states     alternate copy probe / bench while logging clocks and power
+#   ab:<flags> build a second library with HIPFLAGS_EXTRA=<flags> and A/B it
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+snap() { rocm-smi --showtemp --showclocks --showpower --showperflevel 2>/dev/null \
+	| grep -E "Temperature|clk|Power|Perf" | sed 's/  */ /g' | tr '\n' ';'; echo; }
+for task in "$@"; do
+	name=${task%%:*}; arg=${task#*:}; [ "$arg" = "$task" ] && arg=
+	log=gpurun_out/$name.log
+	echo "=== $task $(date +%T)" | tee -a $log
+	case $name in
+	env)
+		{ for t in verilator iverilog vvp yosys ghdl go javac node; do
+			printf '%-10s %s\n' $t "$(command -v $t || echo absent)"; done
+		  nproc; grep -m1 'model name' /proc/cpuinfo; cat /sys/fs/cgroup/cpu.max 2>/dev/null
+		  rocm-smi --showclocks --showpower --showtemp --showperflevel 2>&1 | grep -v '^$'
+		  rocminfo 2>/dev/null | grep -E 'Marketing|Compute Unit|Max Clock|gfx' | head -12; } >> $log 2>&1 ;;
+	tests)	timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS} >> $log 2>&1; echo "rc=$?" >> $log ;;
+	smoke)	timeout 600 python -c "import __graft_entry__ as g; g.smoke()" >> $log 2>&1; echo "rc=$?" >> $log ;;
+	bench)	timeout 900 python bench.py ${BENCH_ARGS} >> $log 2>&1; echo "rc=$?" >> $log ;;
+	hbm)	snap >> $log; timeout 600 ./tools/hbm_probe2 ${HBM_ARGS} >> $log 2>&1; snap >> $log ;;
+	valu)	timeout 600 ./tools/valu_microbench >> $log 2>&1 ;;
+	prof)	timeout 1200 bash tools/profile_workload.sh $arg >> $log 2>&1 ;;
+	states)
+		for i in $(seq 1 ${STATE_ROUNDS:-10}); do
+			echo "== round $i: $(./tools/hbm_probe2 30 20 marker | grep -m1 persist)" >> $log
+			python bench.py --steps 300 --no-cpu-baseline --no-other-paths 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']), round(d['roofline']['frac'],3), d['roofline'].get('copy_frac'))" >> $log
+			snap >> $log
+		done ;;
+	ab)
+		make -C cordic_amd/csrc -j8 BUILD=build_ab OUT=$PWD/cordic_amd/lib_ab.so HIPFLAGS_EXTRA="$arg" > gpurun_out/ab_build.log 2>&1
+		for r in 1 2 3; do for lib in libcordic_amd.so lib_ab.so; do
+			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-other-paths 2>/dev/null \
+			| python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['roofline']['frac'],3))" >> $log
+		done; done ;;
+	*)	echo "unknown task $task" | tee -a $log ;;
+	esac
+done

@@ -1,7 +1,7 @@
 # rocprofv3 session for one bench.py workload: kernel-trace stats, then PMC
 # passes in SEPARATE runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC
 # is never combined with sys/hip tracing).
-#   bash tools/profile_r01.sh <workload> [extra bench.py flags] 
+#   bash tools/profile_workload.sh <workload> [extra bench.py flags] 
 R=$GRAFT_REPO_ROOT
 W=${1:-cfg2}; shift
 EXTRA="$@"
