@@ -352,6 +352,9 @@ def main():
     ap.add_argument("--no-seed", action="store_true",
                     help="constant-vector feeds: full 16-stage recurrence per "
                     "sample instead of the table-seeded kernel")
+    ap.add_argument("--static-chunks", action="store_true",
+                    help="seeded kernel: one contiguous chunk per persistent "
+                    "block instead of the address-ordered tile queue (A/B)")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
     args = ap.parse_args()
@@ -382,6 +385,8 @@ def main():
         cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
     if args.no_seed:
         cfg = cfg.with_flags(ca.FLAG_NO_SEED)
+    if args.static_chunks:
+        cfg = cfg.with_flags(ca.FLAG_STATIC_CHUNKS)
     n = 1 << args.log2_samples
     index0 = rank * n                   # shard by global sample index
     x0, y0 = (1 << (iw - 1)) - 1, 0

@@ -14,7 +14,8 @@ Reference interfaces mirrored (see include/cordic_amd.h for file:line):
 """
 from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
-    FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_UNIT_GAIN,
+    FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_STATIC_CHUNKS,
+    FLAG_UNIT_GAIN,
     ERR_ARGS, ERR_DEVICE, ERR_CONTAINER,
     Config, CordicError, Plan, Table, TBL, QTR, Quad, Stream, Seq, seed_table,
     lib, lib_path,

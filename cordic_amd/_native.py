@@ -7,6 +7,7 @@ MAX_STAGES = 64
 FLAG_FORCE_GENERIC = 0x1
 FLAG_NO_LJ = 0x4
 FLAG_NO_SEED = 0x8
+FLAG_STATIC_CHUNKS = 0x20
 FLAG_UNIT_GAIN = 0x10
 # enum cordic_status (the codes tests assert on)
 ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9

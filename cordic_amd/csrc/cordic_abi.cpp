@@ -3,6 +3,7 @@
 // the device launchers (cordic_kernels.hip).
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -13,10 +14,18 @@
 using namespace cordic_amd;
 
 // ------------------------------------------------------------------- plans
+// Tile queues of the seeded kernel: every launch takes the next slot of a ring
+// and zeroes it on its own stream, so launches of one plan that overlap (other
+// streams, other threads) never share counters -- short of kQueueSlots of them
+// being in flight at once.
+constexpr unsigned kQueueSlots = 64;
+
 struct cordic_plan {
 	cordic_config cfg;
 	uint32_t *d_table = nullptr;	// device copy of the seed table
 	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
+	uint32_t *d_queues = nullptr;	// kQueueSlots x CORDIC_QUEUE_BYTES
+	mutable std::atomic<unsigned> next_queue{0};
 };
 
 int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
@@ -34,8 +43,11 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 	if (nw) {
 		if (hipMalloc((void **)&p->d_table, nw * 4) != hipSuccess ||
 		    hipMemcpy(p->d_table, words.data(), nw * 4,
-				hipMemcpyHostToDevice) != hipSuccess) {
+				hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMalloc((void **)&p->d_queues, (size_t)kQueueSlots
+				* CORDIC_QUEUE_BYTES) != hipSuccess) {
 			if (p->d_table) (void)hipFree(p->d_table);
+			if (p->d_queues) (void)hipFree(p->d_queues);
 			delete p;
 			return CORDIC_ERR_DEVICE;
 		}
@@ -54,6 +66,8 @@ void cordic_plan_destroy(cordic_plan *plan)
 		return;
 	if (plan->d_table)
 		(void)hipFree(plan->d_table);
+	if (plan->d_queues)
+		(void)hipFree(plan->d_queues);
 	delete plan;
 }
 
@@ -80,6 +94,11 @@ static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 	j.seed_S = plan->S;
 	j.seed_nbuckets = plan->nbuckets;
 	j.seed_nleaves = plan->nleaves;
+	if (plan->d_queues) {
+		const unsigned slot = plan->next_queue.fetch_add(1,
+				std::memory_order_relaxed) % kQueueSlots;
+		j.queue = plan->d_queues + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
+	}
 }
 
 int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,

@@ -677,7 +677,21 @@ struct SeedArgs {
 	int32_t	S;		// bucket shift
 	int32_t	nbuckets;
 	int32_t	nleaves;
+	// Tile queue: kQueueCounters zeroed counters, kQueueStride words apart
+	// (one cache line each), or NULL for the static chunk-per-block sweep.
+	uint32_t *queue;
 };
+
+constexpr int kQueueCounters = 8;	// one per XCD
+constexpr int kQueueStride = 64;	// words between counters
+
+// XCC_ID of the XCD this wave runs on (affinity only, never correctness)
+__device__ __forceinline__ uint32_t xcc_id()
+{
+	uint32_t v;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+	return v & 0xfu;
+}
 
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
 		typename IO = Io32, bool UG = false>
@@ -765,36 +779,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
 		__builtin_trap();
 
-	// Work distribution: every (persistent) block sweeps its own contiguous
-	// chunk.  This kernel runs at HBM speed, and an arithmetic-free kernel
-	// with the same 4 B in / 8 B out traffic measured 2.47 ms per 2^30
-	// samples this way against 2.67 ms with a grid-stride interleave
-	// (tools/hbm_pattern_bench.hip, profiles/r01/hbm_pattern.txt).
-#ifdef CORDIC_SEED_GRIDSTRIDE
-	const size_t stride = (size_t)gridDim.x * kSeedBlock;
-	const size_t hi = nvec;
-	size_t g = (size_t)blockIdx.x * kSeedBlock + threadIdx.x;
-#else
-	const size_t stride = kSeedBlock;
-	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
-	chunk = (chunk + kSeedBlock - 1) / kSeedBlock * kSeedBlock;
-	const size_t lo = (size_t)blockIdx.x * chunk;
-	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
-	size_t g = lo + threadIdx.x;
-#endif
-	// software prefetch (see rotator_unrolled); two passes ahead and
-	// non-temporal loads measured no better
-	typename IO::uvec nph{};
-	if constexpr (FEED != Feed::Nco_ConstXY)
-		if (g < hi)
-			nph = CORDIC_LOAD_IN(&phin[g]);
-	for (; g < hi; g += stride) {
-		const u32x4 tph = IO::widen(nph);
-		if constexpr (FEED != Feed::Nco_ConstXY) {
-			const size_t gn = g + stride;
-			if (gn < hi)
-				nph = CORDIC_LOAD_IN(&phin[gn]);
-		}
+	// One tile pass: 4 samples per lane of vector g, phases in tph.
+	auto pass = [&](size_t g, const u32x4 tph) {
 		uint32_t P[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
 			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
@@ -871,6 +857,103 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		apply_unit_gain<UG>(ry, kp);
 		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
 		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
+	};
+
+	if (sa.queue != nullptr) {
+		// Work distribution, dynamic: the persistent blocks (they keep the
+		// table in LDS) pull 4096-sample tiles from a counter IN ADDRESS
+		// ORDER, the way the hardware dispatcher hands out the blocks of a
+		// one-tile-per-block launch.  Measured with arithmetic-free kernels
+		// of this kernel's traffic (tools/hbm_probe2.hip, profiles/r02/
+		// hbm_probe2.txt): a contiguous chunk per block or a grid-stride
+		// streams at 0.58-0.63 of the HBM peak -- hundreds of far-apart
+		// streams advancing at once -- where one-shot tiles reach 0.72-0.76
+		// and this queue 0.72.  One counter per XCD: XCD j sweeps the j-th
+		// eighth of the batch, and helps the others once its own is done.
+		const uint32_t ntiles = (uint32_t)((nvec + kSeedBlock - 1) / kSeedBlock);
+		const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
+		volatile uint32_t *slot = lds + (size_t)sa.nbuckets * 4 + (size_t)L * 16;
+		constexpr uint32_t kEnd = 0xffffffffu;
+		uint32_t home = 0, tried = 0;		// lane 0 of the block only
+		auto grab = [&]() -> uint32_t {
+			while (tried < (uint32_t)kQueueCounters) {
+				const uint32_t j = (home + tried) % kQueueCounters;
+				const uint32_t lo = j * per;
+				const uint32_t cnt = lo >= ntiles ? 0u
+					: (ntiles - lo < per ? ntiles - lo : per);
+				if (cnt != 0) {
+					const uint32_t t = atomicAdd(&sa.queue[j * kQueueStride], 1u);
+					if (t < cnt)
+						return lo + t;
+				}
+				tried++;
+			}
+			return kEnd;
+		};
+		// tile ids run two passes ahead of the compute (a three-slot ring in
+		// LDS), so that the phases of the next tile can be prefetched while
+		// this one is being rotated
+		if (threadIdx.x == 0) {
+			home = xcc_id() % kQueueCounters;
+			slot[0] = grab();
+			slot[1] = grab();
+		}
+		__syncthreads();
+		uint32_t cur = slot[0];
+		int ring = 0;
+		typename IO::uvec nph{};
+		if constexpr (FEED != Feed::Nco_ConstXY) {
+			const size_t g0 = (size_t)cur * kSeedBlock + threadIdx.x;
+			if (cur != kEnd && g0 < nvec)
+				nph = CORDIC_LOAD_IN(&phin[g0]);
+		}
+		while (cur != kEnd) {
+			const uint32_t nxt = slot[(ring + 1) % 3];
+			if (threadIdx.x == 0)
+				slot[(ring + 2) % 3] = grab();
+			const u32x4 tph = IO::widen(nph);
+			if constexpr (FEED != Feed::Nco_ConstXY) {
+				const size_t gn = (size_t)nxt * kSeedBlock + threadIdx.x;
+				if (nxt != kEnd && gn < nvec)
+					nph = CORDIC_LOAD_IN(&phin[gn]);
+			}
+			const size_t g = (size_t)cur * kSeedBlock + threadIdx.x;
+			if (g < nvec)		// only the batch's last tile is partial
+				pass(g, tph);
+			__syncthreads();
+			cur = nxt;
+			ring = (ring + 1) % 3;
+		}
+		return;
+	}
+
+	// Work distribution, static (no queue): every persistent block sweeps its
+	// own contiguous chunk.
+#ifdef CORDIC_SEED_GRIDSTRIDE
+	const size_t stride = (size_t)gridDim.x * kSeedBlock;
+	const size_t hi = nvec;
+	size_t g = (size_t)blockIdx.x * kSeedBlock + threadIdx.x;
+#else
+	const size_t stride = kSeedBlock;
+	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + kSeedBlock - 1) / kSeedBlock * kSeedBlock;
+	const size_t lo = (size_t)blockIdx.x * chunk;
+	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	size_t g = lo + threadIdx.x;
+#endif
+	// software prefetch (see rotator_unrolled)
+	typename IO::uvec nph{};
+	if constexpr (FEED != Feed::Nco_ConstXY)
+		if (g < hi)
+			nph = CORDIC_LOAD_IN(&phin[g]);
+	for (; g < hi; g += stride) {
+		const u32x4 tph = IO::widen(nph);
+		if constexpr (FEED != Feed::Nco_ConstXY) {
+			const size_t gn = g + stride;
+			if (gn < hi)
+				nph = CORDIC_LOAD_IN(&phin[gn]);
+		}
+		pass(g, tph);
 	}
 }
 

@@ -494,10 +494,15 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		if (FEED != Feed::PhaseArray_XYArray && j.seed_table
 				&& j.seed_m == kSeedStages && j.n >= (size_t)kVec
 				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)) {
+			static_assert(CORDIC_QUEUE_BYTES
+				== kQueueCounters * kQueueStride * 4, "queue layout");
+			uint32_t *queue = (cfg.flags & CORDIC_FLAG_STATIC_CHUNKS)
+					? nullptr : j.queue;
 			SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets,
-					j.seed_nleaves};
+					j.seed_nleaves, queue};
+			// buckets, seeds and the three tile-id slots of the queue
 			const size_t lds = (size_t)j.seed_nbuckets * 16
-					+ (size_t)j.seed_nleaves * 4 * 16;
+					+ (size_t)j.seed_nleaves * 4 * 16 + 16;
 			// blocks per CU: 32 waves and 160 KiB of LDS to share
 			int per_cu = 32 / (kSeedBlock / 64);
 			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
@@ -507,6 +512,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
 			if (per_cu >= 1 && lds <= 160 * 1024) {
+				// the queue's counters start every launch at zero
+				if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
+						st) != hipSuccess)
+					return CORDIC_ERR_DEVICE;
 				if (j.io16)
 					done = launch_seed_narrow16(FEED, cfg.nlive, g2, st,
 							kp, sa, j, lds);

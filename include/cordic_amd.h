@@ -94,6 +94,10 @@ enum cordic_status {
 						   cordic_config_gain_annihilator */
 #define CORDIC_FLAG_NO_SEED		0x8u	/* plans: full recurrence, no
 						   seed table (for A/B)         */
+#define CORDIC_FLAG_STATIC_CHUNKS	0x20u	/* plans: one contiguous chunk
+						   per persistent block instead
+						   of the address-ordered tile
+						   queue (for A/B)              */
 
 /*
  * One generated core.  The first block mirrors, field for field, the
