@@ -10,9 +10,15 @@ already resident in HBM.  The default workload is BASELINE.json configs[1]:
 basiccordic 16-stage, 32-bit phase -> 32-bit sin/cos, 2^30 samples per GPU,
 phase[n] = (uint32)(n << 2) (the reference bench's ramp, cordic_tb.cpp:138),
 x = 2^31-1, y = 0.  Multi-GPU: independent shards by global sample index,
-no data-path collective (weak scaling); a digest all-reduce after the timed
-region checks the shards, `--gather` additionally times collecting the
-outputs on rank 0 over RCCL.
+no data-path collective (weak scaling), driven through the C++ cordic_group
+layer of the C ABI; a digest all-reduce after the timed region checks the
+shards, `--gather` additionally times collecting the outputs on one GPU.
+
+`--gpus N` always means N GPUs: started by torch.distributed.run the world
+size must equal N; started plainly with N > 1 the script re-executes itself
+under torch.distributed.run with N ranks (one GPU each); fewer than N visible
+GPUs is an error, never a silent 1-GPU run.  `--single-process` instead
+drives all N devices from one host process (cordic_group, no process group).
 
 Rank 0 prints ONE JSON line.
 """
@@ -220,37 +226,81 @@ def other_paths(ca, dev, log2n=29, steps=8):
         oq, O.quad_tables(oq), ph[idx].cpu().numpy().view(np.uint32))))
     res["quadtbl"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 8,
                       "bit_exact_vs_oracle": ok}
+    for key, e in res.items():
+        gbs = e["Msamples_per_s"] * 1e6 * e["bytes_per_sample"] / 1e9
+        e["roofline"] = {"bound": "hbm", "achieved": gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS}
+        e["from_profile"] = from_profile(key)
     return res
 
 
-def _pmc_valu(key, samples_per_launch, samples_per_s):
-    """VALU instructions per sample (rocprofv3 SQ_INSTS_VALU of
-    the committed PMC pass, x64 lanes, / samples per launch) and the lane-op
-    rate that implies at the measured sample rate, against the nominal
-    256 CU x 64 lanes x 2.4 GHz = 39.3e12 lane-ops/s.  (gfx950 issues the
-    full-rate integer ops faster than one wave per 4 cycles --
-    profiles/valu_microbench_r01.txt measures 58-65e12 lane-ops/s for
-    add/xor/shift and 37e12 for the half-rate ops -- so the fraction of the
-    nominal figure can exceed 1.)"""
+def _profile_entry(key):
+    """Counters of a workload from the COMMITTED rocprofv3 passes
+    (profiles/pmc_latest.json; tools/profile_workload.sh produced them in an
+    earlier gpurun session) -- not measured by this run, and labelled so."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            e = json.load(f).get(key, {})
-        per_sample = e["SQ_INSTS_VALU"] * 64.0 / samples_per_launch
-    except (OSError, ValueError, KeyError):
-        return None
-    return {"valu_instr_per_sample": per_sample,
-            "lane_ops_per_s": per_sample * samples_per_s,
-            "frac_of_nominal_39e12": per_sample * samples_per_s / 39.3e12}
-
-
-def _pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json), or None if that workload was not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+            db = json.load(f)
+        return db.get(key), db.get("_source", "profiles/pmc_latest.json")
     except (OSError, ValueError):
+        return None, None
+
+
+def from_profile(key, samples_per_launch=1 << 30):
+    """{"source": ..., "hbm_bytes_per_launch": ..., "valu_instr_per_sample": ...}
+    for the bench line's `from_profile` block (FETCH_SIZE x 2 +
+    WRITE_SIZE, SQ_INSTS_VALU x 64 lanes / samples), or None."""
+    e, src = _profile_entry(key)
+    if not e:
         return None
+    out = {"source": src, "note": "rocprofv3 PMC passes of an earlier session "
+           "on this kernel, not re-measured by this run"}
+    if "hbm_bytes_per_launch" in e:
+        out["hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+    if "SQ_INSTS_VALU" in e:
+        out["valu_instr_per_sample"] = (e["SQ_INSTS_VALU"] * 64.0
+                                        / samples_per_launch)
+    return out
+
+
+_probe_lib = None
+
+
+def hbm_probe(in0, in1, out0, out1, nwords, r, w, mode, reps, stream=0):
+    """tools/libhbmprobe.so: average ms per launch of an arithmetic-free
+    kernel reading r and writing w arrays of nwords 32-bit words -- the same
+    traffic as the CORDIC kernel, on the bench's own buffers (which it
+    OVERWRITES).  None if the library is not built."""
+    global _probe_lib
+    import ctypes as C
+    if _probe_lib is None:
+        path = os.path.join(ROOT, "tools", "libhbmprobe.so")
+        if not os.path.exists(path):
+            _probe_lib = False
+        else:
+            _probe_lib = C.CDLL(path)
+            _probe_lib.hbm_probe.restype = C.c_float
+            _probe_lib.hbm_probe.argtypes = [C.c_void_p] * 4 + [
+                C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if not _probe_lib:
+        return None
+    ms = _probe_lib.hbm_probe(in0, in1, out0, out1, nwords, r, w, mode, reps,
+                              stream)
+    return float(ms) if ms > 0 else None
+
+
+def copy_probe(ptrs, n, rw, reps=10):
+    """Both copy patterns over the arrays in `ptrs` = [in0, in1, out0, out1]:
+    `tiles` = the best streaming pattern found on this chip (one-shot 4 KiB
+    tiles), `queued` = the seeded kernel's own work distribution."""
+    r, w = rw
+    res = {}
+    for name, mode in (("tiles", 0), ("queued", 1)):
+        ms = hbm_probe(ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, r, w, mode, reps)
+        if ms is not None:
+            res[name + "_ms"] = ms
+    return res
 
 
 def bench_table(args, w, ca, dist, dev, world, rank):
@@ -321,9 +371,10 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             "roofline": {"bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _pmc_traffic(args.workload),
+                         "traffic": None,
                          "bytes_per_sample": w["bytes"],
                          "kernel_ms_avg": avg * 1e3},
+            "from_profile": from_profile(args.workload),
             "bit_exact_vs_oracle": ok}))
         sys.stdout.flush()
     if dist is not None:
@@ -331,43 +382,540 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-other-paths", action="store_true",
-                    help="skip the informational rates of the other entry "
-                    "points after the default (cfg2) run")
-    ap.add_argument("--log2-samples", type=int, default=30,
-                    help="samples per GPU = 2^this")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="also time gathering the outputs on rank 0 (RCCL)")
-    ap.add_argument("--input", default="ramp", choices=["ramp", "random"],
-                    help="ramp = BASELINE.json's deterministic inputs; random "
-                    "= uniformly random words (worst-case switching activity: "
-                    "the chip clocks lower, MI355X_MICROARCH.md DVFS)")
-    ap.add_argument("--no-seed", action="store_true",
-                    help="constant-vector feeds: full 16-stage recurrence per "
-                    "sample instead of the table-seeded kernel")
-    ap.add_argument("--static-chunks", action="store_true",
-                    help="seeded kernel: one contiguous chunk per persistent "
-                    "block instead of the address-ordered tile queue (A/B)")
-    ap.add_argument("--generic", action="store_true",
-                    help="force the generic (not unrolled) kernel")
-    args = ap.parse_args()
+RW = {"p2r": (1, 2), "nco": (0, 2), "r2p": (2, 2)}   # arrays read / written
 
+
+def visible_gpus():
+    """HIP devices this process can see, through the C ABI (no torch.cuda
+    initialisation in a parent that is about to exec)."""
+    import cordic_amd as ca
+    n = ca.device_count()
+    return n if n > 0 else 0
+
+
+def resolve_launch(args):
+    """How this invocation runs, and the checks that make `n_gpus` in the
+    output impossible to disagree with --gpus:
+      "torchrun"        started by torch.distributed.run: WORLD_SIZE == --gpus
+      "single-process"  --single-process: one host process, --gpus devices,
+                        the C++ cordic_group layer, no process group
+      "spawn"           plain `python bench.py --gpus N` with N > 1 (or
+                        --spawn): re-exec under torch.distributed.run with N
+                        ranks, one GPU each
+      "direct"          N = 1, this process"""
+    need = args.gpus
+    if need < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != need:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- start "
+                             "one rank per GPU (--nproc-per-node %d)"
+                             % (need, world, need))
+        have = visible_gpus()
+        if have < need:
+            raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, "
+                             "found %d" % (need, need, have))
+        return "torchrun"
+    have = visible_gpus()
+    if have < need:
+        raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d"
+                         % (need, need, have))
+    if args.single_process:
+        return "single-process"
+    if need > 1 or args.spawn:
+        return "spawn"
+    return "direct"
+
+
+def respawn(args):
+    """Replace this process by `python -m torch.distributed.run` with --gpus
+    ranks running this same command line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, BENCH_SELF_SPAWNED="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                   "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def spot_indices(n):
+    """(offset, count) windows of a shard checked against the oracle: both
+    ends and 61 windows spread through the middle."""
+    win = min(n, 4096)
+    offs = {0, n - win}
+    for k in range(1, 62):
+        offs.add(min(n - win, (k * (n // 62)) // 4 * 4))
+    return sorted((o, win) for o in offs)
+
+
+def run_group(args, w, launch):
+    """p2r / nco / r2p workloads through the C++ multi-GPU layer of the C ABI
+    (cordic_group_*): this process drives `nlocal` shards of `total`."""
+    import cordic_amd as ca
+    import oracle_lib as O
+    from gpu_util import cpu_digest
+
+    m, iw, ow, xtra, pw, ns = w["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    if args.generic:
+        cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+    if args.no_seed:
+        cfg = cfg.with_flags(ca.FLAG_NO_SEED)
+    if args.static_chunks:
+        cfg = cfg.with_flags(ca.FLAG_STATIC_CHUNKS)
+
+    dist = None
+    rank, world, local = 0, 1, 0
+    if launch == "torchrun":
+        import torch.distributed as dist
+        rank = int(os.environ["RANK"])
+        world = int(os.environ["WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if launch == "single-process":
+        total, nlocal, first = args.gpus, args.gpus, 0
+        devices = list(range(args.gpus))
+    else:
+        total, nlocal, first, devices = world, 1, rank, [local]
+
+    n = 1 << args.log2_samples
+    n_total = n * total
+    kind = w["kind"]
+    x0, y0 = (1 << (iw - 1)) - 1, 0
+    grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
+    seeded = False
+    if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
+        seeded = ca.Plan(cfg).seed_info["stages"] > 0
+
+    def fill(g):
+        if kind == "p2r":
+            g.fill_phase_ramp(n_total, w["shift"])
+        elif kind == "r2p":
+            g.fill_iq_ramp(n_total, 0x9E3779B1, 0x85EBCA77, iw)
+        else:
+            g.reserve(n_total, 0)
+        if args.input == "random" and kind != "nco":
+            for sh in range(nlocal):
+                with torch.cuda.device(devices[sh]):
+                    gen = torch.Generator(device="cuda").manual_seed(
+                        1234 + first + sh)
+                    lo, hi = ((-2**31, 2**31 - 1) if kind == "p2r" else
+                              (-2**(iw - 1), 2**(iw - 1) - 1))
+                    for arr in range(1 if kind == "p2r" else 2):
+                        t = torch.empty(n, dtype=torch.int32, device="cuda")
+                        t.random_(lo, hi, generator=gen)
+                        torch.cuda.synchronize()
+                        g.write(sh, arr, 0, t)
+        g.sync()
+
+    def step(g):
+        if kind == "p2r":
+            g.p2r_const(n_total, x0, y0)
+        elif kind == "r2p":
+            g.r2p(n_total)
+        else:
+            g.nco(n_total, 0, 0x01234567, x0, y0)
+
+    def barrier():
+        grp.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fill(grp)
+    step(grp)                   # allocates the outputs; first-launch costs
+    grp.sync()
+
+    # ---- same-run copy probes on the very arrays of shard 0 (before)
+    _, ptrs, _ = grp.buffers(0)
+    probes = []
+    if not args.no_copy_probe:
+        with torch.cuda.device(devices[0]):
+            probes.append(copy_probe(ptrs, n, RW[kind]))
+
+    for _ in range(args.warmup):
+        step(grp)
+    barrier()
+
+    # ---- timed region: exactly K steps; HIP events on the streams the
+    # kernels are launched on (the shards' compute streams, inside the C ABI)
+    every = max(1, -(-args.steps // 254))
+    marks = [0]
+    t0 = time.perf_counter()
+    grp.mark(0)
+    for k in range(args.steps):
+        step(grp)
+        if (k + 1) % every == 0 or k + 1 == args.steps:
+            grp.mark(len(marks))
+            marks.append(k + 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(v.item()) for v in allt]
+        elapsed = max(per_rank)
+    span_ms = [grp.elapsed(i, i + 1)[0] / (marks[i + 1] - marks[i])
+               for i in range(len(marks) - 1)]
+    kern_total_ms, per_shard_ms = grp.elapsed(0, len(marks) - 1)
+    kern_avg_s = kern_total_ms / args.steps / 1e3
+
+    # ---- after the timed region: correctness of what was just computed
+    digest = grp.digest(n_total)
+    if dist is not None:
+        d = torch.tensor([digest - (1 << 64) if digest >= 1 << 63 else digest],
+                         dtype=torch.int64, device=dev)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
+        digest = int(d.item()) & 0xFFFFFFFFFFFFFFFF
+
+    check = digest_check = None
+    if rank == 0:
+        ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+        start0 = grp.range(n_total, first)[0]
+
+        def oracle(off, cnt):
+            if kind == "r2p":
+                xi = grp.read(0, 0, off, cnt)
+                yi = grp.read(0, 1, off, cnt)
+                ra, rb = O.topolar(ocfg, xi, yi)
+                return ra, rb.view(np.int32)
+            if kind == "p2r":
+                ph = grp.read(0, 0, off, cnt).view(np.uint32)
+            else:
+                idx = np.arange(cnt, dtype=np.uint64) + np.uint64(start0 + off)
+                ph = ((idx * np.uint64(0x01234567))
+                      & np.uint64(0xffffffff)).astype(np.uint32)
+            return O.rotate(ocfg, x0, y0, ph)
+        check = True
+        for off, cnt in spot_indices(n):
+            ra, rb = oracle(off, cnt)
+            check = check and bool(
+                np.array_equal(grp.read(0, 2, off, cnt), ra)
+                and np.array_equal(grp.read(0, 3, off, cnt), rb))
+        # the device digest kernel against the oracle's outputs over the same
+        # leading 2^20 samples of shard 0
+        cnt = min(n, 1 << 20)
+        ra, rb = oracle(0, cnt)
+        want = (cpu_digest(ra, start0)
+                + cpu_digest(rb, start0 + (1 << 40))) % (1 << 64)
+        with torch.cuda.device(devices[0]):
+            dd = torch.zeros(1, dtype=torch.int64, device="cuda")
+            ca.digest_u32(ptrs[2], start0, dd, n=cnt)
+            ca.digest_u32(ptrs[3], start0 + (1 << 40), dd, n=cnt)
+            torch.cuda.synchronize()
+            got = int(dd.cpu().numpy().view(np.uint64)[0])
+        digest_check = {"samples": cnt, "device": "%016x" % got,
+                        "oracle": "%016x" % want, "equal": got == want}
+
+    # ---- constant-vector feeds: also time the full-recurrence kernel (every
+    # sample runs all micro-rotations) so both numbers are on record
+    full = None
+    if seeded:
+        grp2 = ca.Group(cfg.with_flags(ca.FLAG_NO_SEED), devices=devices,
+                        first_shard=first, total_shards=total)
+        for sh in range(nlocal):        # same inputs, bit for bit
+            grp2.reserve(n_total, 1 if kind == "p2r" else 0)
+            if kind == "p2r":
+                _, p1, _ = grp.buffers(sh)
+                grp2.write(sh, 0, 0, _RawWords(p1[0], n))
+        k2 = max(3, min(args.steps, 10))
+        step(grp2)
+        grp2.sync()
+        grp2.mark(0)
+        for _ in range(k2):
+            step(grp2)
+        grp2.mark(1)
+        ms2 = grp2.elapsed(0, 1)[0] / k2
+        d2 = grp2.digest(n_total)
+        if dist is not None:
+            d = torch.tensor([d2 - (1 << 64) if d2 >= 1 << 63 else d2],
+                             dtype=torch.int64, device=dev)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM)
+            d2 = int(d.item()) & 0xFFFFFFFFFFFFFFFF
+        full = {"ms_per_step": ms2, "steps": k2,
+                "value_per_gpu": n / ms2 / 1e3,
+                "hbm_frac": w["bytes"] * n / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "outputs_identical_to_seeded_kernel": d2 == digest,
+                "compared_by": "64-bit position-aware digest of all outputs",
+                "from_profile": from_profile(args.workload + "_noseed")}
+        grp2.close()
+
+    gather = None
+    if args.gather and total > 1:
+        gather = time_gather(args, grp, step, launch, dist, dev, devices, n,
+                             n_total, rank, world, barrier)
+
+    # ---- same-run copy probes again (after): the memory system may have
+    # changed state under sustained load (DESIGN.md 4.4)
+    if not args.no_copy_probe:
+        with torch.cuda.device(devices[0]):
+            probes.append(copy_probe(ptrs, n, RW[kind]))
+
+    grp.close()
+    single = None
+    if (launch == "torchrun" and world > 1 and not args.no_single_process_check):
+        # the C++ one-process layer on the same GPUs, for the record: rank 0
+        # drives every device while the other ranks wait on the HOST (a gloo
+        # barrier: no GPU kernel spins meanwhile)
+        host = dist.new_group(backend="gloo")
+        torch.cuda.empty_cache()
+        if rank == 0:
+            try:
+                single = single_process_block(args, cfg, w, world, step_kind=kind,
+                                              x0=x0, y0=y0, expect=digest)
+            except Exception as e:            # never lose the main line
+                single = {"error": repr(e)}
+        dist.barrier(group=host)
+
+    if rank == 0:
+        value = float(total) * n * args.steps / elapsed / 1e6
+        achieved = w["bytes"] * n / kern_avg_s / 1e9
+        roof = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_sample": w["bytes"],
+            "kernel_ms_avg": kern_avg_s * 1e3,
+            "kernel_ms_min": float(min(span_ms)),
+            "kernel_ms_max": float(max(span_ms)),
+        }
+        if probes and probes[0]:
+            # the plain-copy ceiling of THIS run on THESE arrays: best of the
+            # probes before and after the timed region
+            best = {}
+            for pr in probes:
+                for k, v in pr.items():
+                    best[k] = min(v, best.get(k, v))
+            roof["copy"] = {
+                "what": "arithmetic-free kernels with this kernel's traffic "
+                        "(%dR%dW x 4 B/sample) on the same arrays, 10 "
+                        "launches each before and after the timed region "
+                        "(tools/hbm_probe_lib.hip)" % RW[kind],
+                "before": probes[0], "after": probes[-1]}
+            if "tiles_ms" in best:
+                cf = w["bytes"] * n / (best["tiles_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                roof["copy_frac"] = cf
+                roof["frac_over_copy"] = roof["frac"] / cf
+            if "queued_ms" in best:
+                roof["copy_frac_same_distribution"] = (
+                    w["bytes"] * n / (best["queued_ms"] * 1e-3) / 1e9
+                    / HBM_PEAK_GBS)
+        out = {
+            "metric": "Msamples/sec (sin+cos pairs) at 16-stage/32-bit"
+                      if args.workload == "cfg2" else
+                      "Msamples/sec (%s)" % args.workload,
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": total,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64" if cfg.ww > 32 else "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s" % (args.workload, w["desc"]),
+                "samples_per_gpu": n,
+                "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
+                "nstages": cfg.nstages, "rotations": cfg.nlive,
+                "kernel": "generic" if args.generic else (
+                    "seeded(10)+unrolled, %s" % (
+                        "static chunks" if args.static_chunks
+                        else "address-ordered tile queue")
+                    if seeded else "unrolled"),
+                "input": args.input,
+                "parallelism": "shard%d" % total,
+            },
+            "launch": {
+                "mode": {"torchrun": "one process per GPU (torch.distributed"
+                         ".run%s), RCCL only for the digest all-reduce" % (
+                             ", self-spawned by bench.py" if os.environ.get(
+                                 "BENCH_SELF_SPAWNED") else ""),
+                         "single-process": "one host process, %d devices, C++ "
+                         "cordic_group layer, no process group" % total,
+                         "direct": "one process, one device"}[launch],
+                "world_size": world,
+                "shards_per_process": nlocal,
+                "per_rank_Msamples_per_s": [
+                    nlocal * n * args.steps / t / 1e6 for t in per_rank],
+                "per_shard_kernel_ms": [v / args.steps for v in per_shard_ms],
+            },
+            "roofline": roof,
+            "from_profile": from_profile(
+                args.workload + ("_noseed" if args.no_seed else "")),
+            "bit_exact_vs_oracle": check,
+            "digest": "%016x" % digest,
+            "digest_check": digest_check,
+        }
+        if full is not None:
+            out["full_recurrence_kernel"] = full
+        if gather is not None:
+            out["gather"] = gather
+        if single is not None:
+            out["single_process_cordic_group"] = single
+        if not args.no_cpu_baseline and total == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
+            torch.cuda.empty_cache()
+            out["other_paths"] = other_paths(ca, dev)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _RawWords:
+    """A device address + word count, shaped like what Group.write accepts."""
+
+    def __init__(self, ptr, n):
+        self._p, self._n = ptr, n
+
+    def data_ptr(self):
+        return self._p
+
+    def numel(self):
+        return self._n
+
+
+def single_process_block(args, cfg, w, ndev, step_kind, x0, y0, expect):
+    """One host process, every GPU, through cordic_group (rank 0 of a
+    multi-process run, after the main measurement)."""
+    import cordic_amd as ca
+    n = 1 << args.log2_samples
+    n_total = n * ndev
+    g = ca.Group(cfg, devices=list(range(ndev)), first_shard=0,
+                 total_shards=ndev)
+
+    def step():
+        if step_kind == "p2r":
+            g.p2r_const(n_total, x0, y0)
+        elif step_kind == "r2p":
+            g.r2p(n_total)
+        else:
+            g.nco(n_total, 0, 0x01234567, x0, y0)
+    if step_kind == "p2r":
+        g.fill_phase_ramp(n_total, w["shift"])
+    elif step_kind == "r2p":
+        g.fill_iq_ramp(n_total, 0x9E3779B1, 0x85EBCA77, cfg.iw)
+    for _ in range(max(1, args.warmup)):
+        step()
+    g.sync()
+    t0 = time.perf_counter()
+    g.mark(0)
+    for _ in range(args.steps):
+        step()
+    g.mark(1)
+    g.sync()
+    wall = time.perf_counter() - t0
+    ms, per = g.elapsed(0, 1)
+    res = {"n_gpus": ndev, "steps": args.steps,
+           "value": n_total * args.steps / wall / 1e6, "unit": "Msamples/s",
+           "ms_per_step": wall / args.steps * 1e3,
+           "per_shard_kernel_ms": [v / args.steps for v in per]}
+    if args.input == "ramp":
+        res["digest_equals_multi_process_run"] = g.digest(n_total) == expect
+    # and with the results forwarded to device 0 behind the compute
+    root = ca.Group(cfg, devices=[0], first_shard=0, total_shards=1)
+    root.reserve(n_total, 0)
+    _, rp, _ = root.buffers(0)
+    g.set_gather(0, rp[2], rp[3], 8)
+    step()
+    g.sync()
+    t0 = time.perf_counter()
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+    g.sync()
+    k = max(3, min(args.steps, 10))
+    wall = time.perf_counter() - t0
+    res["compute_and_gather"] = {
+        "what": "every step's outputs forwarded to device 0 in 8 pieces "
+                "(hipMemcpyPeerAsync on the shards' copy streams) while the "
+                "next piece is being computed",
+        "steps": k, "ms_per_step": wall / k * 1e3,
+        "value": n_total * k / wall / 1e6,
+        "gathered_digest_equal": (root.digest(n_total) == g.digest(n_total))}
+    g.set_gather(-1)
+    root.close()
+    g.close()
+    return res
+
+
+def time_gather(args, grp, step, launch, dist, dev, devices, n, n_total, rank,
+                world, barrier):
+    """Collecting the outputs on one GPU, timed separately (never part of
+    `value`): C++ peer copies in the single-process layout, RCCL gather in the
+    process-per-GPU layout."""
+    import cordic_amd as ca
+    if launch == "single-process":
+        root = ca.Group(grp.cfg, devices=[devices[0]], first_shard=0,
+                        total_shards=1)
+        root.reserve(n_total, 0)
+        _, rp, _ = root.buffers(0)
+        grp.set_gather(devices[0], rp[2], rp[3], 8)
+        step(grp)
+        grp.sync()
+        k = max(3, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step(grp)
+        grp.sync()
+        ms = (time.perf_counter() - t1) / k * 1e3
+        ok = root.digest(n_total) == grp.digest(n_total)
+        grp.set_gather(-1)
+        root.close()
+        return {"mode": "hipMemcpyPeerAsync, 8 pieces per shard behind the "
+                "compute (cordic_group_set_gather)",
+                "ms_compute_and_gather": ms, "outputs_identical": ok}
+    if dist is None:
+        return None
+    a = torch.empty(n, dtype=torch.int32, device=dev)
+    b = torch.empty(n, dtype=torch.int32, device=dev)
+    grp.read_into(0, 2, 0, a)
+    grp.read_into(0, 3, 0, b)
+    outs = None
+    if rank == 0:
+        outs = [torch.empty(2 * n, dtype=torch.int32, device=dev)
+                for _ in range(world)]
+    ab = torch.cat([a, b])
+    barrier()
+    t1 = time.perf_counter()
+    dist.gather(ab, outs, dst=0)
+    barrier()
+    return {"mode": "RCCL gather of finished outputs to rank 0",
+            "ms_gather_only": (time.perf_counter() - t1) * 1e3}
+
+
+def run_direct(args, w, launch):
+    """Workloads outside the cordic_group layer -- 16-bit sample containers
+    (cfg1), per-sample x/y vectors (p2rxy) and the table cores -- on torch
+    tensors through the stateless entry points; one process per GPU."""
     import cordic_amd as ca
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launch == "torchrun" else 1
+    rank = int(os.environ.get("RANK", "0")) if launch == "torchrun" else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if launch == "torchrun" else 0
     dist = None
-    if world > 1 or "RANK" in os.environ:
+    if launch == "torchrun":
         # launched by torch.distributed.run: RCCL process group (also for a
         # single rank, so that the collective path can be exercised on 1 GPU)
         import torch.distributed as dist
@@ -536,52 +1084,10 @@ def main():
                 "outputs_identical_to_seeded_kernel": same}
         del a2, b2
 
-    gather_ms = None
-    if args.gather and dist is not None:
-        # collect the output shards on rank 0 (RCCL gather over xGMI); timed
-        # separately, never folded into `value`
-        outs = None
-        if rank == 0:
-            outs = [torch.empty(2 * n, dtype=sdt, device=dev)
-                    for _ in range(world)]
-        ab = torch.cat([a, b])
-        barrier()
-        t1 = time.perf_counter()
-        dist.gather(ab, outs, dst=0)
-        barrier()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-        del outs, ab
-        # end to end, pipelined: one step computed in 8 chunks, every chunk's
-        # outputs sent to rank 0 on a side stream while the next chunk is
-        # being computed (cordic_amd/shard.py:pipelined_gather)
-        gather_pipelined = None
-        if w["kind"] == "p2r":
-            from cordic_amd.shard import pipelined_gather
-            a3, b3 = torch.zeros_like(a), torch.zeros_like(b)
-            comm = torch.cuda.Stream(device=dev)
-
-            def compute_chunk(lo, hi):
-                plan.p2r_const(x0, y0, phase[lo:hi], a3[lo:hi], b3[lo:hi])
-            barrier()
-            t1 = time.perf_counter()
-            got = pipelined_gather(compute_chunk, [a3, b3], chunks=8, dst=0,
-                                   comm_stream=comm)
-            barrier()
-            ms = (time.perf_counter() - t1) * 1e3
-            ok = bool(torch.equal(a3, a) and torch.equal(b3, b))
-            if rank == 0:
-                ok = ok and bool(torch.equal(got[0][0], a)
-                                 and torch.equal(got[1][0], b))
-            gather_pipelined = {"ms_compute_and_gather": ms, "chunks": 8,
-                                "outputs_identical": ok}
-            del got, a3, b3
-
     if rank == 0:
         total = float(world) * n * args.steps
         value = total / elapsed / 1e6
         achieved = w["bytes"] * n / kern_avg_s / 1e9
-        traffic = _pmc_traffic(args.workload
-                               + ("_noseed" if args.no_seed else ""))
         out = {
             "metric": "Msamples/sec (sin+cos pairs) at 16-stage/32-bit"
                       if args.workload == "cfg2" else
@@ -614,42 +1120,77 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": None,
                 "bytes_per_sample": w["bytes"],
                 "kernel_ms_avg": kern_avg_s * 1e3,
                 "kernel_ms_min": float(np.min(kern_ms)),
-                "note": ("table-seeded kernel: within ~5 % of an arithmetic-"
-                         "free kernel with the same 4 B in / 8 B out traffic "
-                         "(tools/hbm_pattern_bench.hip reaches 0.62-0.66 of "
-                         "peak for this pattern); the full-recurrence kernel "
-                         "is integer-VALU bound (DESIGN.md 4.5)"
-                         if (w["kind"] in ("p2r", "nco") and not args.no_seed
-                             and not args.generic) else
-                         "integer-VALU bound, not HBM bound: DESIGN.md 4.5"),
             },
-            "valu": _pmc_valu(args.workload
-                              + ("_noseed" if args.no_seed else ""),
-                              1 << 30, n / kern_avg_s),
+            "from_profile": from_profile(
+                args.workload + ("_noseed" if args.no_seed else "")),
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,
         }
         if full is not None:
             out["full_recurrence_kernel"] = full
-        if gather_ms is not None:
-            out["gather_ms"] = gather_ms
-            if gather_pipelined is not None:
-                out["gather_pipelined"] = gather_pipelined
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        if world == 1 and args.workload == "cfg2" and not args.no_other_paths:
-            del a, b, phase
-            torch.cuda.empty_cache()
-            out["other_paths"] = other_paths(ca, dev)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--single-process", action="store_true",
+                    help="one host process drives all --gpus devices through "
+                    "the C++ cordic_group layer (no torch.distributed)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the self-launch path (re-exec under "
+                    "torch.distributed.run) even for --gpus 1")
+    ap.add_argument("--no-other-paths", action="store_true",
+                    help="skip the informational rates of the other entry "
+                    "points after the default (cfg2) run")
+    ap.add_argument("--log2-samples", type=int, default=30,
+                    help="samples per GPU = 2^this")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-probe", action="store_true")
+    ap.add_argument("--no-single-process-check", action="store_true",
+                    help="multi-process runs: skip the extra one-process "
+                    "cordic_group measurement on rank 0")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time collecting the outputs on one GPU")
+    ap.add_argument("--input", default="ramp", choices=["ramp", "random"],
+                    help="ramp = BASELINE.json's deterministic inputs; random "
+                    "= uniformly random words (worst-case switching activity: "
+                    "the chip clocks lower, MI355X_MICROARCH.md DVFS)")
+    ap.add_argument("--no-seed", action="store_true",
+                    help="constant-vector feeds: full 16-stage recurrence per "
+                    "sample instead of the table-seeded kernel")
+    ap.add_argument("--static-chunks", action="store_true",
+                    help="seeded kernel: one contiguous chunk per persistent "
+                    "block instead of the address-ordered tile queue (A/B)")
+    ap.add_argument("--generic", action="store_true",
+                    help="force the generic (not unrolled) kernel")
+    args = ap.parse_args()
+
+    launch = resolve_launch(args)
+    if launch == "spawn":
+        respawn(args)               # does not return
+    w = WORKLOADS[args.workload]
+    if w["kind"] in RW and not w.get("io16"):
+        return run_group(args, w, launch)
+    if launch == "single-process":
+        raise SystemExit("bench.py: --single-process covers the p2r / nco / "
+                         "r2p workloads on 32-bit containers")
+    return run_direct(args, w, launch)
 
 
 if __name__ == "__main__":

@@ -109,6 +109,45 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_device_count": (C.c_int, []),
+    "cordic_shard_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int,
+                                     C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64)]),
+    "cordic_group_create": (C.c_int, [_cfgp, C.c_int, C.POINTER(C.c_int),
+                                      C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "cordic_group_destroy": (None, [C.c_void_p]),
+    "cordic_group_size": (C.c_int, [C.c_void_p]),
+    "cordic_group_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int,
+                                     C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64)]),
+    "cordic_group_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "cordic_group_fill_phase_ramp": (C.c_int, [C.c_void_p, C.c_uint64,
+                                               C.c_int]),
+    "cordic_group_fill_iq_ramp": (C.c_int, [C.c_void_p, C.c_uint64,
+                                            C.c_uint32, C.c_uint32, C.c_int]),
+    "cordic_group_p2r_const": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32,
+                                         C.c_int32]),
+    "cordic_group_nco": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32,
+                                   C.c_uint32, C.c_int32, C.c_int32]),
+    "cordic_group_r2p": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cordic_group_sync": (C.c_int, [C.c_void_p]),
+    "cordic_group_digest": (C.c_int, [C.c_void_p, C.c_uint64,
+                                      C.POINTER(C.c_uint64)]),
+    "cordic_group_set_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int]),
+    "cordic_group_mark": (C.c_int, [C.c_void_p, C.c_int]),
+    "cordic_group_elapsed": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
+                                       C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float)]),
+    "cordic_group_buffers": (C.c_int, [C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_int)] +
+                             [C.POINTER(C.c_void_p)] * 4 +
+                             [C.POINTER(C.c_uint64)]),
+    "cordic_group_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64,
+                                    C.c_uint64, C.c_void_p]),
+    "cordic_group_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
+                                     C.c_uint64, C.c_uint64, C.c_void_p]),
     "cordic_gain_annihilator": (C.c_uint32, [C.c_int]),
     "cordic_config_gain_annihilator": (C.c_uint32, [_cfgp]),
     "cordic_stream_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
@@ -311,6 +350,144 @@ class Plan:
                                      fcw & 0xffffffff, index0, x0, y0,
                                      _ptr(ox), _ptr(oy), _stream(stream)),
                "cordic_plan_nco")
+
+
+class Group:
+    """cordic_group: the local shards of a multi-GPU job (include/
+    cordic_amd.h, "multi-GPU jobs").  devices=None: ordinals 0..nlocal-1."""
+
+    IN0, IN1, OUT0, OUT1 = 0, 1, 2, 3
+
+    def __init__(self, cfg, nlocal=1, devices=None, first_shard=0,
+                 total_shards=None):
+        self.cfg = cfg
+        dv = None
+        if devices is not None:
+            nlocal = len(devices)
+            dv = (C.c_int * nlocal)(*devices)
+        total = nlocal if total_shards is None else total_shards
+        h = C.c_void_p()
+        _check(lib().cordic_group_create(cfg.ref, nlocal, dv, first_shard,
+                                         total, C.byref(h)),
+               "cordic_group_create")
+        self._h = h
+        self.nlocal, self.first, self.total = nlocal, first_shard, total
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cordic_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def range(self, n_total, shard):
+        a, c = C.c_uint64(), C.c_uint64()
+        _check(lib().cordic_group_range(self._h, n_total, shard, C.byref(a),
+                                        C.byref(c)), "cordic_group_range")
+        return a.value, c.value
+
+    def reserve(self, n_total, inputs):
+        _check(lib().cordic_group_reserve(self._h, n_total, inputs),
+               "cordic_group_reserve")
+
+    def fill_phase_ramp(self, n_total, shift):
+        _check(lib().cordic_group_fill_phase_ramp(self._h, n_total, shift),
+               "cordic_group_fill_phase_ramp")
+
+    def fill_iq_ramp(self, n_total, mulx, muly, bits):
+        _check(lib().cordic_group_fill_iq_ramp(self._h, n_total, mulx, muly,
+                                               bits),
+               "cordic_group_fill_iq_ramp")
+
+    def p2r_const(self, n_total, x0, y0):
+        _check(lib().cordic_group_p2r_const(self._h, n_total, x0, y0),
+               "cordic_group_p2r_const")
+
+    def nco(self, n_total, phase0, fcw, x0, y0):
+        _check(lib().cordic_group_nco(self._h, n_total, phase0 & 0xffffffff,
+                                      fcw & 0xffffffff, x0, y0),
+               "cordic_group_nco")
+
+    def r2p(self, n_total):
+        _check(lib().cordic_group_r2p(self._h, n_total), "cordic_group_r2p")
+
+    def sync(self):
+        _check(lib().cordic_group_sync(self._h), "cordic_group_sync")
+
+    def digest(self, n_total):
+        d = C.c_uint64()
+        _check(lib().cordic_group_digest(self._h, n_total, C.byref(d)),
+               "cordic_group_digest")
+        return d.value
+
+    def set_gather(self, root_device, out0=None, out1=None, chunks=8):
+        """out0 / out1: device tensors or raw device addresses."""
+        def addr(t):
+            return t if isinstance(t, int) or t is None else _ptr(t)
+        _check(lib().cordic_group_set_gather(self._h, root_device, addr(out0),
+                                             addr(out1), chunks),
+               "cordic_group_set_gather")
+
+    def mark(self, slot):
+        _check(lib().cordic_group_mark(self._h, slot), "cordic_group_mark")
+
+    def elapsed(self, a, b):
+        """(max over the local shards, [per shard]) in ms."""
+        mx = C.c_float()
+        per = (C.c_float * self.nlocal)()
+        _check(lib().cordic_group_elapsed(self._h, a, b, C.byref(mx), per),
+               "cordic_group_elapsed")
+        return mx.value, list(per)
+
+    def buffers(self, local_shard):
+        dev = C.c_int()
+        p = [C.c_void_p() for _ in range(4)]
+        cap = C.c_uint64()
+        _check(lib().cordic_group_buffers(self._h, local_shard, C.byref(dev),
+                                          *[C.byref(q) for q in p],
+                                          C.byref(cap)),
+               "cordic_group_buffers")
+        return dev.value, [q.value for q in p], cap.value
+
+    def read(self, local_shard, array, offset, count, dtype=None):
+        import numpy as np
+        out = np.empty(count, dtype=np.int32 if dtype is None else dtype)
+        _check(lib().cordic_group_read(self._h, local_shard, array, offset,
+                                       count, out.ctypes.data), "cordic_group_read")
+        return out
+
+    def read_into(self, local_shard, array, offset, dst):
+        """dst: device tensor (or numpy array) of 32-bit words to fill."""
+        if hasattr(dst, "ctypes"):
+            addr, count = dst.ctypes.data, dst.size
+        else:
+            addr, count = _ptr(dst), dst.numel()
+        _check(lib().cordic_group_read(self._h, local_shard, array, offset,
+                                       count, addr), "cordic_group_read")
+
+    def write(self, local_shard, array, offset, src):
+        """src: numpy array (host) or device tensor of 32-bit words."""
+        if hasattr(src, "ctypes"):
+            addr, count = src.ctypes.data, src.size
+        else:
+            addr, count = _ptr(src), src.numel()
+        _check(lib().cordic_group_write(self._h, local_shard, array, offset,
+                                        count, addr), "cordic_group_write")
+
+
+def device_count():
+    return lib().cordic_device_count()
+
+
+def shard_range(n_total, shard, total_shards):
+    a, c = C.c_uint64(), C.c_uint64()
+    _check(lib().cordic_shard_range(n_total, shard, total_shards, C.byref(a),
+                                    C.byref(c)), "cordic_shard_range")
+    return a.value, c.value
 
 
 TBL, QTR = 4, 5

@@ -183,6 +183,16 @@ int cordic_device_count(void)
 	return n;
 }
 
+int cordic_shard_range(uint64_t n_total, int shard, int total_shards,
+		uint64_t *start, uint64_t *count)
+{
+	if (total_shards < 1 || shard < 0 || shard >= total_shards || !start
+			|| !count)
+		return CORDIC_ERR_ARGS;
+	shard_span(n_total, shard, total_shards, start, count);
+	return CORDIC_OK;
+}
+
 void cordic_group_destroy(cordic_group *grp)
 {
 	if (!grp)
@@ -492,7 +502,27 @@ int cordic_group_read(cordic_group *grp, int local_shard, int array,
 	if (!ok(hipSetDevice(s.device)) ||
 	    !ok(hipStreamSynchronize(s.compute)) ||
 	    !ok(hipMemcpy(host_dst, static_cast<const uint32_t *>(s.buf[array])
-			+ offset, (size_t)count * 4, hipMemcpyDeviceToHost)))
+			+ offset, (size_t)count * 4, hipMemcpyDefault)))
+		return CORDIC_ERR_DEVICE;
+	return CORDIC_OK;
+}
+
+int cordic_group_write(cordic_group *grp, int local_shard, int array,
+		uint64_t offset, uint64_t count, const void *src)
+{
+	if (!grp || local_shard < 0 || local_shard >= (int)grp->shards.size()
+			|| array < 0 || array > 3 || !src)
+		return CORDIC_ERR_ARGS;
+	Shard &s = grp->shards[(size_t)local_shard];
+	if (!s.buf[array] || offset > s.cap || count > s.cap - offset)
+		return CORDIC_ERR_ARGS;
+	if (count == 0)
+		return CORDIC_OK;
+	DeviceScope scope;
+	if (!ok(hipSetDevice(s.device)) ||
+	    !ok(hipStreamSynchronize(s.compute)) ||
+	    !ok(hipMemcpy(static_cast<uint32_t *>(s.buf[array]) + offset, src,
+			(size_t)count * 4, hipMemcpyDefault)))
 		return CORDIC_ERR_DEVICE;
 	return CORDIC_OK;
 }

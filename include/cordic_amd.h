@@ -477,6 +477,10 @@ int	cordic_seq_violations(cordic_seq *s, uint64_t *count);
 typedef struct cordic_group cordic_group;
 
 int	cordic_device_count(void);	/* visible HIP devices, or a negative status */
+/* [start, start+count) of shard `shard` of `total_shards` of an n_total job
+ * (host arithmetic only: no device needed) */
+int	cordic_shard_range(uint64_t n_total, int shard, int total_shards,
+		uint64_t *start, uint64_t *count);
 int	cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices,
 		int first_shard, int total_shards, cordic_group **grp);
 void	cordic_group_destroy(cordic_group *grp);
@@ -523,11 +527,16 @@ int	cordic_group_mark(cordic_group *grp, int slot);
 int	cordic_group_elapsed(cordic_group *grp, int slot_a, int slot_b,
 		float *max_ms, float *per_shard_ms);
 /* Shard-local views for callers that consume the results in place, and a
- * host read-back for checks: array 0..3 = in0, in1, out0, out1. */
+ * read-back for checks (the destination may be host or device memory):
+ * array 0..3 = in0, in1, out0, out1. */
 int	cordic_group_buffers(const cordic_group *grp, int local_shard, int *device,
 		void **in0, void **in1, void **out0, void **out1, uint64_t *count);
 int	cordic_group_read(cordic_group *grp, int local_shard, int array,
 		uint64_t offset, uint64_t count, void *host_dst);
+/* the reverse: fill `count` words of a shard's array from host or device
+ * memory (e.g. caller-provided inputs instead of the generated ramps) */
+int	cordic_group_write(cordic_group *grp, int local_shard, int array,
+		uint64_t offset, uint64_t count, const void *src);
 
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,

@@ -1,0 +1,81 @@
+"""bench.py --gpus N can never report a different GPU count than it ran on
+("Next round" 1): without enough visible GPUs it fails loudly,
+a WORLD_SIZE that disagrees with --gpus is refused, and on a GPU box the
+self-launch path (re-exec under torch.distributed.run) and the one-process
+cordic_group path both produce a line with n_gpus == --gpus."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, text=True,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
+
+
+def test_more_gpus_than_visible_is_a_loud_error():
+    r = run(["--gpus", "64"])
+    assert r.returncode != 0
+    assert re.search(r"--gpus 64 needs 64 visible GPUs, found \d+", r.stderr)
+    assert r.stdout.strip() == ""           # no result line at all
+
+
+def test_world_size_must_equal_gpus():
+    r = run(["--gpus", "8"], env={"RANK": "0", "WORLD_SIZE": "4",
+                                  "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "--gpus 8 but WORLD_SIZE=4" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def _line(stdout):
+    rows = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1, stdout
+    return json.loads(rows[0])
+
+
+SMALL = ["--steps", "5", "--warmup", "1", "--log2-samples", "22",
+         "--no-cpu-baseline", "--no-other-paths"]
+
+
+@pytest.mark.gpu
+def test_self_spawn_path_one_gpu():
+    r = run(["--gpus", "1", "--spawn"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["launch"]["world_size"] == 1
+    assert "self-spawned" in d["launch"]["mode"]
+    assert d["bit_exact_vs_oracle"] is True
+    assert d["digest_check"]["equal"] is True
+    assert d["full_recurrence_kernel"]["outputs_identical_to_seeded_kernel"]
+
+
+@pytest.mark.gpu
+def test_single_process_path_and_direct_agree():
+    a = _line(run(["--gpus", "1", "--single-process"] + SMALL).stdout)
+    b = _line(run(["--gpus", "1"] + SMALL).stdout)
+    assert a["n_gpus"] == b["n_gpus"] == 1
+    assert a["digest"] == b["digest"]
+    assert a["bit_exact_vs_oracle"] and b["bit_exact_vs_oracle"]
+    assert "copy_frac" in b["roofline"]
+
+
+@pytest.mark.gpu
+def test_two_gpus_on_a_one_gpu_box_is_refused():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    r = run(["--gpus", "2"] + SMALL)
+    assert r.returncode != 0 and "needs 2 visible GPUs, found 1" in r.stderr

@@ -1,0 +1,150 @@
+"""cordic_group_* on the GPU: the C++ multi-GPU layer of the C ABI, exercised
+on ONE device by placing several shards on it (a device may be listed more
+than once).  Digests of any sharding equal the digest of the same global range
+computed in one piece; outputs equal the oracle; forwarded (gathered) results
+equal what the shards hold."""
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+from gpu_util import cpu_digest
+
+pytestmark = pytest.mark.gpu
+
+CFG4 = (ca.P2R, 32, 32, 2, 32, 24)          # BASELINE.json configs[3] core
+AMP = 2**31 - 1
+
+
+def both(*a):
+    return ca.Config.from_cli(*a), O.config_cli(*a)
+
+
+def oracle_p2r(ocfg, start, cnt, shift=0):
+    idx = np.arange(cnt, dtype=np.uint64) + np.uint64(start)
+    ph = ((idx << np.uint64(shift)) & np.uint64(0xffffffff)).astype(np.uint32)
+    return O.rotate(ocfg, AMP, 0, ph)
+
+
+@pytest.mark.parametrize("n_total", [1 << 20, (1 << 20) + 4099, 12345, 3])
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_p2r_shards_match_oracle_and_digest_adds(n_total, shards):
+    cfg, ocfg = both(*CFG4)
+    g = ca.Group(cfg, devices=[0] * shards)
+    g.fill_phase_ramp(n_total, 0)
+    g.p2r_const(n_total, AMP, 0)
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    for s in range(shards):
+        a, c = g.range(n_total, s)
+        assert (a, c) == ca.shard_range(n_total, s, shards)
+        if c:
+            assert np.array_equal(g.read(s, g.OUT0, 0, c), rx[a:a + c])
+            assert np.array_equal(g.read(s, g.OUT1, 0, c), ry[a:a + c])
+    want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
+    assert g.digest(n_total) == want
+    g.close()
+
+
+def test_process_per_gpu_layout_digests_add():
+    """Two groups of one shard each (what two ranks would hold) add up."""
+    cfg, ocfg = both(*CFG4)
+    n_total = (1 << 19) + 77
+    total = 0
+    for rank in range(2):
+        g = ca.Group(cfg, devices=[0], first_shard=rank, total_shards=2)
+        g.fill_phase_ramp(n_total, 0)
+        g.p2r_const(n_total, AMP, 0)
+        total = (total + g.digest(n_total)) % 2**64
+        g.close()
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    assert total == (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
+
+
+def test_nco_and_r2p_shards():
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n_total = (1 << 18) + 5
+    g = ca.Group(cfg, devices=[0, 0])
+    g.nco(n_total, 0x1000, 0x01234567, AMP, 0)
+    idx = np.arange(n_total, dtype=np.uint64)
+    ph = ((np.uint64(0x1000) + idx * np.uint64(0x01234567))
+          & np.uint64(0xffffffff)).astype(np.uint32)
+    rx, ry = O.rotate(ocfg, AMP, 0, ph)
+    got = np.concatenate([g.read(s, g.OUT0, 0, g.range(n_total, s)[1])
+                          for s in range(2)])
+    assert np.array_equal(got, rx)
+    assert g.digest(n_total) == (cpu_digest(rx, 0)
+                                 + cpu_digest(ry, 1 << 40)) % 2**64
+    g.close()
+
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    g = ca.Group(cfg, devices=[0, 0, 0])
+    g.fill_iq_ramp(n_total, 0x9E3779B1, 0x85EBCA77, 24)
+    g.r2p(n_total)
+    for s in range(3):
+        a, c = g.range(n_total, s)
+        xi, yi = g.read(s, g.IN0, 0, c), g.read(s, g.IN1, 0, c)
+        i = (np.arange(c, dtype=np.uint64) + np.uint64(a)).astype(np.uint32)
+        ex = ((i * np.uint32(0x9E3779B1)) >> np.uint32(8)).astype(np.int64)
+        ex = ((ex & 0xffffff) ^ 0x800000) - 0x800000
+        assert np.array_equal(xi, ex.astype(np.int32))   # ramp by GLOBAL index
+        rm, rp = O.topolar(ocfg, xi, yi)
+        assert np.array_equal(g.read(s, g.OUT0, 0, c), rm)
+        assert np.array_equal(g.read(s, g.OUT1, 0, c).view(np.uint32), rp)
+    g.close()
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+def test_forwarding_to_one_consumer(chunks):
+    cfg, ocfg = both(*CFG4)
+    n_total = (1 << 20) + 4101
+    g = ca.Group(cfg, devices=[0, 0, 0])
+    root = ca.Group(cfg, devices=[0])
+    root.reserve(n_total, 0)
+    _, rp, _ = root.buffers(0)
+    g.fill_phase_ramp(n_total, 0)
+    g.set_gather(0, rp[2], rp[3], chunks)
+    g.p2r_const(n_total, AMP, 0)
+    g.sync()
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    assert np.array_equal(root.read(0, root.OUT0, 0, n_total), rx)
+    assert np.array_equal(root.read(0, root.OUT1, 0, n_total), ry)
+    assert root.digest(n_total) == g.digest(n_total)
+    g.set_gather(-1)
+    g.close()
+    root.close()
+
+
+def test_marks_and_write():
+    cfg, ocfg = both(*CFG4)
+    n_total = 1 << 20
+    g = ca.Group(cfg, devices=[0, 0])
+    g.reserve(n_total, 1)
+    rng = np.random.RandomState(5)
+    ph = rng.randint(0, 2**32, size=n_total, dtype=np.uint64).astype(np.uint32)
+    for s in range(2):
+        a, c = g.range(n_total, s)
+        g.write(s, g.IN0, 0, ph[a:a + c])
+    g.mark(0)
+    g.p2r_const(n_total, AMP, 0)
+    g.mark(1)
+    ms, per = g.elapsed(0, 1)
+    assert ms > 0 and len(per) == 2 and max(per) == pytest.approx(ms)
+    rx, _ = O.rotate(ocfg, AMP, 0, ph)
+    got = np.concatenate([g.read(s, g.OUT0, 0, g.range(n_total, s)[1])
+                          for s in range(2)])
+    assert np.array_equal(got, rx)
+    g.close()
+
+
+def test_bad_arguments():
+    cfg, _ = both(*CFG4)
+    with pytest.raises(ca.CordicError):
+        ca.Group(cfg, devices=[ca.device_count()])      # no such device
+    with pytest.raises(ca.CordicError):
+        ca.Group(cfg, devices=[0], first_shard=1, total_shards=1)
+    g = ca.Group(cfg, devices=[0])
+    with pytest.raises(ca.CordicError):
+        g.digest(1 << 10)                               # nothing computed yet
+    with pytest.raises(ca.CordicError):
+        g.set_gather(0, 0, 0, 8)                        # NULL destination
+    g.close()

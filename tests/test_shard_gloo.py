@@ -27,6 +27,18 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_c_abi_shard_range_matches():
+    """cordic_shard_range (C++, what cordic_group uses) == shard.py."""
+    import cordic_amd as ca
+    for n in (0, 1, 7, 8, 1000, (1 << 33) + 5):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert ca.shard_range(n, r, world) == shard_range(n, r, world)
+    import pytest
+    with pytest.raises(ca.CordicError):
+        ca.shard_range(10, 2, 2)
+
+
 def test_chunk_ranges_cover_without_overlap():
     for n in (0, 1, 5, 8, 4099, 1 << 30):
         for k in (1, 3, 8, 16):
@@ -49,6 +61,8 @@ WORKER = textwrap.dedent("""
     N = 100003
     cfg = O.config_cli(O.P2R, 32, 32, 2, 32, 24)     # BASELINE config 4 core
     start, cnt = shard_range(N, rank, world)
+    import cordic_amd as ca
+    assert ca.shard_range(N, rank, world) == (start, cnt)   # the C ABI's split
     g = np.arange(cnt, dtype=np.uint64) + np.uint64(start)
     ph = (g & np.uint64(0xffffffff)).astype(np.uint32)   # phase[n] = (uint32)n
     ox, oy = O.rotate(cfg, 2**31 - 1, 0, ph)

@@ -1,0 +1,148 @@
+// hbm_probe_lib.hip -> tools/libhbmprobe.so: the arithmetic-free twins of the
+// CORDIC kernels' memory traffic, callable from bench.py on the bench's own
+// buffers, so that every bench line can say "kernel = x % of a plain copy with
+// the same traffic, measured in the same run".  Measurement infrastructure,
+// not part of the product library.
+//
+//   mode 0  one-shot tiles: one 256-thread block per 256 vectors (4 KiB per
+//           array), XCD-contiguous placement -- the best streaming pattern
+//           found on MI355X (tools/hbm_probe2.hip, profiles/r02/hbm_probe2.txt)
+//   mode 1  persistent 1024-thread blocks pulling 1024-vector tiles from
+//           per-XCD counters in address order: the seeded kernel's own
+//           work distribution (cordic_device.h: rotator_seeded)
+//
+// R input arrays are read, W output arrays written, 16 bytes per lane.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int W>
+__global__ __launch_bounds__(256) void tiles(const u32x4 *__restrict__ a,
+		const u32x4 *__restrict__ b, u32x4 *__restrict__ c,
+		u32x4 *__restrict__ d, size_t nvec, int xcd)
+{
+	size_t t = blockIdx.x;
+	if (xcd)
+		t = (size_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	const size_t g = t * 256 + threadIdx.x;
+	if (g >= nvec)
+		return;
+	u32x4 v = u32x4{(uint32_t)g, 1, 2, 3};
+	if (R >= 1) v = a[g];
+	if (R >= 2) v += b[g];
+	if (W >= 1) c[g] = v;
+	if (W >= 2) d[g] = v + 1;
+}
+
+template <int R, int W>
+__global__ __launch_bounds__(1024) void queued(const u32x4 *__restrict__ a,
+		const u32x4 *__restrict__ b, u32x4 *__restrict__ c,
+		u32x4 *__restrict__ d, size_t nvec, unsigned *ctr)
+{
+	__shared__ unsigned slot[3];
+	const unsigned ntiles = (unsigned)((nvec + 1023) / 1024);
+	const unsigned per = (ntiles + 7) / 8;
+	unsigned home = 0, tried = 0;
+	auto grab = [&]() -> unsigned {
+		while (tried < 8) {
+			const unsigned j = (home + tried) & 7, lo = j * per;
+			const unsigned cnt = lo >= ntiles ? 0u : (ntiles - lo < per ? ntiles - lo : per);
+			if (cnt) {
+				const unsigned t = atomicAdd(&ctr[j * 64], 1u);
+				if (t < cnt) return lo + t;
+			}
+			tried++;
+		}
+		return 0xffffffffu;
+	};
+	if (threadIdx.x == 0) {
+		unsigned x;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+		home = x & 7;
+		slot[0] = grab();
+		slot[1] = grab();
+	}
+	__syncthreads();
+	unsigned cur = slot[0];
+	int ring = 0;
+	while (cur != 0xffffffffu) {
+		const unsigned nxt = slot[(ring + 1) % 3];
+		if (threadIdx.x == 0) slot[(ring + 2) % 3] = grab();
+		const size_t g = (size_t)cur * 1024 + threadIdx.x;
+		if (g < nvec) {
+			u32x4 v = u32x4{(uint32_t)g, 1, 2, 3};
+			if (R >= 1) v = a[g];
+			if (R >= 2) v += b[g];
+			if (W >= 1) c[g] = v;
+			if (W >= 2) d[g] = v + 1;
+		}
+		__syncthreads();
+		cur = nxt;
+		ring = (ring + 1) % 3;
+	}
+}
+
+template <int R, int W>
+static float run(const void *in0, const void *in1, void *out0, void *out1,
+		size_t nvec, int mode, int reps, hipStream_t st)
+{
+	hipEvent_t e0, e1;
+	unsigned *ctr = nullptr;
+	int cus = 256, dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess ||
+	    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+		return -1.f;
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+		return -1.f;
+	if (mode == 1 && hipMalloc((void **)&ctr, 2048) != hipSuccess)
+		return -1.f;
+	const size_t blocks = (nvec + 255) / 256;
+	auto launch = [&]() {
+		if (mode == 0) {
+			hipLaunchKernelGGL((tiles<R, W>), dim3((unsigned)blocks), dim3(256), 0, st,
+				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
+				nvec, (blocks % 8 == 0) ? 1 : 0);
+		} else {
+			(void)hipMemsetAsync(ctr, 0, 2048, st);
+			hipLaunchKernelGGL((queued<R, W>), dim3(2 * cus), dim3(1024), 0, st,
+				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
+				nvec, ctr);
+		}
+	};
+	launch();
+	float ms = -1.f;
+	if (hipEventRecord(e0, st) == hipSuccess) {
+		for (int r = 0; r < reps; r++)
+			launch();
+		if (hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess
+				&& hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+			ms /= (float)reps;
+		else
+			ms = -1.f;
+	}
+	if (hipGetLastError() != hipSuccess)
+		ms = -1.f;
+	if (ctr) (void)hipFree(ctr);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return ms;
+}
+
+// Average milliseconds per launch over `reps` launches (after one warm-up
+// launch) of the R-read / W-write pattern over nwords 32-bit words per array,
+// or a negative value on error.  Arrays that the pattern does not use may be
+// NULL.  The OUTPUT ARRAYS ARE OVERWRITTEN.
+extern "C" float hbm_probe(const void *in0, const void *in1, void *out0, void *out1,
+		size_t nwords, int R, int W, int mode, int reps, void *stream)
+{
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t nvec = nwords / 4;
+	if (reps < 1 || nvec == 0 || (mode != 0 && mode != 1))
+		return -1.f;
+	if (R == 1 && W == 2) return run<1, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
+	if (R == 2 && W == 2) return run<2, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
+	if (R == 0 && W == 2) return run<0, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
+	if (R == 1 && W == 1) return run<1, 1>(in0, in1, out0, out1, nvec, mode, reps, st);
+	return -1.f;
+}
