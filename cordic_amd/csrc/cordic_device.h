@@ -872,33 +872,57 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// eighth of the batch, and helps the others once its own is done.
 		const uint32_t ntiles = (uint32_t)((nvec + kSeedBlock - 1) / kSeedBlock);
 		const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
-		volatile uint32_t *slot = lds + (size_t)sa.nbuckets * 4 + (size_t)L * 16;
+		// three tile-id slots behind the seeds, addressed like them by byte
+		// offset (ds_read / ds_write: a generic `volatile` pointer would
+		// become flat loads with a vmcnt(0) wait each)
+		typedef volatile __attribute__((address_space(3))) uint32_t lds_word;
+		lds_word *slot = (lds_word *)(uintptr_t)(seed_base + 4u * qstride);
 		constexpr uint32_t kEnd = 0xffffffffu;
 		uint32_t home = 0, tried = 0;		// lane 0 of the block only
-		auto grab = [&]() -> uint32_t {
-			while (tried < (uint32_t)kQueueCounters) {
-				const uint32_t j = (home + tried) % kQueueCounters;
-				const uint32_t lo = j * per;
-				const uint32_t cnt = lo >= ntiles ? 0u
-					: (ntiles - lo < per ? ntiles - lo : per);
-				if (cnt != 0) {
-					const uint32_t t = atomicAdd(&sa.queue[j * kQueueStride], 1u);
-					if (t < cnt)
-						return lo + t;
-				}
-				tried++;
+		auto range_of = [&](uint32_t &lo, uint32_t &cnt) {
+			const uint32_t j = (home + tried) % kQueueCounters;
+			lo = j * per;
+			cnt = lo >= ntiles ? 0u : (ntiles - lo < per ? ntiles - lo : per);
+			return &sa.queue[j * kQueueStride];
+		};
+		// the ticket is drawn first and looked at later (resolve), so that
+		// the atomic's round trip is not waited for where it is issued
+		auto draw = [&]() -> uint32_t {
+			uint32_t lo, cnt;
+			uint32_t *c = range_of(lo, cnt);
+			return (tried < (uint32_t)kQueueCounters && cnt != 0)
+				? atomicAdd(c, 1u) : kEnd;
+		};
+		auto resolve = [&](uint32_t ticket) -> uint32_t {
+			for (;;) {
+				if (tried >= (uint32_t)kQueueCounters)
+					return kEnd;
+				uint32_t lo, cnt;
+				uint32_t *c = range_of(lo, cnt);
+				if (ticket < cnt)
+					return lo + ticket;
+				tried++;		// this XCD's share is done: help the next
+				if (tried >= (uint32_t)kQueueCounters)
+					return kEnd;
+				c = range_of(lo, cnt);
+				ticket = cnt != 0 ? atomicAdd(c, 1u) : kEnd;
 			}
-			return kEnd;
+		};
+		// Block-wide rendezvous on LDS contents only.  __syncthreads() also
+		// fences global memory: every wave would wait until HBM has
+		// acknowledged its stores (s_waitcnt vmcnt(0)) once per pass.
+		auto lds_barrier = [] {
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 		};
 		// tile ids run two passes ahead of the compute (a three-slot ring in
 		// LDS), so that the phases of the next tile can be prefetched while
 		// this one is being rotated
 		if (threadIdx.x == 0) {
 			home = xcc_id() % kQueueCounters;
-			slot[0] = grab();
-			slot[1] = grab();
+			slot[0] = resolve(draw());
+			slot[1] = resolve(draw());
 		}
-		__syncthreads();
+		lds_barrier();
 		uint32_t cur = slot[0];
 		int ring = 0;
 		typename IO::uvec nph{};
@@ -909,18 +933,24 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 		while (cur != kEnd) {
 			const uint32_t nxt = slot[(ring + 1) % 3];
-			if (threadIdx.x == 0)
-				slot[(ring + 2) % 3] = grab();
 			const u32x4 tph = IO::widen(nph);
 			if constexpr (FEED != Feed::Nco_ConstXY) {
 				const size_t gn = (size_t)nxt * kSeedBlock + threadIdx.x;
 				if (nxt != kEnd && gn < nvec)
 					nph = CORDIC_LOAD_IN(&phin[gn]);
 			}
+			// the ticket for the tile after next: drawn now (behind the
+			// prefetch, so that nothing waits for it here), looked at after
+			// this pass's stores -- its round trip hides behind the rotation
+			uint32_t ahead = 0;
+			if (threadIdx.x == 0)
+				ahead = draw();
 			const size_t g = (size_t)cur * kSeedBlock + threadIdx.x;
 			if (g < nvec)		// only the batch's last tile is partial
 				pass(g, tph);
-			__syncthreads();
+			if (threadIdx.x == 0)
+				slot[(ring + 2) % 3] = resolve(ahead);
+			lds_barrier();
 			cur = nxt;
 			ring = (ring + 1) % 3;
 		}
