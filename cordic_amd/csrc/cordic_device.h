@@ -779,8 +779,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
 		__builtin_trap();
 
-	// One tile pass: 4 samples per lane of vector g, phases in tph.
-	auto pass = [&](size_t g, const u32x4 tph) {
+	// One tile pass: 4 samples per lane of vector g, phases in tph; results in
+	// rx / ry (the caller stores them).
+	auto pass = [&](size_t g, const u32x4 tph, i32x4 &rx, i32x4 &ry) {
 		uint32_t P[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
 			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
@@ -827,7 +828,6 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			}
 		}
 
-		i32x4 rx, ry;
 		if constexpr (C::lj == 0) {
 			RotChain<C, NLIVE, 0, M, DYN>::run(x, y, p, kp);
 #pragma unroll
@@ -855,8 +855,6 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 		apply_unit_gain<UG>(rx, kp);
 		apply_unit_gain<UG>(ry, kp);
-		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
-		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	};
 
 	if (sa.queue != nullptr) {
@@ -931,6 +929,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			if (cur != kEnd && g0 < nvec)
 				nph = CORDIC_LOAD_IN(&phin[g0]);
 		}
+		// (Storing the results one pass late, so that the compiler's
+		// vmcnt(0) wait for the prefetch never meets a young store, measured
+		// no gain: same-box A/B in profiles/r02/ab_delayed_stores.txt.)
 		while (cur != kEnd) {
 			const uint32_t nxt = slot[(ring + 1) % 3];
 			const u32x4 tph = IO::widen(nph);
@@ -946,8 +947,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			if (threadIdx.x == 0)
 				ahead = draw();
 			const size_t g = (size_t)cur * kSeedBlock + threadIdx.x;
-			if (g < nvec)		// only the batch's last tile is partial
-				pass(g, tph);
+			if (g < nvec) {		// only the batch's last tile is partial
+				i32x4 rx, ry;
+				pass(g, tph, rx, ry);
+				CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
+				CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
+			}
 			if (threadIdx.x == 0)
 				slot[(ring + 2) % 3] = resolve(ahead);
 			lds_barrier();
@@ -983,7 +988,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			if (gn < hi)
 				nph = CORDIC_LOAD_IN(&phin[gn]);
 		}
-		pass(g, tph);
+		i32x4 rx, ry;
+		pass(g, tph, rx, ry);
+		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
+		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	}
 }
 
