@@ -34,6 +34,8 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		return CORDIC_ERR_ARGS;
 	if (cfg->mode < CORDIC_P2R || cfg->mode > CORDIC_SR2P)
 		return CORDIC_ERR_MODE;
+	if (!config_sane(*cfg))
+		return CORDIC_ERR_ARGS;
 	cordic_plan *p = new (std::nothrow) cordic_plan;
 	if (!p)
 		return CORDIC_ERR_NOMEM;
@@ -300,7 +302,7 @@ int cordic_table_values(const cordic_table_config *cfg, int32_t *out, size_t cap
 
 int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 {
-	if (!cfg || !tbl || cfg->entries <= 0)
+	if (!cfg || !tbl || !table_sane(*cfg))
 		return CORDIC_ERR_ARGS;
 	std::vector<int32_t> host((size_t)cfg->entries);
 	int rc = table_fill(*cfg, host.data(), host.size());
@@ -390,7 +392,7 @@ int cordic_quad_write_header(const cordic_quad_config *cfg, const char *name,
 
 int cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core)
 {
-	if (!cfg || !core || cfg->entries <= 0)
+	if (!cfg || !core || !quad_sane(*cfg))
 		return CORDIC_ERR_ARGS;
 	const size_t n = (size_t)cfg->entries;
 	std::vector<int32_t> c(n), l(n), q(n), packed(n * 4);
@@ -459,6 +461,8 @@ int cordic_stream_create(const cordic_config *cfg, cordic_stream **out)
 		return CORDIC_ERR_ARGS;
 	if (cfg->mode != CORDIC_P2R && cfg->mode != CORDIC_R2P)
 		return CORDIC_ERR_MODE;
+	if (!config_sane(*cfg))
+		return CORDIC_ERR_ARGS;
 	cordic_stream *s = new (std::nothrow) cordic_stream;
 	if (!s)
 		return CORDIC_ERR_NOMEM;
@@ -567,6 +571,8 @@ int cordic_seq_create(const cordic_config *cfg, cordic_seq **out)
 		return CORDIC_ERR_ARGS;
 	if (cfg->mode != CORDIC_SP2R && cfg->mode != CORDIC_SR2P)
 		return CORDIC_ERR_MODE;
+	if (!config_sane(*cfg))
+		return CORDIC_ERR_ARGS;
 	cordic_seq *s = new (std::nothrow) cordic_seq;
 	if (!s)
 		return CORDIC_ERR_NOMEM;

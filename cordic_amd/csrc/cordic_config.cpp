@@ -313,17 +313,27 @@ int parse_args(cordic_config *cfg, int argc, const char *const *argv,
 	if (!cfg || argc < 1 || !argv)
 		return CORDIC_ERR_ARGS;
 	int nstages = -1, iw = -1, ow = -1, xtra = 2, pw = -1;
-	int mode = CORDIC_R2P;		// sw/main.cpp:100: r2p unless -t says so
+	// sw/main.cpp:99-103: the generator's own flag set.  Every -t clears the
+	// first four and sets one; `sequential` and gen_quadtbl are only ever
+	// set, never cleared ("-t sr2p -t p2r" generates the SEQUENTIAL rotator).
+	bool polar_to_rect = false, rect_to_polar = true, gen_sintable = false,
+	     gen_quarterwav = false, gen_quadtbl = false, sequential = false;
 	bool reset = true, aux = false, areset = false, hdr = false;
+	// fname: -f always sets it, a -t only while it is still unset
+	// (sw/main.cpp:151-153,183-211), so the FIRST -t names the default file
+	bool have_file = false;
 	std::string file;
-	const char *deffile = "topolar.v";
 
-	// A small getopt: flags may be bundled ("-vca"), values may be glued
-	// ("-i13") or separate ("-i 13"), as with getopt(3).
+	// getopt(3) as glibc runs it for "aAcf:hi:n:o:p:Rrt:vx:": flags may be
+	// bundled ("-vca"), values glued ("-i13") or separate ("-i 13", the next
+	// word whatever it looks like); words that are not options are skipped
+	// (glibc permutes them to the end) and "--" ends the options.
 	for (int k = 1; k < argc; k++) {
 		const char *a = argv[k];
-		if (!a || a[0] != '-' || a[1] == '\0')
-			break;			// first non-option ends parsing
+		if (!a)
+			return CORDIC_ERR_ARGS;
+		if (a[0] != '-' || a[1] == '\0')
+			continue;		// not an option: skipped, not a stop
 		if (a[1] == '-' && a[2] == '\0')
 			break;
 		for (const char *p = a + 1; *p; p++) {
@@ -334,24 +344,40 @@ int parse_args(cordic_config *cfg, int argc, const char *const *argv,
 				if (!val)
 					return CORDIC_ERR_ARGS;
 				switch (f) {
-				case 'f': file = val; break;
+				case 'f': file = val; have_file = true; break;
 				case 'i': iw = std::atoi(val); break;
 				case 'n': nstages = std::atoi(val); break;
 				case 'o': ow = std::atoi(val); break;
 				case 'p': pw = std::atoi(val); break;
 				case 'x': xtra = std::atoi(val); break;
-				case 't':
+				case 't': {
+					const char *def = nullptr;
+					rect_to_polar = polar_to_rect = false;
+					gen_sintable = gen_quarterwav = false;
 					if (!std::strcmp(val, "r2p")) {
-						mode = CORDIC_R2P; deffile = "topolar.v";
+						def = "topolar.v"; rect_to_polar = true;
 					} else if (!std::strcmp(val, "sr2p")) {
-						mode = CORDIC_SR2P; deffile = "seqpolar.v";
+						def = "seqpolar.v"; rect_to_polar = true;
+						sequential = true;
 					} else if (!std::strcmp(val, "p2r")) {
-						mode = CORDIC_P2R; deffile = "basiccordic.v";
+						def = "basiccordic.v"; polar_to_rect = true;
 					} else if (!std::strcmp(val, "sp2r")) {
-						mode = CORDIC_SP2R; deffile = "seqcordic.v";
+						def = "seqcordic.v"; polar_to_rect = true;
+						sequential = true;
+					} else if (!std::strcmp(val, "tbl")) {
+						def = "sintable.v"; gen_sintable = true;
+					} else if (!std::strcmp(val, "qtr")) {
+						def = "quarterwav.v"; gen_quarterwav = true;
+					} else if (!std::strcmp(val, "qtbl")) {
+						def = "quadtbl.v"; gen_quadtbl = true;
 					} else
 						return CORDIC_ERR_MODE;
+					if (!have_file) {
+						file = def;
+						have_file = true;
+					}
 					break;
+				}
 				}
 				break;		// value consumed the rest of a
 			}
@@ -361,11 +387,25 @@ int parse_args(cordic_config *cfg, int argc, const char *const *argv,
 			case 'c': hdr = true; break;
 			case 'R': reset = false; break;
 			case 'r': reset = true; break;
-			case 'v': case 'h': break;
+			case 'v': break;
+			// usage() and exit: the generator writes no core
+			case 'h': return CORDIC_ERR_ARGS;
 			default: return CORDIC_ERR_ARGS;
 			}
 		}
 	}
+	// sw/main.cpp:260,312: which CORDIC core this command line generates
+	// (table generators are cordic_table_* / cordic_quad_* territory)
+	int mode;
+	if (polar_to_rect)
+		mode = sequential ? CORDIC_SP2R : CORDIC_P2R;
+	else if (rect_to_polar)
+		mode = sequential ? CORDIC_SR2P : CORDIC_R2P;
+	else
+		return CORDIC_ERR_MODE;
+	(void)gen_sintable; (void)gen_quarterwav; (void)gen_quadtbl;
+	const char *deffile = "topolar.v";	// no -t, no -f: stdout in the
+						// generator; the r2p default here
 	int rc = build_from_cli(cfg, mode, iw, ow, xtra, pw, nstages);
 	if (rc != CORDIC_OK)
 		return rc;
@@ -374,7 +414,7 @@ int parse_args(cordic_config *cfg, int argc, const char *const *argv,
 	cfg->async_reset = areset;
 	if (c_header) *c_header = hdr;
 	if (fname && fname_cap) {
-		const std::string &f = file.empty() ? std::string(deffile) : file;
+		const std::string &f = have_file ? file : std::string(deffile);
 		std::snprintf(fname, fname_cap, "%s", f.c_str());
 	}
 	return CORDIC_OK;
@@ -456,6 +496,45 @@ int write_header(const cordic_config *c, const char *name, char *buf, size_t cap
 // ---------------------------------------------------------------------------
 // Table cores (sw/sintable.cpp), row F4
 // ---------------------------------------------------------------------------
+bool config_sane(const cordic_config &c)
+{
+	if (c.mode < CORDIC_P2R || c.mode > CORDIC_SR2P)
+		return false;
+	const bool rot = (c.mode == CORDIC_P2R || c.mode == CORDIC_SP2R);
+	const int in_shl = rot ? (c.ww - c.iw - 1) : (c.ww - c.iw - 2);
+	return c.iw >= 1 && c.iw <= 32 && c.ow >= 1 && c.ow <= 32
+		&& c.ww >= c.ow && c.ww <= 64 && in_shl >= 0
+		&& c.pw >= 3 && c.pw <= 32
+		&& c.nstages >= 1 && c.nstages <= CORDIC_AMD_MAX_STAGES
+		&& c.nlive >= 0 && c.nlive <= c.nstages;
+}
+
+// sw/sintable.cpp:186-194 / sw/hexfile.cpp:52-59 bounds, and the table length
+// the kernels index with (table_lookup: ph & (2^pw - 1), 2^(pw-2) per quadrant)
+bool table_sane(const cordic_table_config &t)
+{
+	if (t.kind != CORDIC_TBL && t.kind != CORDIC_QTR)
+		return false;
+	if (t.pw < 3 || t.pw > 25 || t.ow < 2 || t.ow > 30)
+		return false;
+	return t.entries == ((t.kind == CORDIC_TBL) ? (1 << t.pw)
+						   : (1 << (t.pw - 2)));
+}
+
+// rtl/quadtbl.v:149-153,214-216,244-277 widths as quad_build_core derives them;
+// the kernel copies 2^lgtbl entries into 16 * entries bytes of LDS and shifts
+// by these widths
+bool quad_sane(const cordic_quad_config &q)
+{
+	return q.lgtbl >= 4 && q.lgtbl <= 12 && q.entries == (1 << q.lgtbl)
+		&& q.pw >= q.lgtbl + 1 && q.pw <= 32
+		&& q.dxbits == q.pw - q.lgtbl + 1 && q.dxbits >= 2
+		&& q.ow >= 2 && q.xtra >= 2 && q.ww == q.ow + q.xtra && q.ww <= 32
+		&& q.tbl_width > 6 && q.tbl_width <= 30
+		&& q.qbits >= 1 && q.lbits > q.qbits && q.cbits > q.lbits
+		&& q.cbits >= q.ww && q.cbits <= 31;
+}
+
 int table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw)
 {
 	if (!t)
@@ -493,7 +572,7 @@ int table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw)
 
 int table_fill(const cordic_table_config &t, int32_t *out, size_t cap)
 {
-	if (!out || cap < (size_t)t.entries)
+	if (!out || !table_sane(t) || cap < (size_t)t.entries)
 		return CORDIC_ERR_ARGS;
 	const int n = 1 << t.pw;
 	const long maxv = (1l << (t.ow - 1)) - 1l;

@@ -73,6 +73,37 @@ bool CORDIC_INST_NAME(Feed feed, int nlive, int grid, hipStream_t st,
 }
 #elif CORDIC_INST_KIND == 3
 namespace {
+// rotator_seeded addresses LDS by byte offset from 0, which holds as long as
+// the kernel has no static LDS in front of its dynamic array.  A build that
+// adds some (instrumentation, a debug option) is detected here, once per
+// kernel, and the job then runs on the full-recurrence kernel instead of
+// trapping on the device.  Also raises the dynamic-LDS limit.
+inline bool seeded_kernel_usable(const void *kern, size_t lds_bytes)
+{
+	// verified kernels of this thread (the attribute is sticky per function
+	// and always raised to the whole 160 KiB, so one check per kernel does)
+	constexpr int kCache = 16;
+	thread_local const void *ok[kCache] = {};
+	for (int i = 0; i < kCache; i++)
+		if (ok[i] == kern)
+			return lds_bytes <= 160 * 1024;
+	hipFuncAttributes attr;
+	if (hipFuncGetAttributes(&attr, kern) != hipSuccess
+			|| attr.sharedSizeBytes != 0
+			|| hipFuncSetAttribute(kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+				!= hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	for (int i = 0; i < kCache; i++)
+		if (!ok[i]) {
+			ok[i] = kern;
+			break;
+		}
+	return lds_bytes <= 160 * 1024;
+}
+
 template <Feed FEED>
 bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 		const dev::SeedArgs &sa, const RotatorJob &j, size_t lds_bytes)
@@ -83,10 +114,8 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			return false;
 		auto kern = rotator_seeded<CORDIC_INST_CONTAINER, kDynStages,
 				kSeedStages, FEED, true, Io32, true>;
-		if (lds_bytes > 64 * 1024)
-			(void)hipFuncSetAttribute((const void *)kern,
-				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)lds_bytes);
+		if (!seeded_kernel_usable((const void *)kern, lds_bytes))
+			return false;
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st,
 			kp, sa, (const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
 			j.n / kVec);
@@ -95,9 +124,8 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	switch (nlive) {
 #define X(N) case N: { \
 	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
-	if (lds_bytes > 64 * 1024) \
-		(void)hipFuncSetAttribute((const void *)kern, \
-			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+	if (!seeded_kernel_usable((const void *)kern, lds_bytes)) \
+		return false; \
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp, sa, \
 		(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec); \
 	return true; }
@@ -108,10 +136,8 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			return false;
 		auto kern = rotator_seeded<CORDIC_INST_CONTAINER, kDynStages,
 				kSeedStages, FEED, true>;
-		if (lds_bytes > 64 * 1024)
-			(void)hipFuncSetAttribute((const void *)kern,
-				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)lds_bytes);
+		if (!seeded_kernel_usable((const void *)kern, lds_bytes))
+			return false;
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st,
 			kp, sa, (const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
 			j.n / kVec);

@@ -49,9 +49,16 @@ bool seed16(int nlive, int grid, hipStream_t st, const CoreParams &kp,
 		kern = rotator_seeded<Narrow32, 13, kSeedStages, FEED, false, Io16>;
 	if (kp.post_mul == 0 && nlive == 16)
 		kern = rotator_seeded<Narrow32, 16, kSeedStages, FEED, false, Io16>;
-	if (lds_bytes > 64 * 1024)
-		(void)hipFuncSetAttribute((const void *)kern,
-			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	hipFuncAttributes attr;	// see cordic_inst_body.h: seeded_kernel_usable
+	if (hipFuncGetAttributes(&attr, (const void *)kern) != hipSuccess
+			|| attr.sharedSizeBytes != 0
+			|| (lds_bytes > 64 * 1024 && hipFuncSetAttribute(
+				(const void *)kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)lds_bytes) != hipSuccess)) {
+		(void)hipGetLastError();
+		return false;
+	}
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp,
 		sa, (const u16x4 *)j.phase, (i16x4 *)j.ox, (i16x4 *)j.oy,
 		j.n / kVec);

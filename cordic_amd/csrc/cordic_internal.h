@@ -29,6 +29,11 @@ int	parse_args(cordic_config *cfg, int argc, const char *const *argv,
 int	write_header(const cordic_config *c, const char *name, char *buf,
 		size_t cap);
 const char *status_text(int s);
+// Caller-owned PODs are checked before anything indexes with their fields:
+// could this struct have come out of the matching *_init call?
+bool	config_sane(const cordic_config &c);
+bool	table_sane(const cordic_table_config &t);
+bool	quad_sane(const cordic_quad_config &q);
 int	table_derive(cordic_table_config *t, int kind, int iw, int ow, int pw);
 int	table_fill(const cordic_table_config &t, int32_t *out, size_t cap);
 

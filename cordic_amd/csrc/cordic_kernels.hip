@@ -4,6 +4,7 @@
 // in cordic_device.h.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <type_traits>
 
@@ -395,17 +396,35 @@ void launch_pol_generic(int grid, hipStream_t st, const CoreParams &kp,
 			0, st, kp, x, y, mag, ph, n);
 }
 
+// CUs of the CURRENT device (plans and groups launch on whatever device the
+// caller made current): one relaxed atomic per device ordinal, filled on first
+// use -- no shared mutable state beyond that, as the ABI promises.
+int cus_of_current_device()
+{
+	constexpr int kMaxDevices = 64;
+	static std::atomic<int> cache[kMaxDevices];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return -1;
+	if (dev >= 0 && dev < kMaxDevices) {
+		const int c = cache[dev].load(std::memory_order_relaxed);
+		if (c > 0)
+			return c;
+	}
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)
+			!= hipSuccess || cus <= 0)
+		return -1;
+	if (dev >= 0 && dev < kMaxDevices)
+		cache[dev].store(cus, std::memory_order_relaxed);
+	return cus;
+}
+
 int grid_for(size_t work_items_per_block, size_t n, int blocks_per_cu = 8)
 {
-	static int cus = 0;
-	if (cus == 0) {
-		int dev = 0;
-		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) != hipSuccess ||
-		    hipGetDeviceProperties(&prop, dev) != hipSuccess)
-			return -1;
-		cus = prop.multiProcessorCount;
-	}
+	const int cus = cus_of_current_device();
+	if (cus < 0)
+		return -1;
 	const size_t blocks = (n + work_items_per_block - 1) / work_items_per_block;
 	const size_t cap = (size_t)cus * blocks_per_cu;	// resident blocks; the rest is grid-stride
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
@@ -575,19 +594,6 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 
 // ----------------------------------------------------------------- launchers
 
-// A cordic_config is a caller-owned POD: refuse one whose fields cannot have
-// come out of cordic_config_init* before any kernel indexes with them.
-static bool config_sane(const cordic_config &c)
-{
-	const bool rot = (c.mode == CORDIC_P2R || c.mode == CORDIC_SP2R);
-	const int in_shl = rot ? (c.ww - c.iw - 1) : (c.ww - c.iw - 2);
-	return c.iw >= 1 && c.iw <= 32 && c.ow >= 1 && c.ow <= 32
-		&& c.ww >= c.ow && c.ww <= 64 && in_shl >= 0
-		&& c.pw >= 3 && c.pw <= 32
-		&& c.nstages >= 1 && c.nstages <= CORDIC_AMD_MAX_STAGES
-		&& c.nlive >= 0 && c.nlive <= c.nstages;
-}
-
 int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		void *stream)
 {
@@ -703,7 +709,7 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
-	if (!d_tbl || !phase || !val) return CORDIC_ERR_ARGS;
+	if (!d_tbl || !phase || !val || !table_sane(t)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	if (d_lds16 && lds_mode) {
 		const size_t bytes = ((size_t)lds_entries * 2 + 15) & ~(size_t)15;
@@ -715,12 +721,17 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		auto k1 = table_lookup_lds<1>;
 		auto k2 = table_lookup_lds<2>;
 		auto kern = (lds_mode == 1) ? k1 : k2;
+		bool lds_ok = true;
 		if (bytes > 64 * 1024)
-			(void)hipFuncSetAttribute((const void *)kern,
-				hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), bytes, st, d_lds16,
-				lds_entries, phase, val, n, t.pw, t.ow);
-		return check_launch();
+			lds_ok = hipFuncSetAttribute((const void *)kern,
+				hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+				== hipSuccess;
+		if (lds_ok) {
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), bytes, st,
+					d_lds16, lds_entries, phase, val, n, t.pw, t.ow);
+			return check_launch();
+		}
+		clear_stale_error();	// the L2 gather kernel below serves the table
 	}
 	const int grid = grid_for((size_t)1024 * kVec, n, 2);
 	if (grid < 0) return CORDIC_ERR_DEVICE;
@@ -739,7 +750,7 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
-	if (!d_tables || !phase || !val) return CORDIC_ERR_ARGS;
+	if (!d_tables || !phase || !val || !quad_sane(q)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	const int grid = grid_for((size_t)1024 * kVec, n, 2);
 	if (grid < 0) return CORDIC_ERR_DEVICE;

@@ -254,9 +254,7 @@ int quad_build_from_cli(cordic_quad_config *q, int iw, int ow, int xtra,
 int quad_fill(const cordic_quad_config &q, int32_t *c, int32_t *l, int32_t *qq,
 		size_t cap)
 {
-	if (!c || !l || !qq || cap < (size_t)q.entries)
-		return CORDIC_ERR_ARGS;
-	if (q.lgtbl < 4 || q.lgtbl > 20 || q.tbl_width <= 6 || q.tbl_width > 30)
+	if (!c || !l || !qq || !quad_sane(q) || cap < (size_t)q.entries)
 		return CORDIC_ERR_ARGS;
 	const QuadFit f = fit_tables(q.lgtbl, q.tbl_width);
 	if (!f.representable || f.cbits != q.cbits || f.lbits != q.lbits

@@ -106,6 +106,38 @@ def test_from_args_flags_and_defaults():
         assert ei.value.status == status
 
 
+def test_getopt_semantics_match_the_generator():
+    """Repeated -t (sticky `sequential`, the FIRST -t names the default
+    file), words that are not options, "--", -h: cordic_config_from_args
+    against what the real gencordic did with the same command lines
+    (tests/golden/getopt_golden.json, made by make_getopt_golden.py)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden",
+                           "getopt_golden.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 15
+    for e in cases:
+        core = e.get("core")
+        if core is None:            # the generator wrote no core (-h, errors)
+            with pytest.raises(ca.CordicError):
+                ca.Config.from_args(e["args"])
+            continue
+        c = ca.Config.from_args(e["args"])
+        want_mode = {("p2r", False): ca.P2R, ("p2r", True): ca.SP2R,
+                     ("r2p", False): ca.R2P, ("r2p", True): ca.SR2P}[
+                         (core["kind"], core["sequential"])]
+        assert c.mode == want_mode, e["args"]
+        vfile = [f for f in e["files"] if f.endswith(".v")][0]
+        assert c.fname == vfile, e["args"]
+        assert (c.iw, c.ow, c.ww, c.pw, c.nstages) == (
+            core["IW"], core["OW"], core["WW"], core["PW"],
+            core["NSTAGES"]), e["args"]
+        assert bool(c.has_reset) == core["has_reset"], e["args"]
+        assert bool(c.async_reset) == core["async_reset"], e["args"]
+        assert bool(c.has_aux) == core["has_aux"], e["args"]
+        assert c.c_header == any(f.endswith(".h") for f in e["files"]), e["args"]
+
+
 def test_core_level_constructor_equals_cli_level():
     """sw/main.cpp hands the emitters nxtra = xtra+1 (p2r) / xtra+2 (r2p)."""
     a = ca.Config.from_cli(ca.P2R, 13, 13, 2)
