@@ -437,6 +437,28 @@ int cordic_quad_lookup(const cordic_quad *core, size_t n, const uint32_t *d_phas
 	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream);
 }
 
+// Scratch of the clocked views.  cordic_*_reserve sizes it up front; a *_ticks
+// call that needs more grows it IN STREAM ORDER on the caller's stream
+// (hipFreeAsync / hipMallocAsync): earlier kernels of that stream still see the
+// old block, no other stream is stalled and nothing synchronises the device.
+// (Not inside a stream capture: reserve first, then capture.)
+static int grow_workspace(void **ws, size_t *ws_bytes, size_t need, void *stream)
+{
+	if (need <= *ws_bytes)
+		return CORDIC_OK;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (*ws && hipFreeAsync(*ws, st) != hipSuccess)
+		return CORDIC_ERR_DEVICE;
+	*ws = nullptr;
+	*ws_bytes = 0;
+	if (hipMallocAsync(ws, need, st) != hipSuccess) {
+		*ws = nullptr;
+		return CORDIC_ERR_DEVICE;
+	}
+	*ws_bytes = need;
+	return CORDIC_OK;
+}
+
 // ------------------------------------------------- clocked view (stream)
 struct cordic_stream {
 	cordic_config cfg;
@@ -541,7 +563,8 @@ int cordic_stream_ticks(cordic_stream *s, size_t ticks, const uint8_t *d_ce,
 {
 	if (!s)
 		return CORDIC_ERR_ARGS;
-	if (int rc = cordic_stream_reserve(s, ticks))
+	if (int rc = grow_workspace(&s->st.ws, &s->st.ws_bytes,
+			stream_workspace_bytes(ticks), stream))
 		return rc;
 	return launch_stream_ticks(s->cfg, s->st, ticks, d_ce, d_reset, d_aux,
 			d_xval, d_yval, d_phase, d_out0, d_out1, d_oaux, stream);
@@ -622,7 +645,8 @@ int cordic_seq_ticks(cordic_seq *s, size_t ticks, const uint8_t *d_stb,
 {
 	if (!s)
 		return CORDIC_ERR_ARGS;
-	if (int rc = cordic_seq_reserve(s, ticks))
+	if (int rc = grow_workspace(&s->st.ws, &s->st.ws_bytes,
+			seq_workspace_bytes(ticks), stream))
 		return rc;
 	return launch_seq_ticks(s->cfg, s->st, ticks, d_stb, d_reset, d_aux, d_xval,
 			d_yval, d_phase, d_out0, d_out1, d_busy, d_done, d_oaux,

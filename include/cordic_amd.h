@@ -400,8 +400,10 @@ int	cordic_quad_lookup(const cordic_quad *core, size_t n,
  *   d_oaux : o_aux per clock (may be NULL)
  * A freshly created stream is in the reset state.  The call needs
  * cordic_stream_workspace(T) bytes of device scratch; cordic_stream_reserve
- * allocates it up front, otherwise the first call that needs more allocates
- * (and thereby synchronises).  Once reserved a call only enqueues kernels, and
+ * allocates it up front (synchronising the device), otherwise a call that
+ * needs more grows it in stream order on its own stream (hipMallocAsync: no
+ * device-wide stall, but not legal inside a stream capture -- reserve first,
+ * then capture).  Once reserved a call only enqueues kernels, and
  * the pipeline state sits in one set of device buffers that the kernels update
  * in place, so a HIP graph captured around it can be replayed block after
  * block (the same holds for cordic_seq_ticks).
