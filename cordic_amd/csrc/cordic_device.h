@@ -1073,6 +1073,167 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 	}
 }
 
+// ------------------------------------- converter, left-justified fast form
+//
+// topolar_unrolled spends 8 VALU instructions per micro-rotation, three of
+// them the half-rate v_mad_i64_i32 (x, y, phase).  For cores whose registers
+// cannot overflow and fit 32 bits (WW <= 32, cfg.needs_wrap == 0) this form
+// needs 7, only two of them half-rate (profiles/isa/topolar_lj.txt):
+//
+//  * x, y are carried LEFT-justified by 30 bits in their register pairs
+//    (x~ = x << 30) from stage 2 on.  (y >>> k) then is an arithmetic shift of
+//    the HIGH word by k-2 and the multipliers are +/-2^30, read straight off
+//    the sign bit of that word:  t~ = (yh & 2^31) | 2^30,  -t~ = (yh & 2^31) ^
+//    (2^31 | 2^30): two full-rate v_bitop3_b32 (2^30 and 2^31|2^30 are the
+//    inline constants 2.0 and -2.0) instead of shift + or + xor.
+//  * the phase is not accumulated per stage.  After the quadrant fold the
+//    vector lies within +/-45 degrees and every stage at least halves the bound
+//    on |y| / x  (|angle| <= atan 2^-(k-1) before stage k), so before stage k
+//    |y| < 2^(32-k) + k: in the high word yh = y >> 2 every bit from 32-k
+//    upwards is a copy of the sign (k <= 24 leaves two spare bits however the
+//    truncations fall).  One more full-rate v_bitop3_b32 per stage,
+//    D |= yh & 2^(32-k), collects the direction bits in D, and
+//        o_phase = p0 + sum_k (D_k ? -a_k : +a_k)
+//    comes out of three 1024-entry tables in LDS indexed by ten direction bits
+//    each (built per block from the core's arctan table): 3 ds_read_b32 and a
+//    few adds per sample replace NLIVE multiply-adds.
+//
+// rtl/topolar.v:122-152 (fold), :217-243 (stages), :251-271 (outputs): same
+// values as topolar_unrolled, bit for bit.
+constexpr int kPolLjMaxStages = 24;	// bound of the sign-copy argument above
+constexpr int kPolLjGroup = 10;		// direction bits per phase table
+
+__device__ __forceinline__ uint32_t op_sign_or(uint32_t a, uint32_t smask)
+{	// (a & 2^31) | 2^30
+	uint32_t d;
+	asm("v_bitop3_b32 %0, %1, 2.0, %2 bitop3:0xec" : "=v"(d) : "v"(a), "s"(smask));
+	return d;
+}
+__device__ __forceinline__ uint32_t op_sign_xor(uint32_t a, uint32_t smask)
+{	// (a & 2^31) ^ (2^31 | 2^30)
+	uint32_t d;
+	asm("v_bitop3_b32 %0, %1, -2.0, %2 bitop3:0x6c" : "=v"(d) : "v"(a), "s"(smask));
+	return d;
+}
+__device__ __forceinline__ uint32_t op_collect(uint32_t a, uint32_t acc, uint32_t bit)
+{	// acc | (a & bit), bit wave-uniform
+	uint32_t d;
+	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xec" : "=v"(d) : "v"(a), "v"(acc), "s"(bit));
+	return d;
+}
+
+template <int K>
+__device__ __forceinline__ void pol_stage_lj(int64_t &x, int64_t &y, uint32_t &dirs,
+		uint32_t smask)
+{
+	static_assert(K >= 2 && K <= kPolLjMaxStages, "stage outside the fast form");
+	const uint32_t yh = (uint32_t)((uint64_t)y >> 32);
+	const int32_t t = (int32_t)op_sign_or(yh, smask);	// +/- 2^30
+	const int32_t nt = (int32_t)op_sign_xor(yh, smask);	// -t
+	const int32_t sy = (int32_t)yh >> (K - 2);
+	const int32_t sx = (int32_t)((uint64_t)x >> 32) >> (K - 2);
+	dirs = op_collect(yh, dirs, 1u << (32 - K));
+	op_mad(x, sy, t);		// x' = x + t * (y >>> k)
+	op_mad(y, sx, nt);		// y' = y - t * (x >>> k)
+}
+
+template <int NLIVE, int I, bool DYN> struct PolChainLJ {
+	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
+			int64_t (&y)[kVec], uint32_t (&dirs)[kVec], uint32_t smask,
+			const CoreParams &kp)
+	{
+		if constexpr (I < NLIVE) {
+			if (!DYN || I < kp.nlive) {
+#pragma unroll
+				for (int v = 0; v < kVec; v++)
+					pol_stage_lj<I + 1>(x[v], y[v], dirs[v], smask);
+				PolChainLJ<NLIVE, I + 1, DYN>::run(x, y, dirs, smask, kp);
+			}
+		}
+	}
+};
+
+template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false>
+__global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
+		const typename IO::ivec *__restrict__ xin,
+		const typename IO::ivec *__restrict__ yin,
+		typename IO::ivec *__restrict__ omag,
+		typename IO::uvec *__restrict__ oph, size_t nvec)
+{
+	static_assert(NLIVE >= 2 && NLIVE <= kPolLjMaxStages, "see kPolLjMaxStages");
+	constexpr int kGroups = (NLIVE + kPolLjGroup - 1) / kPolLjGroup;
+	// phase tables: entry idx of group g = sum over the group's stages of
+	// -a (direction bit set: y was negative, rtl/topolar.v:226-234) or +a
+	__shared__ uint32_t ptab[kGroups][1 << kPolLjGroup];
+	for (int e = threadIdx.x; e < kGroups << kPolLjGroup; e += kBlock) {
+		const int g = e >> kPolLjGroup, idx = e & ((1 << kPolLjGroup) - 1);
+		uint32_t acc = 0;
+		for (int j = 0; j < kPolLjGroup; j++) {
+			const int stage = g * kPolLjGroup + j;	// 0-based
+			if (stage < kp.nlive) {
+				const uint32_t a = kp.angle[stage];
+				acc += ((idx >> (kPolLjGroup - 1 - j)) & 1) ? 0u - a : a;
+			}
+		}
+		ptab[g][idx] = acc;
+	}
+	__syncthreads();
+	const uint32_t smask = 0x80000000u;
+
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	typename IO::ivec nx{}, ny{};		// software prefetch
+	if (g < nvec) {
+		nx = xin[g];
+		ny = yin[g];
+	}
+	for (; g < nvec; g += stride) {
+		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
+		const size_t gn = g + stride;
+		if (gn < nvec) {
+			nx = xin[gn];
+			ny = yin[gn];
+		}
+		int64_t x[kVec], y[kVec];
+		uint32_t dirs[kVec], p0[kVec];
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const int32_t ix = sext32(tx[v], kp.iw);
+			const int32_t iy = sext32(ty[v], kp.iw);
+			const int32_t ex = (int32_t)((uint32_t)ix << kp.in_shl);
+			const int32_t ey = (int32_t)((uint32_t)iy << kp.in_shl);
+			int32_t fx, fy;
+			fold_quadrant_masks<int32_t>(ex, ey, ix, iy, fx, fy, p0[v]);
+			// stage 1 (shift 1) on the 32-bit values, rtl/topolar.v:226-243
+			const int32_t d = fy >> 31;
+			const int32_t sy = fy >> 1, sx = fx >> 1;
+			const int32_t x1 = fx + ((sy ^ d) - d);	// x + t * sy
+			const int32_t y1 = fy - ((sx ^ d) - d);	// y - t * sx
+			dirs[v] = (uint32_t)d & 0x80000000u;
+			x[v] = (int64_t)((uint64_t)(int64_t)x1 << 30);
+			y[v] = (int64_t)((uint64_t)(int64_t)y1 << 30);
+		}
+
+		PolChainLJ<NLIVE, 1, DYN>::run(x, y, dirs, smask, kp);
+
+		i32x4 rm;
+		u32x4 rp;
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			rm[v] = round_to_ow<int32_t>((int32_t)(x[v] >> 30), kp);
+			uint32_t p = p0[v] + ptab[0][dirs[v] >> 22];
+			if constexpr (kGroups > 1)
+				p += ptab[1][(dirs[v] >> 12) & 1023u];
+			if constexpr (kGroups > 2)
+				p += ptab[2][(dirs[v] >> 2) & 1023u];
+			rp[v] = p >> kp.pw_shl;			// rtl/topolar.v:269
+		}
+		apply_unit_gain<UG>(rm, kp);
+		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
+		CORDIC_STORE_OUT(true, &oph[g], IO::narrow(rp));
+	}
+}
+
 } // namespace dev
 } // namespace cordic_amd
 #endif

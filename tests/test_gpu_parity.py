@@ -130,6 +130,49 @@ def test_exhaustive_p2r_checked_in_core_and_bench_criteria():
     assert abs(q["cnr"] - cfg.best_possible_cnr) < 0.5
 
 
+POL_LJ_CASES = [   # (iw, ow, xtra, pw, nstages): WW <= 32, <= 24 rotations
+    (24, 24, 2, -1, 20), (24, 24, 2, -1, 16), (24, 24, 2, -1, 18),
+    (24, 24, 2, -1, 24), (24, 24, 2, -1, 22), (13, 13, 2, -1, -1),
+    (16, 16, 2, -1, -1), (20, 24, 1, 30, 19), (26, 26, 0, -1, 24),
+    (8, 8, 2, -1, -1), (12, 16, 3, -1, 12), (24, 24, 2, 32, 3),
+    (24, 24, 2, 32, 2), (24, 24, 2, 32, 11),
+]
+
+
+@pytest.mark.parametrize("mode", [ca.R2P, ca.SR2P])
+@pytest.mark.parametrize("args", POL_LJ_CASES)
+def test_r2p_left_justified_form(args, mode):
+    """topolar_lj (left-justified x/y, o_phase rebuilt from direction bits
+    through LDS tables) against the oracle AND against the plain unrolled
+    kernel (CORDIC_FLAG_NO_LJ), on random vectors, the axes / diagonals /
+    extremes, and vectors a few LSBs long (where the truncations dominate the
+    |y| bound the direction-bit argument rests on)."""
+    try:
+        cfg, ocfg = both(mode, *args)
+    except ca.CordicError:
+        pytest.skip("core refused (sequential corner case)")
+    assert cfg.ww <= 32 and not cfg.needs_wrap and 2 <= cfg.nlive <= 24
+    rng = np.random.RandomState(7)
+    n = (1 << 17) + 3
+    lim = 1 << (cfg.iw - 1)
+    x = rng.randint(-lim, lim, size=n).astype(np.int32)
+    y = rng.randint(-lim, lim, size=n).astype(np.int32)
+    sp = np.array([0, 1, -1, lim - 1, -lim, lim // 2, -(lim // 2), 2, -2, 3],
+                  dtype=np.int32)
+    gx, gy = np.meshgrid(sp, sp)
+    x[:100], y[:100] = gx.ravel(), gy.ravel()
+    small = rng.randint(-8, 8, size=(2, 4096)).astype(np.int32)
+    x[100:4196], y[100:4196] = small[0], small[1]
+    # |y| == x after the fold (the 45 degree edge of the convergence range)
+    x[4196:8292] = rng.randint(-lim, lim, size=4096)
+    y[4196:8292] = 0
+    m, p = gpu_r2p(cfg, x, y)
+    rm, rp = O.topolar(ocfg, x, y)
+    assert np.array_equal(m, rm) and np.array_equal(p, rp)
+    m2, p2 = gpu_r2p(cfg.with_flags(ca.FLAG_NO_LJ), x, y)
+    assert np.array_equal(m, m2) and np.array_equal(p, p2)
+
+
 def test_exhaustive_r2p_checked_in_core_and_bench_criteria():
     cfg, ocfg = both(ca.R2P, 13, 13, 2)
     x, y, mg = Q.r2p_bench_inputs(cfg.iw, cfg.pw)
