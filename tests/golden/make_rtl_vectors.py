@@ -53,12 +53,31 @@ def emit(args):
                        capture_output=True)
         v = open(vf).read()
         h = open(os.path.join(td, "core.h")).read()
-    # sw/basiccordic.cpp:418-419 prints "// }}}" and the always header of the
-    # WW == OW+1 ("No rounding required") branch on ONE line, which comments
-    # the always header out: that core does not elaborate as emitted.  Restore
-    # the evidently intended line break so the branch can be executed.
-    v = v.replace("// }}}\talways", "// }}}\n\talways")
-    return v, h
+    return repair_truncating_core(v), h
+
+
+# The ONE edit ever made to emitted text, and only for cores with WW == OW+1:
+# sw/basiccordic.cpp:418-419 prints "// }}}" and the `always` header of the "No
+# rounding required" branch on ONE line, which comments the header out -- that
+# core does not elaborate as emitted (a FINDING about the reference, recorded
+# in DESIGN.md section 2; tests/test_rtl_vectors.py asserts that the unrepaired
+# text is rejected and that no other core is touched).  The evidently intended
+# line break is restored so that the branch can be executed at all; vectors of
+# such a core carry "repaired_text": true.
+BROKEN, REPAIRED = "// }}}\talways", "// }}}\n\talways"
+
+
+def repair_truncating_core(v):
+    return v.replace(BROKEN, REPAIRED)
+
+
+def emit_raw(args):
+    """(Verilog text exactly as emitted, header text)."""
+    with tempfile.TemporaryDirectory() as td:
+        vf = os.path.join(td, "core.v")
+        subprocess.run([GEN] + args.split() + ["-c", "-f", vf], check=True,
+                       capture_output=True)
+        return open(vf).read(), open(os.path.join(td, "core.h")).read()
 
 
 def inputs(rng, iw, pw, n, need_phase):
@@ -88,7 +107,8 @@ def main():
     out = {}
     rng = np.random.RandomState(20240917)
     for name, (args, n) in CORES.items():
-        v, h = emit(args)
+        raw, h = emit_raw(args)
+        v = repair_truncating_core(raw)
         m = vsim.Module(v)
         iw, pw = m.params["IW"], m.params["PW"]
         rot = "i_phase" in m.decl
@@ -106,7 +126,8 @@ def main():
             res = vsim.run_sequential(m, samples, cpo)
         else:
             res = vsim.run_pipelined(m, samples)
-        e = {"args": args.replace("-a ", ""), "IW": iw, "OW": m.params["OW"],
+        e = {"args": args.replace("-a ", ""), "repaired_text": v != raw,
+             "IW": iw, "OW": m.params["OW"],
              "WW": m.params["WW"], "PW": pw, "x": [int(v) for v in x],
              "y": [int(v) for v in y]}
         if rot:

@@ -53,6 +53,39 @@ def test_oracle_reproduces_every_rtl_vector(vectors):
     assert total >= 10000
 
 
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref/gencordic "
+                    "not built (make -C oracle ref)")
+def test_the_only_text_repair_is_the_truncating_core(vectors):
+    """A finding about the reference, not a convenience: for WW == OW+1 the
+    generator comments its own `always` header out (sw/basiccordic.cpp:418-419),
+    so the core as emitted has no output registers.  vsim must reject or
+    mis-elaborate the raw text (no o_xval assignment is ever executed), the
+    repaired text must differ by exactly that one line break, and no other
+    core's text may be touched."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_rtl_vectors as mk
+    for name, (args, _) in mk.CORES.items():
+        raw, _ = mk.emit_raw(args)
+        fixed = mk.repair_truncating_core(raw)
+        e = vectors[name]
+        truncating = ("phase" in e) and e["WW"] == e["OW"] + 1
+        assert e.get("repaired_text", False) == truncating, name
+        if not truncating:
+            assert fixed == raw, name
+            continue
+        assert raw.count(mk.BROKEN) == 1
+        assert fixed == raw.replace(mk.BROKEN, mk.REPAIRED, 1)
+        # as emitted: either unparsable, or a core whose outputs never change
+        try:
+            m = vsim.Module(raw)
+        except (SyntaxError, KeyError, IndexError):
+            continue
+        res = vsim.run_pipelined(m, [dict(i_xval=1000, i_yval=-700,
+                                          i_phase=12345)] * 4)
+        assert all(r["o_xval"] == 0 and r["o_yval"] == 0 for r in res)
+
+
 def test_vectors_cover_the_corner_semantics(vectors):
     """The fixture must really exercise what is hard: WW-bit overflow of a
     tiny core, the WW == OW+1 truncation branch, stages past WW."""

@@ -19,11 +19,11 @@ case; blocking and non-blocking assignments; `always @(*)`; continuous
 assignments to part selects of a wire; localparam items; expressions with
 + - * unary-, !, reduction & and |, && ||, == != < <= > >=, >> >>> <<,
 concatenation, replication, bit and part selects, sized literals and
-$signed().  Values are evaluated as unbounded
-integers in the signedness Verilog assigns to the expression and truncated to
-the declared width on assignment; this is exact for every expression the
-generator emits (no intermediate result depends on a carry that a narrower
-context would have dropped).
+$signed().  Expressions are sized and signed as IEEE 1364-2005 5.4-5.5 say
+(context width = the wider of the two sides of an assignment, an expression
+is unsigned as soon as one operand is, shift amounts / concatenation operands /
+comparison operand pairs are self-determined); tests/test_vsim_conformance.py
+holds the cases with their values worked out from those rules by hand.
 """
 import re
 
@@ -469,15 +469,32 @@ class Module:
         w, _ = self.sig(node, env)
         return self.val(node, env, False) & ((1 << w) - 1)
 
-    def val(self, node, env, signed=None):
-        """mathematical value of `node` evaluated in a context of the given
-        signedness (None: the expression's own)."""
+    def val(self, node, env, signed=None, cw=None):
+        """Value of `node` as IEEE 1364-2005 5.4-5.5 evaluate it: in a context
+        of `cw` bits (None: the expression's self-determined width; callers
+        pass max(width of the right-hand side, width of the target)) and of the
+        given signedness (None: the expression's own -- unsigned as soon as one
+        operand is).  Context-determined operands (of + - * ~ unary-, the left
+        operand of a shift) are extended to cw bits first -- sign-extended only
+        if the WHOLE expression is signed -- and every such operation wraps to
+        cw bits, so a carry out of the context is lost exactly as in a
+        simulator.  Returns a signed integer in a signed context, else a
+        non-negative one below 2^cw."""
         k = node.kind
         w, s = self.sig(node, env)
         if signed is None:
             signed = s
+        if cw is None:
+            cw = w
+
+        def wrap(v):
+            v &= (1 << cw) - 1
+            if signed and (v >> (cw - 1)) & 1:
+                v -= 1 << cw
+            return v
 
         def leaf(u):
+            # a w-bit operand extended to the context
             if signed and s and (u >> (w - 1)) & 1:
                 return u - (1 << w)
             return u
@@ -491,11 +508,14 @@ class Module:
                 return self.params[n]
             if n in self.assigns:
                 rhs, e2 = self.assigns[n]
-                return leaf(self.val(rhs, e2) & ((1 << w) - 1))
+                c2 = max(w, self.sig(rhs, e2)[0])
+                return leaf(self.val(rhs, e2, None, c2) & ((1 << w) - 1))
             if n in self.assign_parts:
                 u = 0
                 for hi, lo, rhs, e2 in self.assign_parts[n]:
-                    u |= (self.val(rhs, e2) & ((1 << (hi - lo + 1)) - 1)) << lo
+                    pw_ = hi - lo + 1
+                    c2 = max(pw_, self.sig(rhs, e2)[0])
+                    u |= (self.val(rhs, e2, None, c2) & ((1 << pw_) - 1)) << lo
                 return leaf(u)
             return leaf(self.state[n])
         if k == "idx":
@@ -508,7 +528,7 @@ class Module:
             hi = self.const(node.args[1], env)
             lo = self.const(node.args[2], env)
             return (self.raw(node.args[0], env) >> lo) & ((1 << (hi - lo + 1)) - 1)
-        if k == "cat":
+        if k == "cat":                      # operands self-determined, unsigned
             v = 0
             for it in node.args[0]:
                 iw = self.sig(it, env)[0]
@@ -522,7 +542,7 @@ class Module:
             for _ in range(n):
                 v = (v << iw) | b
             return v
-        if k == "signed":
+        if k == "signed":                   # $signed(): operand self-determined
             return leaf(self.raw(node.args[0], env))
         if k == "un":
             op, a = node.args
@@ -534,34 +554,34 @@ class Module:
             if op == "|":
                 return int(self.raw(a, env) != 0)
             if op == "-":
-                return -self.val(a, env, signed)
+                return wrap(-self.val(a, env, signed, cw))
             if op == "~":
-                return ~self.val(a, env, signed)
-            return self.val(a, env, signed)
+                return wrap(~self.val(a, env, signed, cw))
+            return self.val(a, env, signed, cw)
         op, a, b = node.args
         if op == "||":
             return int(self.raw(a, env) != 0 or self.raw(b, env) != 0)
         if op == "&&":
             return int(self.raw(a, env) != 0 and self.raw(b, env) != 0)
         if op in ("==", "!=", "<", "<=", ">", ">="):
-            sg = self.sig(a, env)[1] and self.sig(b, env)[1]
-            x, y = self.val(a, env, sg), self.val(b, env, sg)
+            # operands sized to the wider of the two, signed only if both are
+            (wa, sa), (wb, sb) = self.sig(a, env), self.sig(b, env)
+            sg, cc = sa and sb, max(wa, wb)
+            x, y = self.val(a, env, sg, cc), self.val(b, env, sg, cc)
             return int({"==": x == y, "!=": x != y, "<": x < y, "<=": x <= y,
                         ">": x > y, ">=": x >= y}[op])
         if op in (">>>", ">>", "<<", "<<<"):
-            sh = self.raw(b, env)
-            x = self.val(a, env, signed)
-            if op == ">>>":
-                if not (signed and s):
-                    x &= (1 << w) - 1       # unsigned: logical shift
-                return x >> sh
-            if op == ">>":
-                return (x & ((1 << max(w, 64)) - 1)) >> sh if x < 0 else x >> sh
-            return x << sh
-        x, y = self.val(a, env, signed), self.val(b, env, signed)
+            sh = self.raw(b, env)           # the amount is self-determined
+            x = self.val(a, env, signed, cw)
+            if op == ">>>" and signed and s:
+                return x >> sh              # arithmetic: the context is signed
+            if op in (">>>", ">>"):
+                return (x & ((1 << cw) - 1)) >> sh
+            return wrap(x << sh)
+        x, y = self.val(a, env, signed, cw), self.val(b, env, signed, cw)
         if op == "*":
-            return x * y
-        return x + y if op == "+" else x - y
+            return wrap(x * y)
+        return wrap(x + y if op == "+" else x - y)
 
     def exec(self, st, env, ups, blocking=False):
         k = st.kind
@@ -586,7 +606,8 @@ class Module:
             now = blocking or k == "ba"
             if lhs.kind == "cat":          # { a, b } <= value
                 widths = [self.decl[i.args[0]][0] for i in lhs.args[0]]
-                v = self.val(rhs, env) & ((1 << sum(widths)) - 1)
+                cw = max(sum(widths), self.sig(rhs, env)[0])
+                v = self.val(rhs, env, None, cw) & ((1 << sum(widths)) - 1)
                 for item, w in zip(reversed(lhs.args[0]), reversed(widths)):
                     part = v & ((1 << w) - 1)
                     v >>= w
@@ -599,7 +620,8 @@ class Module:
                 name = lhs.args[0].args[0]
                 idx = self.val(lhs.args[1], env)
                 if self.decl[name][2] is None:     # bit select of a vector
-                    bit = self.val(rhs, env) & 1
+                    bit = self.val(rhs, env, None,
+                                   max(1, self.sig(rhs, env)[0])) & 1
                     if now:
                         self._store(name, ("bit", idx), bit)
                     else:
@@ -608,8 +630,10 @@ class Module:
             else:
                 name, idx = lhs.args[0], None
             w = self.decl[name][0]
-            # the RHS is evaluated in its own signedness, then truncated
-            v = self.val(rhs, env) & ((1 << w) - 1)
+            # the RHS is evaluated in its own signedness, in a context as wide
+            # as the wider of the two sides, then truncated to the target
+            v = self.val(rhs, env, None, max(w, self.sig(rhs, env)[0])) \
+                & ((1 << w) - 1)
             if now:
                 self._store(name, idx, v)
             else:
