@@ -20,12 +20,30 @@ using namespace cordic_amd;
 // being in flight at once.
 constexpr unsigned kQueueSlots = 64;
 
+struct QueueRing {
+	uint32_t *d = nullptr;		// kQueueSlots x CORDIC_QUEUE_BYTES
+	mutable std::atomic<unsigned> next{0};
+	bool alloc()
+	{
+		return hipMalloc((void **)&d, (size_t)kQueueSlots
+				* CORDIC_QUEUE_BYTES) == hipSuccess;
+	}
+	void release() { if (d) (void)hipFree(d); d = nullptr; }
+	uint32_t *take() const
+	{
+		if (!d)
+			return nullptr;
+		const unsigned slot = next.fetch_add(1, std::memory_order_relaxed)
+				% kQueueSlots;
+		return d + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
+	}
+};
+
 struct cordic_plan {
 	cordic_config cfg;
 	uint32_t *d_table = nullptr;	// device copy of the seed table
 	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
-	uint32_t *d_queues = nullptr;	// kQueueSlots x CORDIC_QUEUE_BYTES
-	mutable std::atomic<unsigned> next_queue{0};
+	QueueRing queues;
 };
 
 int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
@@ -46,10 +64,9 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		if (hipMalloc((void **)&p->d_table, nw * 4) != hipSuccess ||
 		    hipMemcpy(p->d_table, words.data(), nw * 4,
 				hipMemcpyHostToDevice) != hipSuccess ||
-		    hipMalloc((void **)&p->d_queues, (size_t)kQueueSlots
-				* CORDIC_QUEUE_BYTES) != hipSuccess) {
+		    !p->queues.alloc()) {
 			if (p->d_table) (void)hipFree(p->d_table);
-			if (p->d_queues) (void)hipFree(p->d_queues);
+			p->queues.release();
 			delete p;
 			return CORDIC_ERR_DEVICE;
 		}
@@ -68,8 +85,7 @@ void cordic_plan_destroy(cordic_plan *plan)
 		return;
 	if (plan->d_table)
 		(void)hipFree(plan->d_table);
-	if (plan->d_queues)
-		(void)hipFree(plan->d_queues);
+	plan->queues.release();
 	delete plan;
 }
 
@@ -96,11 +112,7 @@ static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 	j.seed_S = plan->S;
 	j.seed_nbuckets = plan->nbuckets;
 	j.seed_nleaves = plan->nleaves;
-	if (plan->d_queues) {
-		const unsigned slot = plan->next_queue.fetch_add(1,
-				std::memory_order_relaxed) % kQueueSlots;
-		j.queue = plan->d_queues + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
-	}
+	j.queue = plan->queues.take();
 }
 
 int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,
@@ -249,6 +261,7 @@ struct cordic_table {
 	// table folded to its first quadrant (+ the peak entry)
 	int16_t *d_lds16 = nullptr;
 	int	lds_mode = 0, lds_entries = 0;
+	QueueRing queues;	// optional: without it the chunk-per-block sweep runs
 };
 
 namespace {
@@ -334,6 +347,8 @@ int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 			(void)hipGetLastError();
 		}
 	}
+	if (!t->queues.alloc())
+		(void)hipGetLastError();
 	*tbl = t;
 	return CORDIC_OK;
 }
@@ -342,6 +357,7 @@ void cordic_table_destroy(cordic_table *tbl)
 {
 	if (!tbl)
 		return;
+	tbl->queues.release();
 	if (tbl->d_tbl)
 		(void)hipFree(tbl->d_tbl);
 	if (tbl->d_lds16)
@@ -355,13 +371,15 @@ int cordic_table_lookup(const cordic_table *tbl, size_t n,
 	if (!tbl)
 		return CORDIC_ERR_ARGS;
 	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream,
-			tbl->d_lds16, tbl->lds_mode, tbl->lds_entries);
+			tbl->d_lds16, tbl->lds_mode, tbl->lds_entries,
+			tbl->queues.take());
 }
 
 // ------------------------------------------------- quadratic sine core
 struct cordic_quad {
 	cordic_quad_config cfg;
 	int32_t *d_tab = nullptr;	// entries x {C, L, Q, 0}
+	QueueRing queues;
 };
 
 int cordic_quad_config_init(cordic_quad_config *cfg, int iw, int ow, int xtra,
@@ -416,6 +434,8 @@ int cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core)
 		delete h;
 		return CORDIC_ERR_DEVICE;
 	}
+	if (!h->queues.alloc())
+		(void)hipGetLastError();
 	*core = h;
 	return CORDIC_OK;
 }
@@ -424,6 +444,7 @@ void cordic_quad_destroy(cordic_quad *core)
 {
 	if (!core)
 		return;
+	core->queues.release();
 	if (core->d_tab)
 		(void)hipFree(core->d_tab);
 	delete core;
@@ -434,7 +455,8 @@ int cordic_quad_lookup(const cordic_quad *core, size_t n, const uint32_t *d_phas
 {
 	if (!core)
 		return CORDIC_ERR_ARGS;
-	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream);
+	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream,
+			core->queues.take());
 }
 
 // Scratch of the clocked views.  cordic_*_reserve sizes it up front; a *_ticks

@@ -693,6 +693,55 @@ __device__ __forceinline__ uint32_t xcc_id()
 	return v & 0xfu;
 }
 
+// Generic form of the address-ordered tile queue for kernels without a
+// cross-tile prefetch (the table cores): persistent BS-thread blocks pull tile
+// numbers from the per-XCD counters in `queue` and call body(tile) for each;
+// `slot` is three words of LDS.  See rotator_seeded for the why.
+template <int BS, typename F>
+__device__ __forceinline__ void for_each_queued_tile(uint32_t *queue,
+		volatile uint32_t *slot, uint32_t ntiles, F body)
+{
+	constexpr uint32_t kEnd = 0xffffffffu;
+	const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
+	uint32_t home = 0, tried = 0;		// lane 0 of the block only
+	auto grab = [&]() -> uint32_t {
+		while (tried < (uint32_t)kQueueCounters) {
+			const uint32_t j = (home + tried) % kQueueCounters;
+			const uint32_t lo = j * per;
+			const uint32_t cnt = lo >= ntiles ? 0u
+				: (ntiles - lo < per ? ntiles - lo : per);
+			if (cnt != 0) {
+				const uint32_t t = atomicAdd(&queue[j * kQueueStride], 1u);
+				if (t < cnt)
+					return lo + t;
+			}
+			tried++;
+		}
+		return kEnd;
+	};
+	auto lds_barrier = [] {		// LDS only: no wait for global stores
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	};
+	if (threadIdx.x == 0) {
+		home = xcc_id() % kQueueCounters;
+		slot[0] = grab();
+		slot[1] = grab();
+	}
+	lds_barrier();
+	uint32_t cur = slot[0];
+	int ring = 0;
+	while (cur != kEnd) {
+		const uint32_t nxt = slot[(ring + 1) % 3];
+		body(cur);
+		if (threadIdx.x == 0)
+			slot[(ring + 2) % 3] = grab();
+		lds_barrier();
+		cur = nxt;
+		ring = (ring + 1) % 3;
+	}
+}
+
+
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
 		typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,

@@ -101,7 +101,7 @@ int	launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 int	launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream,
 		const int16_t *d_lds16 = nullptr, int lds_mode = 0,
-		int lds_entries = 0);
+		int lds_entries = 0, uint32_t *queue = nullptr);
 // ---- clocked view of the pipelined cores: cordic_stream.hip
 struct StreamState {
 	void	*ws = nullptr;		// scan / gather workspace
@@ -140,7 +140,8 @@ int	launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 		int32_t *o0, int32_t *o1, uint8_t *busy, uint8_t *done,
 		uint8_t *oaux, void *stream);
 int	launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
-		size_t n, const uint32_t *phase, int32_t *val, void *stream);
+		size_t n, const uint32_t *phase, int32_t *val, void *stream,
+		uint32_t *queue = nullptr);
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream);
 

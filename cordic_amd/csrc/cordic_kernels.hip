@@ -164,27 +164,50 @@ __device__ __forceinline__ int32_t table_sample(const int32_t *__restrict__ tbl,
 	}
 }
 
-template <bool QUARTER>
-__global__ __launch_bounds__(1024) void table_lookup(
-		const int32_t *__restrict__ tbl, const uint32_t *__restrict__ phase,
-		int32_t *__restrict__ val, size_t n, int pw, int ow)
+// Work distribution of the three table kernels: persistent 1024-thread blocks
+// (they keep their table in LDS) that pull 1024-vector tiles from the per-XCD
+// counters in `queue` in address order (cordic_device.h: for_each_queued_tile;
+// an arithmetic-free 1R1W stream runs at 0.58-0.63 of the HBM peak with one
+// contiguous chunk per block and at 0.72-0.79 this way, profiles/r02/
+// hbm_probe2.txt).  queue == NULL: the chunk-per-block sweep.
+template <typename F>
+__device__ __forceinline__ void sweep_tiles(uint32_t *queue, volatile uint32_t *slot,
+		size_t nvec, F one_vector)
 {
-	// 1024-thread blocks, one contiguous chunk each (see quad_lookup)
-	const size_t nvec = n / kVec;
+	if (queue) {
+		for_each_queued_tile<1024>(queue, slot,
+			(uint32_t)((nvec + 1023) / 1024), [&](uint32_t tile) {
+				const size_t g = (size_t)tile * 1024 + threadIdx.x;
+				if (g < nvec)
+					one_vector(g);
+			});
+		return;
+	}
 	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
 	chunk = (chunk + 1023) / 1024 * 1024;
 	const size_t lo = (size_t)blockIdx.x * chunk;
 	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
+	for (size_t g = lo + threadIdx.x; g < hi; g += 1024)
+		one_vector(g);
+}
+
+template <bool QUARTER>
+__global__ __launch_bounds__(1024) void table_lookup(
+		const int32_t *__restrict__ tbl, const uint32_t *__restrict__ phase,
+		int32_t *__restrict__ val, size_t n, int pw, int ow, uint32_t *queue)
+{
+	__shared__ uint32_t slot[3];
+	const size_t nvec = n / kVec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+	sweep_tiles(queue, slot, nvec, [&](size_t g) {
 		const u32x4 p = pv[g];
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = table_sample<QUARTER>(tbl, p[v], pw, ow);
 		ov[g] = o;
-	}
+	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
 			val[i] = table_sample<QUARTER>(tbl, phase[i], pw, ow);
@@ -202,9 +225,10 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void table_lookup_lds(
 		const int16_t *__restrict__ packed, int entries,
 		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
-		size_t n, int pw, int ow)
+		size_t n, int pw, int ow, uint32_t *queue)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds16[];
+	__shared__ uint32_t slot[3];
 	for (int i = threadIdx.x; i < entries; i += 1024)
 		lds16[i] = packed[i];
 	__syncthreads();
@@ -225,20 +249,16 @@ __global__ __launch_bounds__(1024) void table_lookup_lds(
 		}
 	};
 	const size_t nvec = n / kVec;
-	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
-	chunk = (chunk + 1023) / 1024 * 1024;
-	const size_t lo = (size_t)blockIdx.x * chunk;
-	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+	sweep_tiles(queue, slot, nvec, [&](size_t g) {
 		const u32x4 p = pv[g];
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = sample(p[v]);
 		ov[g] = o;
-	}
+	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
 			val[i] = sample(phase[i]);
@@ -293,9 +313,10 @@ __device__ __forceinline__ int32_t quad_sample(const i32x4 e, uint32_t ph,
 __global__ __launch_bounds__(1024) void quad_lookup(
 		const i32x4 *__restrict__ tab, QuadParams qp,
 		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
-		size_t n)
+		size_t n, uint32_t *queue)
 {
 	extern __shared__ __attribute__((aligned(16))) i32x4 lds_tab[];
+	__shared__ uint32_t slot[3];
 	for (int i = threadIdx.x; i < (1 << qp.lgtbl); i += 1024)
 		lds_tab[i] = tab[i];
 	__syncthreads();
@@ -303,20 +324,16 @@ __global__ __launch_bounds__(1024) void quad_lookup(
 	const uint32_t imask = (1u << qp.lgtbl) - 1u;
 	const int ish = qp.dxbits - 1;
 	const size_t nvec = n / kVec;
-	size_t chunk = (nvec + gridDim.x - 1) / gridDim.x;
-	chunk = (chunk + 1023) / 1024 * 1024;
-	const size_t lo = (size_t)blockIdx.x * chunk;
-	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	for (size_t g = lo + threadIdx.x; g < hi; g += 1024) {
+	sweep_tiles(queue, slot, nvec, [&](size_t g) {
 		const u32x4 p = pv[g];
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = quad_sample(t[(p[v] >> ish) & imask], p[v], qp);
 		ov[g] = o;
-	}
+	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
 			val[i] = quad_sample(t[(phase[i] >> ish) & imask], phase[i], qp);
@@ -710,10 +727,14 @@ int launch_fill_iq_ramp(int32_t *x, int32_t *y, size_t n, uint64_t index0,
 
 int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		size_t n, const uint32_t *phase, int32_t *val, void *stream,
-		const int16_t *d_lds16, int lds_mode, int lds_entries)
+		const int16_t *d_lds16, int lds_mode, int lds_entries,
+		uint32_t *queue)
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
+	if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
+			static_cast<hipStream_t>(stream)) != hipSuccess)
+		return CORDIC_ERR_DEVICE;
 	if (!d_tbl || !phase || !val || !table_sane(t)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	if (d_lds16 && lds_mode) {
@@ -727,13 +748,14 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 		auto k2 = table_lookup_lds<2>;
 		auto kern = (lds_mode == 1) ? k1 : k2;
 		bool lds_ok = true;
-		if (bytes > 64 * 1024)
+		if (bytes + 64 > 64 * 1024)	// + the kernel's static tile-id slots
 			lds_ok = hipFuncSetAttribute((const void *)kern,
-				hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
-				== hipSuccess;
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)bytes + 64) == hipSuccess;
 		if (lds_ok) {
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), bytes, st,
-					d_lds16, lds_entries, phase, val, n, t.pw, t.ow);
+					d_lds16, lds_entries, phase, val, n, t.pw, t.ow,
+					queue);
 			return check_launch();
 		}
 		clear_stale_error();	// the L2 gather kernel below serves the table
@@ -743,18 +765,22 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (t.kind == CORDIC_QTR)
 		hipLaunchKernelGGL(table_lookup<true>, dim3(grid), dim3(1024), 0,
-				st, d_tbl, phase, val, n, t.pw, t.ow);
+				st, d_tbl, phase, val, n, t.pw, t.ow, queue);
 	else
 		hipLaunchKernelGGL(table_lookup<false>, dim3(grid), dim3(1024), 0,
-				st, d_tbl, phase, val, n, t.pw, t.ow);
+				st, d_tbl, phase, val, n, t.pw, t.ow, queue);
 	return check_launch();
 }
 
 int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
-		size_t n, const uint32_t *phase, int32_t *val, void *stream)
+		size_t n, const uint32_t *phase, int32_t *val, void *stream,
+		uint32_t *queue)
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
+	if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
+			static_cast<hipStream_t>(stream)) != hipSuccess)
+		return CORDIC_ERR_DEVICE;
 	if (!d_tables || !phase || !val || !quad_sane(q)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	const int grid = grid_for((size_t)1024 * kVec, n, 2);
@@ -766,7 +792,7 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 	if (bytes > 64 * 1024)
 		return CORDIC_ERR_UNSUPPORTED;
 	hipLaunchKernelGGL(quad_lookup, dim3(grid), dim3(1024), bytes, st, tab,
-			qp, phase, val, n);
+			qp, phase, val, n, queue);
 	return check_launch();
 }
 

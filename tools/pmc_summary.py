@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense one tools/profile_r01.sh output directory into
+"""Condense one tools/profile_workload.sh output directory into
 gpurun_out/prof/<tag>/summary.json (+ the kernel_stats.csv next to it).
 
 HBM bytes per launch = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024: both counters
@@ -29,8 +29,8 @@ def counters(sub):
 
 def short(name):
     for key in ("rotator_seeded", "rotator_unrolled", "rotator_generic",
-                "topolar_unrolled", "topolar_generic", "table_lookup",
-                "quad_lookup"):
+                "topolar_lj", "topolar_unrolled", "topolar_generic",
+                "table_lookup", "quad_lookup"):
         if key in name:
             return key
     return None
