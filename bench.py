@@ -667,7 +667,8 @@ def run_group(args, w, launch):
 
     grp.close()
     single = None
-    if (launch == "torchrun" and world > 1 and not args.no_single_process_check):
+    if (launch == "torchrun" and not args.no_single_process_check
+            and (world > 1 or os.environ.get("BENCH_FORCE_SINGLE_CHECK"))):
         # the C++ one-process layer on the same GPUs, for the record: rank 0
         # drives every device while the other ranks wait on the HOST (a gloo
         # barrier: no GPU kernel spins meanwhile)
@@ -675,8 +676,7 @@ def run_group(args, w, launch):
         torch.cuda.empty_cache()
         if rank == 0:
             try:
-                single = single_process_block(args, cfg, w, world, step_kind=kind,
-                                              x0=x0, y0=y0, expect=digest)
+                single = single_process_block(args, world, digest)
             except Exception as e:            # never lose the main line
                 single = {"error": repr(e)}
         dist.barrier(group=host)
@@ -797,66 +797,40 @@ class _RawWords:
         return self._n
 
 
-def single_process_block(args, cfg, w, ndev, step_kind, x0, y0, expect):
-    """One host process, every GPU, through cordic_group (rank 0 of a
-    multi-process run, after the main measurement)."""
-    import cordic_amd as ca
-    n = 1 << args.log2_samples
-    n_total = n * ndev
-    g = ca.Group(cfg, devices=list(range(ndev)), first_shard=0,
-                 total_shards=ndev)
-
-    def step():
-        if step_kind == "p2r":
-            g.p2r_const(n_total, x0, y0)
-        elif step_kind == "r2p":
-            g.r2p(n_total)
-        else:
-            g.nco(n_total, 0, 0x01234567, x0, y0)
-    if step_kind == "p2r":
-        g.fill_phase_ramp(n_total, w["shift"])
-    elif step_kind == "r2p":
-        g.fill_iq_ramp(n_total, 0x9E3779B1, 0x85EBCA77, cfg.iw)
-    for _ in range(max(1, args.warmup)):
-        step()
-    g.sync()
-    t0 = time.perf_counter()
-    g.mark(0)
-    for _ in range(args.steps):
-        step()
-    g.mark(1)
-    g.sync()
-    wall = time.perf_counter() - t0
-    ms, per = g.elapsed(0, 1)
-    res = {"n_gpus": ndev, "steps": args.steps,
-           "value": n_total * args.steps / wall / 1e6, "unit": "Msamples/s",
-           "ms_per_step": wall / args.steps * 1e3,
-           "per_shard_kernel_ms": [v / args.steps for v in per]}
-    if args.input == "ramp":
-        res["digest_equals_multi_process_run"] = g.digest(n_total) == expect
-    # and with the results forwarded to device 0 behind the compute
-    root = ca.Group(cfg, devices=[0], first_shard=0, total_shards=1)
-    root.reserve(n_total, 0)
-    _, rp, _ = root.buffers(0)
-    g.set_gather(0, rp[2], rp[3], 8)
-    step()
-    g.sync()
-    t0 = time.perf_counter()
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-    g.sync()
-    k = max(3, min(args.steps, 10))
-    wall = time.perf_counter() - t0
-    res["compute_and_gather"] = {
-        "what": "every step's outputs forwarded to device 0 in 8 pieces "
-                "(hipMemcpyPeerAsync on the shards' copy streams) while the "
-                "next piece is being computed",
-        "steps": k, "ms_per_step": wall / k * 1e3,
-        "value": n_total * k / wall / 1e6,
-        "gathered_digest_equal": (root.digest(n_total) == g.digest(n_total))}
-    g.set_gather(-1)
-    root.close()
-    g.close()
+def single_process_block(args, ndev, expect):
+    """The C++ one-process layer (cordic_group over every GPU, no process
+    group) measured on the same node: a SEPARATE `bench.py --single-process`
+    process with a time limit, so that nothing it does can take the main
+    result down with it.  Returns a digest of its line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE",
+                        "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "BENCH_SELF_SPAWNED")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(ndev),
+           "--single-process", "--workload", args.workload, "--steps",
+           str(args.steps), "--warmup", str(args.warmup), "--log2-samples",
+           str(args.log2_samples), "--input", args.input, "--gather",
+           "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe"]
+    for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
+                     ("--static-chunks", args.static_chunks)):
+        if on:
+            cmd.append(flag)
+    r = subprocess.run(cmd, env=env, text=True, capture_output=True,
+                       timeout=300)
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not rows:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+    d = json.loads(rows[-1])
+    res = {"n_gpus": d["n_gpus"], "value": d["value"], "unit": d["unit"],
+           "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+           "mode": d["launch"]["mode"],
+           "per_shard_kernel_ms": d["launch"]["per_shard_kernel_ms"],
+           "bit_exact_vs_oracle": d["bit_exact_vs_oracle"],
+           "digest_equals_multi_process_run":
+               int(d["digest"], 16) == expect if args.input == "ramp" else None}
+    if "gather" in d:
+        res["gather"] = d["gather"]
     return res
 
 

@@ -63,6 +63,21 @@ def test_self_spawn_path_one_gpu():
 
 
 @pytest.mark.gpu
+def test_multi_process_run_also_measures_the_one_process_layer():
+    """What a >1-GPU torchrun line carries: rank 0 runs `bench.py
+    --single-process` as a guarded subprocess while the other ranks wait on
+    the host (forced here on one GPU)."""
+    r = run(["--gpus", "1", "--spawn"] + SMALL,
+            env={"BENCH_FORCE_SINGLE_CHECK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    sp = d["single_process_cordic_group"]
+    assert "error" not in sp, sp
+    assert sp["n_gpus"] == 1 and sp["bit_exact_vs_oracle"] is True
+    assert sp["digest_equals_multi_process_run"] is True
+
+
+@pytest.mark.gpu
 def test_single_process_path_and_direct_agree():
     a = _line(run(["--gpus", "1", "--single-process"] + SMALL).stdout)
     b = _line(run(["--gpus", "1"] + SMALL).stdout)
