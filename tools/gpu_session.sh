@@ -10,6 +10,7 @@
 #   hbm        tools/hbm_probe2 streaming-pattern sweep  [HBM_ARGS=...]
 #   valu       tools/valu_microbench
 #   prof:<w>   rocprofv3 stats + PMC passes of bench.py --workload <w>
+#   sweep      every bench.py workload x {ramp, random} + the default line
 #   states     alternate copy probe / bench while logging clocks and power
 #   ab:<flags> build a second library with HIPFLAGS_EXTRA=<flags> and A/B it
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -50,6 +51,15 @@ d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['roofline']['frac'],3))" >> $log
 		done; done ;;
+	sweep)	# one bench.py line per workload x {ramp, random}
+		mkdir -p gpurun_out/bench_sweep
+		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 quadtbl quadtbl24; do
+			for inp in ramp random; do
+				python bench.py --workload $w --input $inp --no-cpu-baseline --no-other-paths \
+					> gpurun_out/bench_sweep/${w}_${inp}.json 2>> $log
+			done
+		done
+		python bench.py > gpurun_out/bench_sweep/default.json 2>> $log ;;
 	*)	echo "unknown task $task" | tee -a $log ;;
 	esac
 done
