@@ -15,9 +15,9 @@ using namespace cordic_amd;
 
 // ------------------------------------------------------------------- plans
 // Tile queues of the seeded kernel: every launch takes the next slot of a ring
-// and zeroes it on its own stream, so launches of one plan that overlap (other
-// streams, other threads) never share counters -- short of kQueueSlots of them
-// being in flight at once.
+// (zeroed once here, left zeroed by every kernel that used it), so launches of
+// one plan that overlap (other streams, other threads) never share counters --
+// short of kQueueSlots of them being in flight at once.
 constexpr unsigned kQueueSlots = 64;
 
 struct QueueRing {
@@ -25,8 +25,14 @@ struct QueueRing {
 	mutable std::atomic<unsigned> next{0};
 	bool alloc()
 	{
-		return hipMalloc((void **)&d, (size_t)kQueueSlots
-				* CORDIC_QUEUE_BYTES) == hipSuccess;
+		const size_t bytes = (size_t)kQueueSlots * CORDIC_QUEUE_BYTES;
+		if (hipMalloc((void **)&d, bytes) != hipSuccess)
+			return false;
+		if (hipMemset(d, 0, bytes) != hipSuccess) {
+			release();
+			return false;
+		}
+		return true;
 	}
 	void release() { if (d) (void)hipFree(d); d = nullptr; }
 	uint32_t *take() const

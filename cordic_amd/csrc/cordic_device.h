@@ -684,6 +684,23 @@ struct SeedArgs {
 
 constexpr int kQueueCounters = 8;	// one per XCD
 constexpr int kQueueStride = 64;	// words between counters
+constexpr int kQueueDoneWord = 32;	// blocks that have left the queue
+
+// The queue resets ITSELF: every block, once it has drawn its last ticket
+// (all of lane 0's atomics have returned by then), counts itself out, and the
+// last one to do so zeroes the counters for the next launch.  No memset node
+// in front of the kernel -- a HIP graph that holds a launch replays correctly
+// (a captured hipMemsetAsync of the counters did not re-run on replay) -- and
+// no extra kernel boundary.  The host zeroes a fresh ring once.
+__device__ __forceinline__ void queue_leave(uint32_t *queue)
+{
+	const uint32_t left = atomicAdd(&queue[kQueueDoneWord], 1u);
+	if (left == gridDim.x - 1) {
+		for (int j = 0; j < kQueueCounters; j++)
+			atomicExch(&queue[j * kQueueStride], 0u);
+		atomicExch(&queue[kQueueDoneWord], 0u);
+	}
+}
 
 // XCC_ID of the XCD this wave runs on (affinity only, never correctness)
 __device__ __forceinline__ uint32_t xcc_id()
@@ -739,6 +756,8 @@ __device__ __forceinline__ void for_each_queued_tile(uint32_t *queue,
 		cur = nxt;
 		ring = (ring + 1) % 3;
 	}
+	if (threadIdx.x == 0)
+		queue_leave(queue);
 }
 
 
@@ -1008,6 +1027,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			cur = nxt;
 			ring = (ring + 1) % 3;
 		}
+		if (threadIdx.x == 0)
+			queue_leave(sa.queue);
 		return;
 	}
 

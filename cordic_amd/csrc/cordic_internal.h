@@ -82,9 +82,9 @@ struct RotatorJob {
 	// optional seed table (cordic_plan): device words + their host header
 	const uint32_t *seed_table = nullptr;
 	int seed_m = 0, seed_S = 0, seed_nbuckets = 0, seed_nleaves = 0;
-	// tile queue of the seeded kernel: CORDIC_QUEUE_BYTES of device memory
-	// that no other launch in flight uses (the launcher zeroes it on the
-	// job's stream); NULL = static chunk-per-block sweep
+	// tile queue of the seeded kernel: CORDIC_QUEUE_BYTES of zeroed device
+	// memory that no other launch in flight uses (the kernel leaves it zeroed
+	// again: cordic_device.h queue_leave); NULL = static chunk-per-block sweep
 	uint32_t *queue = nullptr;
 };
 #define CORDIC_QUEUE_BYTES 2048	/* 8 counters, one 256-byte line each */

@@ -548,10 +548,6 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
 			if (per_cu >= 1 && lds <= 160 * 1024) {
-				// the queue's counters start every launch at zero
-				if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
-						st) != hipSuccess)
-					return CORDIC_ERR_DEVICE;
 				if (j.io16)
 					done = launch_seed_narrow16(FEED, cfg.nlive, g2, st,
 							kp, sa, j, lds);
@@ -732,9 +728,6 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
-	if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
-			static_cast<hipStream_t>(stream)) != hipSuccess)
-		return CORDIC_ERR_DEVICE;
 	if (!d_tbl || !phase || !val || !table_sane(t)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	if (d_lds16 && lds_mode) {
@@ -778,9 +771,6 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 {
 	clear_stale_error();
 	if (n == 0) return CORDIC_OK;
-	if (queue && hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES,
-			static_cast<hipStream_t>(stream)) != hipSuccess)
-		return CORDIC_ERR_DEVICE;
 	if (!d_tables || !phase || !val || !quad_sane(q)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
 	const int grid = grid_for((size_t)1024 * kVec, n, 2);

@@ -747,3 +747,48 @@ def test_unit_gain_flag_is_output_times_k_shift_32(mode, iw, ow, pw, ns, flags):
         gm, gp = gpu_r2p(cfg, x, y)
         rm, rp = O.topolar(ocfg, x, y)
         assert np.array_equal(gm, scaled(rm)) and np.array_equal(gp, rp)
+
+
+def test_seeded_plan_in_a_hip_graph_and_on_two_streams():
+    """The tile queue of the seeded kernel takes a fresh counter block per
+    launch and zeroes it on the job's stream: (a) a launch captured into a HIP
+    graph replays correctly any number of times, (b) launches of ONE plan that
+    overlap on two streams never share counters."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    n = (1 << 20) + 4096 * 3 + 8
+    rng = np.random.RandomState(3)
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    x0 = (1 << 31) - 1
+    rx, ry = O.rotate(ocfg, x0, 0, ph)
+    dph = dev_i32(ph)
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    # (a) capture once, replay
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.p2r_const(x0, 0, dph, ox, oy, n=n - n % 4)   # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.p2r_const(x0, 0, dph, ox, oy, n=n - n % 4)
+    for _ in range(5):
+        ox.zero_(); oy.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        m = n - n % 4
+        assert np.array_equal(to_np(ox)[:m], rx[:m])
+        assert np.array_equal(to_np(oy)[:m], ry[:m])
+    # (b) two streams, interleaved launches of the same plan
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    outs = [[torch.zeros(n, dtype=torch.int32, device=DEV) for _ in range(2)]
+            for _ in range(8)]
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(outs):
+        plan.p2r_const(x0, 0, dph, a, b, n=n, stream=(s1, s2)[k & 1])
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert np.array_equal(to_np(a), rx) and np.array_equal(to_np(b), ry)
+    plan.close()

@@ -35,7 +35,7 @@ for t in range(ncfg):
             refused += 1
             continue
     ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
-    n = int(rng.choice([1, 3, 4, 5, 257, 1024, 4099]))
+    n = int(rng.choice([1, 3, 4, 5, 257, 1024, 4099, 8192, 12293, 65541]))
     x, y, ph = rand_inputs(rng, iw, pw, n)
     key = (mode, "wrap" if cfg.needs_wrap else ("wide" if cfg.ww > 35 else
            "lj" if cfg.ww > 32 else "narrow"))

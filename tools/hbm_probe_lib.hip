@@ -81,6 +81,11 @@ __global__ __launch_bounds__(1024) void queued(const u32x4 *__restrict__ a,
 		cur = nxt;
 		ring = (ring + 1) % 3;
 	}
+	// the queue resets itself (cordic_device.h: queue_leave)
+	if (threadIdx.x == 0 && atomicAdd(&ctr[32], 1u) == gridDim.x - 1) {
+		for (int j = 0; j < 8; j++) atomicExch(&ctr[j * 64], 0u);
+		atomicExch(&ctr[32], 0u);
+	}
 }
 
 template <int R, int W>
@@ -95,7 +100,8 @@ static float run(const void *in0, const void *in1, void *out0, void *out1,
 		return -1.f;
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
 		return -1.f;
-	if (mode == 1 && hipMalloc((void **)&ctr, 2048) != hipSuccess)
+	if (mode == 1 && (hipMalloc((void **)&ctr, 2048) != hipSuccess
+			|| hipMemset(ctr, 0, 2048) != hipSuccess))
 		return -1.f;
 	const size_t blocks = (nvec + 255) / 256;
 	auto launch = [&]() {
@@ -104,7 +110,6 @@ static float run(const void *in0, const void *in1, void *out0, void *out1,
 				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
 				nvec, (blocks % 8 == 0) ? 1 : 0);
 		} else {
-			(void)hipMemsetAsync(ctr, 0, 2048, st);
 			hipLaunchKernelGGL((queued<R, W>), dim3(2 * cus), dim3(1024), 0, st,
 				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
 				nvec, ctr);
