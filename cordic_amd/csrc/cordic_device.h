@@ -97,7 +97,9 @@ __device__ __forceinline__ int64_t sext64(int64_t v, int w)
 // the phase register pair is don't-care).
 //
 // v_mad_i64_i32 also writes a carry-out SGPR pair (VCC here, declared as a
-// clobber); nothing reads it, so no wait states are owed.
+// clobber); nothing reads it, so no wait states are owed.  (Letting the
+// compiler spread the carry-outs over other SGPR pairs measured no difference:
+// the shared VCC is not a bottleneck.)
 // -s for s = +/-1 as one full-rate VOP2 (hipcc would fuse (d|1)^-2 into a
 // three-operand v_bitop3_b32)
 __device__ __forceinline__ int32_t op_flip(int32_t s)
@@ -539,6 +541,16 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 	// block; per sample the fold is then one ds_read_b128 indexed by the
 	// quadrant instead of ~20 VALU selects/negations.
 	__shared__ int64_t fold_tab[4][2];
+	// Per-sample vectors in a 64-bit container: the fold is a rotation by
+	// q * 90 degrees of the 32-bit port values scaled by 2^in_shl,
+	//     x0 = c*i_x - s*i_y,  y0 = s*i_x + c*i_y,  (c, s) in {0, +/-2^in_shl},
+	// i.e. FOUR v_mad_i64_i32 on the 32-bit inputs (sign extension, the left
+	// shift and the negations all inside the multiply) instead of ~25 64-bit
+	// mask / xor / subtract instructions; {c, s, -s} come from a 4-entry LDS
+	// table indexed by the quadrant.  Exact: every product fits 64 bits and
+	// the additions are the same two's-complement additions (in_shl <= 30).
+	constexpr bool kMadFold = !kConstXY && C::wide;
+	__shared__ int32_t rot_tab[4][4];
 	if constexpr (kConstXY) {
 		if (threadIdx.x < 4) {
 			const T ex = (T)((U)(T)kp.x0 << kp.in_shl);
@@ -548,6 +560,18 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			fold_octant<T>(ex, ey, (uint32_t)threadIdx.x << 30, fx, fy, fp);
 			fold_tab[threadIdx.x][0] = (int64_t)(Z)fx;
 			fold_tab[threadIdx.x][1] = (int64_t)(Z)fy;
+		}
+		__syncthreads();
+	} else if constexpr (kMadFold) {
+		if (threadIdx.x < 4) {
+			// q = 0: (x, y); 1: (-y, x); 2: (-x, -y); 3: (y, -x)
+			const int32_t k = (int32_t)(1u << (kp.in_shl & 31));
+			const int32_t c = (threadIdx.x == 0) ? k : (threadIdx.x == 2) ? -k : 0;
+			const int32_t sn = (threadIdx.x == 1) ? k : (threadIdx.x == 3) ? -k : 0;
+			rot_tab[threadIdx.x][0] = c;
+			rot_tab[threadIdx.x][1] = sn;
+			rot_tab[threadIdx.x][2] = -sn;
+			rot_tab[threadIdx.x][3] = 0;
 		}
 		__syncthreads();
 	}
@@ -608,6 +632,21 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 					reinterpret_cast<const char *>(&fold_tab[0][0]) + q16);
 				x[v] = e[0];
 				y[v] = e[1];
+				p[v] = (int64_t)((pb & 0x3fffffffu) - 0x20000000u);
+			} else if constexpr (kMadFold) {	// launcher: in_shl <= 30
+				const int32_t ix = sext32(tx[v], kp.iw);
+				const int32_t iy = sext32(ty[v], kp.iw);
+				const uint32_t pb = P[v] + 0x20000000u;
+				const uint32_t q16 = ((uint32_t)((int32_t)pb >> 26)) & 0x30u;
+				const i32x4 m = *reinterpret_cast<const i32x4 *>(
+					reinterpret_cast<const char *>(&rot_tab[0][0]) + q16);
+				int64_t fx = 0, fy = 0;
+				op_mad(fx, iy, m[2]);		// -s * i_y
+				op_mad(fx, ix, m[0]);		// + c * i_x
+				op_mad(fy, iy, m[0]);		//  c * i_y
+				op_mad(fy, ix, m[1]);		// + s * i_x
+				x[v] = fx;
+				y[v] = fy;
 				p[v] = (int64_t)((pb & 0x3fffffffu) - 0x20000000u);
 			} else {
 				const int32_t ix = sext32(tx[v], kp.iw);

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "cordic_device.h"
@@ -444,6 +445,7 @@ int grid_for(size_t work_items_per_block, size_t n, int blocks_per_cu = 8)
 		return -1;
 	const size_t blocks = (n + work_items_per_block - 1) / work_items_per_block;
 	const size_t cap = (size_t)cus * blocks_per_cu;	// resident blocks; the rest is grid-stride
+
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
@@ -517,9 +519,12 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		vec_ok = vec_ok && vec_aligned(j.phase);
 	if (FEED == Feed::PhaseArray_XYArray)
 		vec_ok = vec_ok && vec_aligned(j.x) && vec_aligned(j.y);
+	// (per-sample vectors in a 64-bit container are folded with 32-bit
+	// multipliers 2^in_shl: cordic_device.h kMadFold)
 	const bool fast_ok = vec_ok && !(cfg.flags & CORDIC_FLAG_FORCE_GENERIC)
 		&& (!cfg.needs_wrap || cfg.ww == 32 || cfg.ww == 64)
-		&& (!j.io16 || cfg.ww <= 32);
+		&& (!j.io16 || cfg.ww <= 32)
+		&& !(FEED == Feed::PhaseArray_XYArray && cfg.ww > 32 && kp.in_shl > 30);
 
 	if (fast_ok) {
 		const int grid = grid_for(kTile, j.n);
