@@ -40,6 +40,58 @@ def test_world_size_must_equal_gpus():
     assert r.stdout.strip() == ""
 
 
+def test_launch_decisions_and_respawn_command(monkeypatch):
+    """The N > 1 launch logic without GPUs: with N GPUs visible a plain
+    `--gpus N` becomes `python -m torch.distributed.run --nproc-per-node N
+    ... bench.py --gpus N ...` (one rank per GPU, 127.0.0.1 rendezvous), a
+    torchrun-started rank is accepted only if WORLD_SIZE == N, and
+    --single-process stays in this process."""
+    import argparse
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+
+    def ns(**kw):
+        d = dict(gpus=1, single_process=False, spawn=False)
+        d.update(kw)
+        return argparse.Namespace(**d)
+    assert bench.resolve_launch(ns(gpus=1)) == "direct"
+    assert bench.resolve_launch(ns(gpus=1, spawn=True)) == "spawn"
+    assert bench.resolve_launch(ns(gpus=8)) == "spawn"
+    assert bench.resolve_launch(ns(gpus=8, single_process=True)) == "single-process"
+    with pytest.raises(SystemExit, match="needs 9 visible GPUs, found 8"):
+        bench.resolve_launch(ns(gpus=9))
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert bench.resolve_launch(ns(gpus=8)) == "torchrun"
+    with pytest.raises(SystemExit, match="--gpus 4 but WORLD_SIZE=8"):
+        bench.resolve_launch(ns(gpus=4))
+    monkeypatch.delenv("RANK")
+    monkeypatch.delenv("WORLD_SIZE")
+
+    seen = {}
+
+    def fake_exec(prog, argv, env):
+        seen.update(prog=prog, argv=argv, env=env)
+        raise RuntimeError("exec")
+    monkeypatch.setattr(bench.os, "execvpe", fake_exec)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20",
+                                      "--warmup", "5", "--spawn"])
+    with pytest.raises(RuntimeError, match="exec"):
+        bench.respawn(ns(gpus=8))
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in a and a[a.index("--nproc-per-node") + 1] == "8"
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1"
+    tail = a[a.index(os.path.abspath(BENCH)) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "20", "--warmup", "5"]   # --spawn dropped
+    assert seen["env"]["BENCH_SELF_SPAWNED"] == "1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 def _line(stdout):
     rows = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     assert len(rows) == 1, stdout
