@@ -286,9 +286,14 @@ __device__ __forceinline__ void left_justify(const u32x4 in, uint32_t (&P)[4],
 }
 
 // (a & c) | b  and  (a & c) ^ b  as one v_bitop3_b32 each (truth tables with
-// src0 = 0xF0, src1 = 0xCC, src2 = 0xAA): two instructions at 3.3 cycles
-// instead of and + or + xor.  Constants live in VGPRs (VOP3 takes no literal
-// and at most one SGPR on gfx950).
+// src0 = 0xF0, src1 = 0xCC, src2 = 0xAA) instead of and + or + xor.  Constants
+// live in VGPRs (VOP3 takes no literal and at most one SGPR on gfx950).
+// Inline asm although __builtin_amdgcn_bitop3_b32 exists: hipcc pads every
+// instruction that depends on an asm-defined VGPR with an s_nop (74 per pass in
+// topolar_lj), yet the asm form keeps the stage-major order written here and
+// measured 3-7 % FASTER than the builtin, which the scheduler rearranges
+// (same-box A/B, profiles/r02/ab_bitop3_builtin.txt; a scheduling fence after
+// every stage on top of the asm form: 0.5-1 % slower again).
 __device__ __forceinline__ uint32_t op_and_or(uint32_t a, uint32_t b, uint32_t c)
 {
 	uint32_t d;
@@ -1184,79 +1189,57 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 
 // ------------------------------------- converter, left-justified fast form
 //
-// topolar_unrolled spends 8 VALU instructions per micro-rotation, three of
-// them the half-rate v_mad_i64_i32 (x, y, phase).  For cores whose registers
-// cannot overflow and fit 32 bits (WW <= 32, cfg.needs_wrap == 0) this form
-// needs 7, only two of them half-rate (profiles/isa/topolar_lj.txt):
+// topolar_unrolled spends 8 VALU instructions per micro-rotation (sign mask,
+// |1, ^-2, two shifts, three multiply-adds).  For cores whose registers cannot
+// overflow and fit 32 bits (WW <= 32, cfg.needs_wrap == 0) this form needs 7:
+// x, y are carried LEFT-justified by 30 bits in their register pairs
+// (x~ = x << 30) from stage 2 on, so that (y >>> k) is an arithmetic shift of
+// the HIGH word by k-2 and the multipliers +/-2^30 come straight off the sign
+// bit of that word -- t~ = (yh & 2^31) | 2^30 as one v_bitop3_b32 with its
+// constants in VGPRs, -t~ = t~ ^ 2^31 as one VOP2 xor -- and the phase is
+// accumulated at the same scale, p~ += t~ * a_k, to be shifted back once at
+// the end.
 //
-//  * x, y are carried LEFT-justified by 30 bits in their register pairs
-//    (x~ = x << 30) from stage 2 on.  (y >>> k) then is an arithmetic shift of
-//    the HIGH word by k-2 and the multipliers are +/-2^30, read straight off
-//    the sign bit of that word:  t~ = (yh & 2^31) | 2^30,  -t~ = (yh & 2^31) ^
-//    (2^31 | 2^30): two full-rate v_bitop3_b32 (2^30 and 2^31|2^30 are the
-//    inline constants 2.0 and -2.0) instead of shift + or + xor.
-//  * the phase is not accumulated per stage.  After the quadrant fold the
-//    vector lies within +/-45 degrees and every stage at least halves the bound
-//    on |y| / x  (|angle| <= atan 2^-(k-1) before stage k), so before stage k
-//    |y| < 2^(32-k) + k: in the high word yh = y >> 2 every bit from 32-k
-//    upwards is a copy of the sign (k <= 24 leaves two spare bits however the
-//    truncations fall).  One more full-rate v_bitop3_b32 per stage,
-//    D |= yh & 2^(32-k), collects the direction bits in D, and
-//        o_phase = p0 + sum_k (D_k ? -a_k : +a_k)
-//    comes out of three 1024-entry tables in LDS indexed by ten direction bits
-//    each (built per block from the core's arctan table): 3 ds_read_b32 and a
-//    few adds per sample replace NLIVE multiply-adds.
+// What decides the speed here is the instruction COUNT: in this mix the chip
+// issues every VALU instruction, full-rate opcode or not, in ~3.65 cycles per
+// SIMD (tools/stage_microbench.hip, profiles/r02/stage_microbench.txt); a
+// v_bitop3_b32 with an SGPR or inline-constant operand costs ~0.4 more.  The
+// first version of this kernel replaced the phase multiply-add by a
+// direction-bit collect (one more v_bitop3_b32 with an SGPR mask) plus LDS
+// tables for the phase: same count per stage, slower per instruction, and a
+// ~12-instruction lookup at the end -- measured 11 % slower per stage.
 //
 // rtl/topolar.v:122-152 (fold), :217-243 (stages), :251-271 (outputs): same
 // values as topolar_unrolled, bit for bit.
-constexpr int kPolLjMaxStages = 24;	// bound of the sign-copy argument above
-constexpr int kPolLjGroup = 10;		// direction bits per phase table
-
-__device__ __forceinline__ uint32_t op_sign_or(uint32_t a, uint32_t smask)
-{	// (a & 2^31) | 2^30
-	uint32_t d;
-	asm("v_bitop3_b32 %0, %1, 2.0, %2 bitop3:0xec" : "=v"(d) : "v"(a), "s"(smask));
-	return d;
-}
-__device__ __forceinline__ uint32_t op_sign_xor(uint32_t a, uint32_t smask)
-{	// (a & 2^31) ^ (2^31 | 2^30)
-	uint32_t d;
-	asm("v_bitop3_b32 %0, %1, -2.0, %2 bitop3:0x6c" : "=v"(d) : "v"(a), "s"(smask));
-	return d;
-}
-__device__ __forceinline__ uint32_t op_collect(uint32_t a, uint32_t acc, uint32_t bit)
-{	// acc | (a & bit), bit wave-uniform
-	uint32_t d;
-	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xec" : "=v"(d) : "v"(a), "v"(acc), "s"(bit));
-	return d;
-}
+struct PolLjRegs { uint32_t sign, p30; };	// 2^31, 2^30 in VGPRs
 
 template <int K>
-__device__ __forceinline__ void pol_stage_lj(int64_t &x, int64_t &y, uint32_t &dirs,
-		uint32_t smask)
+__device__ __forceinline__ void pol_stage_lj(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a, const PolLjRegs &c)
 {
-	static_assert(K >= 2 && K <= kPolLjMaxStages, "stage outside the fast form");
+	static_assert(K >= 2, "stage 1 runs on the 32-bit values");
+	constexpr int sh = (K - 2 > 31) ? 31 : K - 2;
 	const uint32_t yh = (uint32_t)((uint64_t)y >> 32);
-	const int32_t t = (int32_t)op_sign_or(yh, smask);	// +/- 2^30
-	const int32_t nt = (int32_t)op_sign_xor(yh, smask);	// -t
-	const int32_t sy = (int32_t)yh >> (K - 2);
-	const int32_t sx = (int32_t)((uint64_t)x >> 32) >> (K - 2);
-	dirs = op_collect(yh, dirs, 1u << (32 - K));
+	const int32_t t = (int32_t)op_and_or(yh, c.p30, c.sign);	// +/- 2^30
+	const int32_t nt = (int32_t)((uint32_t)t ^ c.sign);		// -t
+	const int32_t sy = (int32_t)yh >> sh;
+	const int32_t sx = (int32_t)((uint64_t)x >> 32) >> sh;
 	op_mad(x, sy, t);		// x' = x + t * (y >>> k)
 	op_mad(y, sx, nt);		// y' = y - t * (x >>> k)
+	op_mad_s(p, a, t);		// p' = p + t * a_k
 }
 
 template <int NLIVE, int I, bool DYN> struct PolChainLJ {
 	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
-			int64_t (&y)[kVec], uint32_t (&dirs)[kVec], uint32_t smask,
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const PolLjRegs &c,
 			const CoreParams &kp)
 	{
 		if constexpr (I < NLIVE) {
 			if (!DYN || I < kp.nlive) {
 #pragma unroll
 				for (int v = 0; v < kVec; v++)
-					pol_stage_lj<I + 1>(x[v], y[v], dirs[v], smask);
-				PolChainLJ<NLIVE, I + 1, DYN>::run(x, y, dirs, smask, kp);
+					pol_stage_lj<I + 1>(x[v], y[v], p[v], kp.angle[I], c);
+				PolChainLJ<NLIVE, I + 1, DYN>::run(x, y, p, c, kp);
 			}
 		}
 	}
@@ -1269,25 +1252,9 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 		typename IO::ivec *__restrict__ omag,
 		typename IO::uvec *__restrict__ oph, size_t nvec)
 {
-	static_assert(NLIVE >= 2 && NLIVE <= kPolLjMaxStages, "see kPolLjMaxStages");
-	constexpr int kGroups = (NLIVE + kPolLjGroup - 1) / kPolLjGroup;
-	// phase tables: entry idx of group g = sum over the group's stages of
-	// -a (direction bit set: y was negative, rtl/topolar.v:226-234) or +a
-	__shared__ uint32_t ptab[kGroups][1 << kPolLjGroup];
-	for (int e = threadIdx.x; e < kGroups << kPolLjGroup; e += kBlock) {
-		const int g = e >> kPolLjGroup, idx = e & ((1 << kPolLjGroup) - 1);
-		uint32_t acc = 0;
-		for (int j = 0; j < kPolLjGroup; j++) {
-			const int stage = g * kPolLjGroup + j;	// 0-based
-			if (stage < kp.nlive) {
-				const uint32_t a = kp.angle[stage];
-				acc += ((idx >> (kPolLjGroup - 1 - j)) & 1) ? 0u - a : a;
-			}
-		}
-		ptab[g][idx] = acc;
-	}
-	__syncthreads();
-	const uint32_t smask = 0x80000000u;
+	PolLjRegs c;
+	c.sign = vgpr_const(0x80000000u);
+	c.p30 = vgpr_const(0x40000000u);
 
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1303,8 +1270,8 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 			nx = xin[gn];
 			ny = yin[gn];
 		}
-		int64_t x[kVec], y[kVec];
-		uint32_t dirs[kVec], p0[kVec];
+		int64_t x[kVec], y[kVec], p[kVec];
+		uint32_t p1[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			const int32_t ix = sext32(tx[v], kp.iw);
@@ -1312,30 +1279,29 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 			const int32_t ex = (int32_t)((uint32_t)ix << kp.in_shl);
 			const int32_t ey = (int32_t)((uint32_t)iy << kp.in_shl);
 			int32_t fx, fy;
-			fold_quadrant_masks<int32_t>(ex, ey, ix, iy, fx, fy, p0[v]);
+			uint32_t p0;
+			fold_quadrant_masks<int32_t>(ex, ey, ix, iy, fx, fy, p0);
 			// stage 1 (shift 1) on the 32-bit values, rtl/topolar.v:226-243
-			const int32_t d = fy >> 31;
+			const uint32_t d = (uint32_t)(fy >> 31);
 			const int32_t sy = fy >> 1, sx = fx >> 1;
-			const int32_t x1 = fx + ((sy ^ d) - d);	// x + t * sy
-			const int32_t y1 = fy - ((sx ^ d) - d);	// y - t * sx
-			dirs[v] = (uint32_t)d & 0x80000000u;
+			const int32_t x1 = fx + (int32_t)(((uint32_t)sy ^ d) - d);	// x + t*sy
+			const int32_t y1 = fy - (int32_t)(((uint32_t)sx ^ d) - d);	// y - t*sx
+			p1[v] = kp.nlive > 0 ? p0 + ((kp.angle[0] ^ d) - d) : p0;	// p + t*a_0
 			x[v] = (int64_t)((uint64_t)(int64_t)x1 << 30);
 			y[v] = (int64_t)((uint64_t)(int64_t)y1 << 30);
+			p[v] = 0;
 		}
 
-		PolChainLJ<NLIVE, 1, DYN>::run(x, y, dirs, smask, kp);
+		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp);
 
 		i32x4 rm;
 		u32x4 rp;
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			rm[v] = round_to_ow<int32_t>((int32_t)(x[v] >> 30), kp);
-			uint32_t p = p0[v] + ptab[0][dirs[v] >> 22];
-			if constexpr (kGroups > 1)
-				p += ptab[1][(dirs[v] >> 12) & 1023u];
-			if constexpr (kGroups > 2)
-				p += ptab[2][(dirs[v] >> 2) & 1023u];
-			rp[v] = p >> kp.pw_shl;			// rtl/topolar.v:269
+			// sum of t*a_k over the stages 2.., accumulated at 2^30
+			const uint32_t acc = (uint32_t)((uint64_t)p[v] >> 30);
+			rp[v] = (p1[v] + acc) >> kp.pw_shl;	// rtl/topolar.v:269
 		}
 		apply_unit_gain<UG>(rm, kp);
 		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));

@@ -1,6 +1,6 @@
 // cordic_inst_pol_lj.hip -- instances of the left-justified converter
 // (cordic_device.h: topolar_lj): r2p / sr2p cores with WW <= 32 whose registers
-// cannot overflow and at most kPolLjMaxStages rotations.
+// cannot overflow.
 #include <hip/hip_runtime.h>
 
 #include "cordic_device.h"
@@ -13,10 +13,10 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 		size_t n)
 {
 	using namespace dev;
-	if (nlive < 2 || nlive > kPolLjMaxStages)
+	if (nlive < 1 || nlive > kDynStages)
 		return false;
 	if (kp.post_mul != 0) {		// CORDIC_FLAG_UNIT_GAIN: dynamic-exit instance
-		hipLaunchKernelGGL((topolar_lj<kPolLjMaxStages, true, Io32, true>),
+		hipLaunchKernelGGL((topolar_lj<kDynStages, true, Io32, true>),
 			dim3(grid), dim3(kBlock), 0, st, kp, (const i32x4 *)x,
 			(const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, n / kVec);
 		return true;
@@ -27,10 +27,10 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 		(const i32x4 *)x, (const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, \
 		n / kVec); \
 	return true;
-	X(16) X(18) X(20) X(24)
+	CORDIC_POL_STAGES(X)
 #undef X
 	default:
-		hipLaunchKernelGGL((topolar_lj<kPolLjMaxStages, true>), dim3(grid),
+		hipLaunchKernelGGL((topolar_lj<kDynStages, true>), dim3(grid),
 			dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y,
 			(i32x4 *)mag, (u32x4 *)ph, n / kVec);
 		return true;

@@ -669,7 +669,7 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 						mag, phase, n);
 			else if (cfg.ww <= 32 && !cfg.needs_wrap
 					&& !(cfg.flags & CORDIC_FLAG_NO_LJ)
-					&& cfg.nlive >= 2 && cfg.nlive <= kPolLjMaxStages)
+					&& cfg.nlive >= 1)
 				done = launch_pol_lj(cfg.nlive, grid, st, kp, x, y, mag,
 						phase, n);
 			else if (cfg.ww <= 32)

@@ -43,8 +43,8 @@ CORDIC_SEED_LAUNCHER(launch_seed_narrow);	// WW <= 32
 CORDIC_SEED_LAUNCHER(launch_seed_lj29);		// WW == 35
 CORDIC_SEED_LAUNCHER(launch_seed_lj30);		// WW == 33, 34
 CORDIC_POL_LAUNCHER(launch_pol_narrow);
-// WW <= 32, no reachable overflow, 2..24 rotations: left-justified form with
-// the phase rebuilt from direction bits (cordic_device.h: topolar_lj)
+// WW <= 32, no reachable overflow: left-justified form, 7 instructions per
+// micro-rotation (cordic_device.h: topolar_lj)
 CORDIC_POL_LAUNCHER(launch_pol_lj);
 CORDIC_POL_LAUNCHER(launch_pol_wide8);
 CORDIC_POL_LAUNCHER(launch_pol_wideall);

@@ -37,7 +37,7 @@ KERNELS = [
      "cfg3 r2p, round-1 form (8 instructions per micro-rotation)"),
     ("topolar_lj_20", "cordic_inst_pol_lj.o",
      r"topolar_lj<20, false, cordic_amd::dev::Io32, false>",
-     "cfg3 r2p, left-justified form (7 per micro-rotation, 2 half-rate)"),
+     "cfg3 r2p, left-justified form (7 instructions per micro-rotation)"),
 ]
 
 
