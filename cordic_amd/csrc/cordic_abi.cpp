@@ -610,7 +610,7 @@ void cordic_seq_destroy(cordic_seq *s)
 		return;
 	SeqState &t = s->st;
 	void *ptrs[] = { t.c, t.px, t.py, t.pph, t.paux, t.l0, t.l1, t.la,
-			 t.violations, t.ws };
+			 t.violations, t.ws, t.lit };
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	delete s;
@@ -633,10 +633,17 @@ int cordic_seq_create(const cordic_config *cfg, cordic_seq **out)
 		return hipMalloc((void **)p, bytes) == hipSuccess
 			&& hipMemset(*p, 0, bytes) == hipSuccess;
 	};
-	const bool ok = zalloc(&t.violations, 8) && zalloc(&t.c, 4)
+	bool ok = zalloc(&t.violations, 8) && zalloc(&t.c, 4)
 		&& zalloc(&t.px, 4) && zalloc(&t.py, 4) && zalloc(&t.pph, 4)
 		&& zalloc(&t.paux, 4) && zalloc(&t.l0, 4) && zalloc(&t.l1, 4)
 		&& zalloc(&t.la, 4);
+	// register-level state for off-protocol stretches: power-on registers
+	// and the padded arctan table
+	std::vector<unsigned char> image(seq_literal_bytes());
+	seq_literal_init(*cfg, image.data());
+	ok = ok && hipMalloc(&t.lit, image.size()) == hipSuccess
+		&& hipMemcpy(t.lit, image.data(), image.size(),
+				hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
 		cordic_seq_destroy(s);
 		return CORDIC_ERR_DEVICE;

@@ -132,7 +132,14 @@ struct SeqState {
 	int32_t	 *l0 = nullptr, *l1 = nullptr;
 	uint8_t	 *la = nullptr;
 	unsigned long long *violations = nullptr;
+	// register-level state for off-protocol stretches (cordic_stream.hip:
+	// SeqLit): the core's whole register file, the padded arctan table, a
+	// snapshot of the fields above taken at the start of every block
+	void	*lit = nullptr;
 };
+size_t	seq_literal_bytes();
+// fills the host image of a fresh SeqLit (power-on registers, padded table)
+void	seq_literal_init(const cordic_config &cfg, void *host_image);
 size_t	seq_workspace_bytes(size_t ticks);
 int	launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 		const uint8_t *stb, const uint8_t *reset, const uint8_t *aux,

@@ -31,6 +31,8 @@
 // kernel of the core, run on the gathered samples.
 #include <hip/hip_runtime.h>
 
+#include <new>
+
 #include <cstdint>
 
 #include "cordic_device.h"
@@ -622,7 +624,7 @@ __device__ __forceinline__ void store16(uint8_t *p, uint32_t t, uint32_t hi,
 __global__ __launch_bounds__(64) void seq_fsm_emit(const uint8_t *stb,
 		const uint8_t *rst, uint32_t T, uint32_t C, const uint8_t *entry,
 		uint32_t ntiles, uint8_t *accept, uint8_t *load, uint8_t *busy,
-		uint8_t *done, unsigned long long *violations)
+		uint8_t *done, uint32_t *violations)
 {
 	const uint32_t tile = blockIdx.x * 64 + threadIdx.x;
 	if (tile >= ntiles)
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(64) void seq_fsm_emit(const uint8_t *stb,
 		store16(done, t, hi, vd, wd);
 	}
 	if (viol)
-		atomicAdd(violations, (unsigned long long)viol);
+		atomicAdd(violations, viol);	// of this block: arms seq_literal
 }
 
 struct SeqView {
@@ -734,7 +736,239 @@ __global__ void seq_carry(SeqView v, const int32_t *o0, const int32_t *o1,
 	*nl0 = a; *nl1 = b; *nla = c;
 }
 
+
+// ------------------------------------------- off protocol: register level
+//
+// The passes above reproduce the handshake for every input stream that keeps to
+// the protocol.  One thing a bench can do that they cannot express: strobe on
+// the very clock that completes a sample.  rtl/seqcordic.v:229-236 /
+// rtl/seqpolar.v:215-221 give i_stb precedence over the return to idle, yet
+// pre_valid (:243-246) needs idle, so NO sample is loaded: the datapath, which
+// rotates on every clock (:270-291 / :259-281), goes round again over its own
+// unrounded result with state counting from 0, and a second o_done appears C-1
+// clocks later with a value that is a function of the core's registers, not of
+// any input.  A bench that holds i_stb high sees exactly that, forever.
+//
+// Such stretches are reproduced by stepping the core's register file clock by
+// clock -- one thread, the literal next-state functions of the RTL.  The block
+// passes run as always; seq_fsm_emit counts the off-protocol strobes of the
+// block, and if there is one (or the previous block ended inside a re-run) the
+// whole block is re-done at register level from the state the block started
+// in, every output array overwritten.  Slow (~10^7 clocks/s) and exact.
+struct SeqRegs {
+	int64_t	prex, prey, xv, yv;	// rtl/seqcordic.v:88-92
+	uint32_t preph, ph, cangle, state;
+	int32_t	idle, pre_valid, aux, o_done, o_aux, o0, o1;
+};
+
+struct SeqLit {
+	SeqRegs	regs;
+	uint32_t literal;	// regs are authoritative: a re-run is in flight
+	uint32_t viol_block;	// off-protocol strobes the block passes saw
+	// fast-path state at the start of the block (the passes update it in place)
+	uint32_t snap_c;
+	int32_t	snap_px, snap_py;
+	uint32_t snap_pph, snap_paux;
+	int32_t	snap_l0, snap_l1;
+	uint32_t snap_la;
+	uint32_t table[128];	// cordic_angle[], padded as the emitter pads it
+};
+
+struct SeqModel {
+	int32_t	rot, ww, pw, iw, ow, in_shl;
+	uint32_t pm, smask, tmask, last, C;
+};
+
+__device__ __forceinline__ int64_t seq_wrap(int64_t v, int ww)
+{
+	return sext64(v, ww);
+}
+__device__ __forceinline__ int64_t seq_asr(int64_t v, uint32_t sh)
+{
+	return v >> (sh > 63u ? 63u : sh);
+}
+
+// rtl/seqcordic.v:124-182 / rtl/seqpolar.v:100-120: the pre-rotation registers
+__device__ void seq_prerotate(const SeqModel &m, int32_t ix, int32_t iy, uint32_t iph,
+		int64_t &px, int64_t &py, uint32_t &pp)
+{
+	const int64_t sx = sext32(ix, m.iw), sy = sext32(iy, m.iw);
+	const int64_t ex = seq_wrap((int64_t)((uint64_t)sx << m.in_shl), m.ww);
+	const int64_t ey = seq_wrap((int64_t)((uint64_t)sy << m.in_shl), m.ww);
+	if (m.rot) {
+		const uint32_t ph = iph & m.pm, q = 1u << (m.pw - 2);
+		switch ((ph >> (m.pw - 3)) & 7u) {
+		case 0: case 7: px = ex; py = ey; pp = ph; break;
+		case 1: case 2: px = seq_wrap(-ey, m.ww); py = ex; pp = (ph - q) & m.pm; break;
+		case 3: case 4: px = seq_wrap(-ex, m.ww); py = seq_wrap(-ey, m.ww);
+				pp = (ph - 2 * q) & m.pm; break;
+		default:	px = ey; py = seq_wrap(-ex, m.ww); pp = (ph - 3 * q) & m.pm; break;
+		}
+	} else {
+		const uint32_t e = 1u << (m.pw - 3);
+		switch ((sx < 0 ? 2 : 0) | (sy < 0 ? 1 : 0)) {
+		case 1:  px = seq_wrap(ex - ey, m.ww); py = seq_wrap(ex + ey, m.ww); pp = 7 * e; break;
+		case 2:  px = seq_wrap(-ex + ey, m.ww); py = seq_wrap(-ex - ey, m.ww); pp = 3 * e; break;
+		case 3:  px = seq_wrap(-ex - ey, m.ww); py = seq_wrap(ex - ey, m.ww); pp = 5 * e; break;
+		default: px = seq_wrap(ex + ey, m.ww); py = seq_wrap(-ex + ey, m.ww); pp = e; break;
+		}
+		pp &= m.pm;
+	}
+}
+
+// rtl/seqcordic.v:298-303 (convergent rounding) or plain truncation
+__device__ int32_t seq_round(const SeqModel &m, int64_t v)
+{
+	const int r = m.ww - m.ow;
+	if (m.ww > m.ow + 1) {
+		const int64_t b = (v >> r) & 1;
+		const int64_t add = (b << (r - 1)) | (b ? 0 : (((int64_t)1 << (r - 1)) - 1));
+		v = seq_wrap(v + add, m.ww);
+	}
+	return (int32_t)sext64(v >> r, m.ow);
+}
+
+// one rising clock edge: every register from its pre-edge value
+__device__ void seq_clock(const SeqModel &m, const uint32_t *table, SeqRegs &r,
+		bool stb, bool rst, bool aux, int32_t ix, int32_t iy, uint32_t iph)
+{
+	const bool at_last = r.state >= m.last;			// :318 / :208
+	const bool leave = m.rot ? (r.state == m.last) : at_last;	// :235,257 / :218,236
+	SeqRegs n = r;
+	seq_prerotate(m, ix, iy, iph, n.prex, n.prey, n.preph);
+	if (rst) n.aux = 0;						// :100-105
+	else if (stb && r.idle) n.aux = aux;
+	if (rst) n.idle = 1;						// :226-236
+	else if (stb) n.idle = 0;
+	else if (leave) n.idle = 1;
+	n.pre_valid = rst ? 0 : (stb && r.idle);			// :240-246
+	if (rst || r.idle || leave) n.state = 0;			// :252-262
+	else n.state = (r.state + 1) & m.smask;
+	n.cangle = table[r.state & m.tmask];				// :248-250
+	if (r.pre_valid) {						// :270-291
+		n.xv = r.prex; n.yv = r.prey; n.ph = r.preph;
+	} else {
+		const int64_t dy = seq_asr(r.yv, r.state), dx = seq_asr(r.xv, r.state);
+		const bool minus = m.rot ? ((r.ph >> (m.pw - 1)) & 1u) != 0 : r.yv < 0;
+		if ((m.rot != 0) == minus) {
+			// p2r with negative phase, or r2p above the axis
+			n.xv = seq_wrap(r.xv + dy, m.ww);
+			n.yv = seq_wrap(r.yv - dx, m.ww);
+			n.ph = (r.ph + r.cangle) & m.pm;
+		} else {
+			n.xv = seq_wrap(r.xv - dy, m.ww);
+			n.yv = seq_wrap(r.yv + dx, m.ww);
+			n.ph = (r.ph - r.cangle) & m.pm;
+		}
+	}
+	n.o_done = rst ? 0 : (at_last ? 1 : 0);			// :308-314
+	if (at_last) {							// :316-324
+		n.o0 = seq_round(m, r.xv);
+		n.o1 = m.rot ? seq_round(m, r.yv) : (int32_t)r.ph;
+		n.o_aux = r.aux;
+	}
+	r = n;
+}
+
+__global__ void seq_snapshot(SeqLit *lit, const uint32_t *c, const int32_t *px,
+		const int32_t *py, const uint32_t *pph, const uint8_t *paux,
+		const int32_t *l0, const int32_t *l1, const uint8_t *la)
+{
+	lit->viol_block = 0;
+	lit->snap_c = *c;
+	lit->snap_px = *px; lit->snap_py = *py; lit->snap_pph = *pph;
+	lit->snap_paux = *paux;
+	lit->snap_l0 = *l0; lit->snap_l1 = *l1; lit->snap_la = *la;
+}
+
+__global__ void seq_literal(SeqModel m, SeqLit *lit, uint32_t T, const uint8_t *stb,
+		const uint8_t *rst, const uint8_t *aux, const int32_t *x,
+		const int32_t *y, const uint32_t *phase, int32_t *o0, int32_t *o1,
+		uint8_t *oaux, uint8_t *busy, uint8_t *done, uint32_t *c_out,
+		int32_t *px, int32_t *py, uint32_t *pph, uint8_t *paux, int32_t *l0,
+		int32_t *l1, uint8_t *la, unsigned long long *violations)
+{
+	if (!lit->literal && lit->viol_block == 0)
+		return;				// the block kept to the protocol
+	SeqRegs r;
+	uint32_t c;				// the block passes' view, kept alongside
+	int32_t sx, sy;				// sample of the run in flight
+	uint32_t sph, sax;
+	bool rerun;				// that run was started by a re-run
+	if (lit->literal) {
+		r = lit->regs;
+		c = lit->snap_c;
+		sx = lit->snap_px; sy = lit->snap_py; sph = lit->snap_pph;
+		sax = lit->snap_paux;
+		rerun = true;
+	} else {
+		// registers of the state the block passes carry: idle, or a sample
+		// accepted C-1-c clocks ago
+		r = SeqRegs{};
+		r.idle = 1;
+		r.cangle = lit->table[0];
+		r.o0 = lit->snap_l0; r.o1 = lit->snap_l1; r.o_aux = (int32_t)lit->snap_la;
+		c = lit->snap_c;
+		sx = lit->snap_px; sy = lit->snap_py; sph = lit->snap_pph;
+		sax = lit->snap_paux;
+		rerun = false;
+		if (c != 0) {
+			seq_clock(m, lit->table, r, true, false, sax != 0, sx, sy, sph);
+			for (uint32_t k = 0; k < m.C - 1 - c; k++)
+				seq_clock(m, lit->table, r, false, false, false, sx, sy, sph);
+		}
+	}
+	unsigned long long viol = 0;
+	for (uint32_t t = 0; t < T; t++) {
+		const bool s_ = stb[t] != 0, rs = rst && rst[t] != 0;
+		const bool ax = aux && aux[t] != 0;
+		const uint32_t ph = phase ? phase[t] : 0u;
+		const bool completing = !r.idle && r.state >= m.last;
+		// the handshake as the block passes count it (fsm_step), with the
+		// re-run: a strobe on the completing clock restarts the count
+		if (rs) {
+			c = 0; rerun = false;
+		} else if (c == 0) {
+			if (s_) {
+				c = m.C - 1; rerun = false;
+				sx = x[t]; sy = y[t]; sph = ph; sax = ax;
+			}
+		} else if (completing && s_) {
+			c = m.C - 1; rerun = true; viol++;
+		} else {
+			c -= 1;
+			if (c == 0) rerun = false;
+		}
+		seq_clock(m, lit->table, r, s_, rs, ax, x[t], y[t], ph);
+		o0[t] = r.o0;
+		o1[t] = r.o1;
+		if (oaux) oaux[t] = (uint8_t)r.o_aux;
+		if (busy) busy[t] = (uint8_t)(r.idle ? 0 : 1);
+		if (done) done[t] = (uint8_t)r.o_done;
+	}
+	lit->regs = r;
+	lit->literal = (rerun && c != 0) ? 1u : 0u;
+	*c_out = c;
+	*px = sx; *py = sy; *pph = sph; *paux = (uint8_t)sax;
+	*l0 = r.o0; *l1 = r.o1; *la = (uint8_t)r.o_aux;
+	*violations += viol;
+}
+
 } // namespace
+
+size_t seq_literal_bytes() { return sizeof(SeqLit); }
+
+void seq_literal_init(const cordic_config &cfg, void *host_image)
+{
+	SeqLit *l = new (host_image) SeqLit{};
+	l->regs.idle = 1;
+	// sw/cordiclib.cpp:145-149: the sequential cores' table has
+	// 2^nextlg(NSTAGES) entries, all of them computed by the formula
+	const unsigned tlen = 1u << next_lg((unsigned)cfg.nstages);
+	for (unsigned k = 0; k < tlen && k < 128; k++)
+		l->table[k] = arctan_entry(k, cfg.pw);
+	l->regs.cangle = l->table[0];
+}
 
 size_t seq_workspace_bytes(size_t T)
 {
@@ -793,13 +1027,16 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 	int32_t *tile_last = reinterpret_cast<int32_t *>(take((size_t)stiles * 4));
 	uint8_t *oa = oaux ? oaux : aux_ws;
 
+	SeqLit *lit = static_cast<SeqLit *>(s.lit);
+	hipLaunchKernelGGL(seq_snapshot, dim3(1), dim3(1), 0, st, lit, s.c, s.px,
+			s.py, s.pph, s.paux, s.l0, s.l1, s.la);
 	hipLaunchKernelGGL(seq_fsm_tables, dim3(ntiles), dim3(128), 0, st, stb,
 			reset, n, C, gtab);
 	hipLaunchKernelGGL(seq_fsm_spine, dim3(1), dim3(64), 0, st, gtab, ntiles,
 			s.c, entry, s.c);			// in place
 	hipLaunchKernelGGL(seq_fsm_emit, dim3((ntiles + 63) / 64), dim3(64), 0, st,
 			stb, reset, n, C, entry, ntiles, accept, load, busy, done,
-			s.violations);
+			&lit->viol_block);
 	TickFlags f{accept, load};	// "advancing" = accept, "reset" = load
 	hipLaunchKernelGGL(stream_tile_totals, dim3(stiles), dim3(kScanThreads), 0,
 			st, f, n, tile_adv, tile_last);
@@ -829,6 +1066,20 @@ int launch_seq_ticks(const cordic_config &cfg, SeqState &s, size_t T,
 			held, s.l0, s.l1, s.la, o0, o1, oa);
 	hipLaunchKernelGGL(seq_carry, dim3(1), dim3(1), 0, st, v, o0, o1, oa, s.px,
 			s.py, s.pph, s.paux, s.l0, s.l1, s.la);	// in place
+	// off-protocol strobes in this block (or a re-run still in flight from the
+	// last one): redo the block at register level, else return at once
+	SeqModel m{};
+	m.rot = rot ? 1 : 0;
+	m.ww = cfg.ww; m.pw = cfg.pw; m.iw = cfg.iw; m.ow = cfg.ow;
+	m.in_shl = rot ? cfg.ww - cfg.iw - 1 : cfg.ww - cfg.iw - 2;
+	m.pm = (cfg.pw >= 32) ? 0xffffffffu : ((1u << cfg.pw) - 1u);
+	m.smask = (1u << next_lg((unsigned)(rot ? cfg.nstages : cfg.nstages + 1))) - 1u;
+	m.tmask = (1u << next_lg((unsigned)cfg.nstages)) - 1u;
+	m.last = (uint32_t)(rot ? cfg.nstages - 1 : cfg.nstages + 1);
+	m.C = C;
+	hipLaunchKernelGGL(seq_literal, dim3(1), dim3(1), 0, st, m, lit, n, stb, reset,
+			aux, x, y, rot ? phase : nullptr, o0, o1, oaux, busy, done, s.c,
+			s.px, s.py, s.pph, s.paux, s.l0, s.l1, s.la, s.violations);
 	return (hipGetLastError() == hipSuccess) ? CORDIC_OK : CORDIC_ERR_DEVICE;
 }
 

@@ -430,8 +430,15 @@ int	cordic_stream_ticks(cordic_stream *s, size_t ticks,
  * only) and o_xval/o_yval (o_mag/o_phase) and o_aux load; i_reset drops a
  * sample in flight and clears o_done, the output registers keep their values.
  * i_stb while busy is ignored, as in the RTL -- except on the very clock that
- * completes a sample, where the RTL re-runs its datapath over its own result:
- * such clocks are counted (cordic_seq_violations) and treated as ignored.
+ * completes a sample: there the RTL gives i_stb precedence over the return to
+ * idle but loads nothing (pre_valid needs idle), so its free-running datapath
+ * goes round again over its own unrounded result and a second o_done appears
+ * C-1 clocks later (rtl/seqcordic.v:229-246,270-291).  That is reproduced too,
+ * bit for bit, for any strobe pattern (a bench that simply holds i_stb high
+ * included): blocks that contain such a strobe are re-done by a register-level
+ * pass (one thread stepping the core's register file: exact, ~10^7 clocks/s
+ * instead of ~10^10), and the register file carries over when a re-run spans
+ * calls.  cordic_seq_violations counts those strobes.
  *   d_stb : one byte per clock (required); d_reset, d_aux, d_busy, d_done,
  *   d_oaux may be NULL.  p2r: d_phase required, outputs o_xval / o_yval;
  *   r2p: d_phase NULL, outputs o_mag / o_phase.  Modes CORDIC_SP2R, CORDIC_SR2P.
@@ -447,7 +454,8 @@ int	cordic_seq_ticks(cordic_seq *s, size_t ticks,
 		const uint32_t *d_phase,
 		int32_t *d_out0, int32_t *d_out1,
 		uint8_t *d_busy, uint8_t *d_done, uint8_t *d_oaux, void *stream);
-/* off-protocol i_stb clocks seen so far (synchronises the device) */
+/* i_stb on completing clocks (each one a re-run of the datapath) seen so far
+ * (synchronises the device) */
 int	cordic_seq_violations(cordic_seq *s, uint64_t *count);
 
 /* ---------------------------------------------------------- multi-GPU jobs

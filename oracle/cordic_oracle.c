@@ -626,6 +626,93 @@ int orc_seq_r2p_cycle(const orc_config *c, int32_t ix, int32_t iy,
 	return -1;
 }
 
+/* --------------------- sequential cores, whole port traces, register level
+ *
+ * rtl/seqcordic.v:100-324 / rtl/seqpolar.v:92-307 stepped over T clocks of
+ * arbitrary i_stb / i_reset / i_aux / sample inputs, every register updated
+ * from its pre-edge value.  Unlike the closed forms this also reproduces what
+ * the cores do OFF protocol: an i_stb on the very clock that completes a sample
+ * keeps `idle` low without loading the new sample (pre_valid needs idle), so
+ * the free-running datapath goes round again over its own result and a second
+ * o_done appears C-1 clocks later.  regs (in/out) carries the register file
+ * from call to call; a zeroed struct with idle = 1 is the power-on state. */
+void orc_seq_regs_init(orc_seq_regs *r)
+{
+	memset(r, 0, sizeof(*r));
+	r->idle = 1;
+}
+
+void orc_seq_trace(const orc_config *c, size_t T, const uint8_t *stb,
+		const uint8_t *rst, const uint8_t *aux, const int32_t *xi,
+		const int32_t *yi, const uint32_t *phi, int32_t *o0, int32_t *o1,
+		uint8_t *oaux, uint8_t *busy, uint8_t *done, orc_seq_regs *r)
+{
+	const int rot = (c->mode == ORC_SP2R);
+	const int ns = c->nstages, ww = c->ww, pw = c->pw;
+	const uint32_t pm = pmask(pw);
+	/* state register width and table length as the emitters size them
+	 * (sw/seqcordic.cpp / sw/seqpolar.cpp via nextlg) */
+	const int sbits = orc_nextlg((unsigned)(rot ? ns : ns + 1));
+	const unsigned smask = (1u << sbits) - 1u;
+	const unsigned tlen = 1u << orc_nextlg((unsigned)ns);
+	const unsigned last = (unsigned)(rot ? ns - 1 : ns + 1);
+	uint32_t table[128];
+	for (unsigned k = 0; k < tlen && k < 128; k++)
+		table[k] = angle_entry(k, pw);
+
+	for (size_t t = 0; t < T; t++) {
+		const int i_stb = stb[t] != 0;
+		const int i_rst = rst ? (rst[t] != 0) : 0;
+		const int i_aux = aux ? (aux[t] != 0) : 0;
+		const int at_last = rot ? (r->state >= last) : (r->state >= last);
+		const int eq_last = rot ? (r->state == last) : at_last;
+		orc_seq_regs n = *r;
+
+		/* pre-rotation registers load on every clock */
+		if (rot)
+			p2r_prerotate(c, xi[t], yi[t], phi[t], &n.prex, &n.prey, &n.preph);
+		else
+			r2p_prerotate(c, xi[t], yi[t], &n.prex, &n.prey, &n.preph);
+
+		if (i_rst)		n.aux = 0;
+		else if (i_stb && r->idle) n.aux = i_aux;
+
+		if (i_rst)		n.idle = 1;
+		else if (i_stb)		n.idle = 0;
+		else if (eq_last)	n.idle = 1;
+
+		n.pre_valid = i_rst ? 0 : (i_stb && r->idle);
+
+		if (i_rst)		n.state = 0;
+		else if (r->idle)	n.state = 0;
+		else if (eq_last)	n.state = 0;
+		else			n.state = (r->state + 1) & smask;
+
+		n.cangle = table[r->state & (tlen - 1)];
+
+		if (r->pre_valid) {
+			n.xv = r->prex; n.yv = r->prey; n.ph = r->preph;
+		} else if (rot) {
+			p2r_rotate(ww, pm, pw, r->state, r->cangle, &n.xv, &n.yv, &n.ph);
+		} else {
+			r2p_rotate(ww, pm, r->state, r->cangle, &n.xv, &n.yv, &n.ph);
+		}
+
+		n.o_done = i_rst ? 0 : at_last;
+		if (at_last) {
+			n.o0 = round_out(r->xv, ww, c->ow);
+			n.o1 = rot ? round_out(r->yv, ww, c->ow) : (int32_t)r->ph;
+			n.o_aux = r->aux;
+		}
+		*r = n;
+		o0[t] = r->o0;
+		o1[t] = r->o1;
+		if (oaux) oaux[t] = (uint8_t)r->o_aux;
+		if (busy) busy[t] = (uint8_t)!r->idle;
+		if (done) done[t] = (uint8_t)r->o_done;
+	}
+}
+
 /* ---------------------------------------------------------------- dispatch */
 
 void orc_rotate(const orc_config *c, size_t n, const int32_t *x,

@@ -93,6 +93,21 @@ int	orc_seq_p2r_cycle(const orc_config *cfg, int32_t x, int32_t y,
 int	orc_seq_r2p_cycle(const orc_config *cfg, int32_t x, int32_t y,
 		int32_t *omag, uint32_t *ophase);
 
+/* register-level model of the sequential cores over whole port traces,
+ * including their off-protocol behaviour (i_stb on a completing clock) */
+typedef struct orc_seq_regs {
+	int64_t	prex, prey, xv, yv;
+	uint32_t preph, ph, cangle;
+	uint32_t state;
+	int32_t	idle, pre_valid, aux, o_done, o_aux;
+	int32_t	o0, o1;
+} orc_seq_regs;
+void	orc_seq_regs_init(orc_seq_regs *r);
+void	orc_seq_trace(const orc_config *cfg, size_t T, const uint8_t *stb,
+		const uint8_t *rst, const uint8_t *aux, const int32_t *x,
+		const int32_t *y, const uint32_t *phase, int32_t *o0, int32_t *o1,
+		uint8_t *oaux, uint8_t *busy, uint8_t *done, orc_seq_regs *regs);
+
 /* dispatch on cfg->mode */
 void	orc_rotate(const orc_config *cfg, size_t n, const int32_t *x,
 		const int32_t *y, int xy_stride, const uint32_t *phase,

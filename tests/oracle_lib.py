@@ -154,6 +154,50 @@ def nco(cfg, n, phase0, fcw, index0, x0, y0):
     return ox, oy
 
 
+class SeqRegs(C.Structure):
+    _fields_ = [("prex", C.c_int64), ("prey", C.c_int64), ("xv", C.c_int64),
+                ("yv", C.c_int64), ("preph", C.c_uint32), ("ph", C.c_uint32),
+                ("cangle", C.c_uint32), ("state", C.c_uint32),
+                ("idle", C.c_int32), ("pre_valid", C.c_int32),
+                ("aux", C.c_int32), ("o_done", C.c_int32),
+                ("o_aux", C.c_int32), ("o0", C.c_int32), ("o1", C.c_int32)]
+
+
+def seq_regs():
+    """power-on register file of a sequential core"""
+    r = SeqRegs()
+    lib().orc_seq_regs_init(C.byref(r))
+    return r
+
+
+def seq_trace(cfg, stb, x, y, phase=None, reset=None, aux=None, regs=None):
+    """Register-level model of rtl/seqcordic.v / rtl/seqpolar.v over a whole
+    port trace (off-protocol strobes included).  Returns (o0, o1, o_aux,
+    o_busy, o_done) per clock; `regs` (SeqRegs) carries the state across
+    calls and is updated in place."""
+    L = lib()
+    L.orc_seq_trace.restype = None
+    n = len(stb)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    stb_, rs_, ax_ = u8(stb), u8(reset), u8(aux)
+    x_ = np.ascontiguousarray(x, dtype=np.int32)
+    y_ = np.ascontiguousarray(y, dtype=np.int32)
+    ph_ = (np.zeros(n, dtype=np.uint32) if phase is None else
+           np.ascontiguousarray(phase, dtype=np.uint32))
+    o0 = np.empty(n, dtype=np.int32)
+    o1 = np.empty(n, dtype=np.int32)
+    oa = np.empty(n, dtype=np.uint8)
+    bs = np.empty(n, dtype=np.uint8)
+    dn = np.empty(n, dtype=np.uint8)
+    r = regs if regs is not None else seq_regs()
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    L.orc_seq_trace.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 12
+    L.orc_seq_trace(C.byref(cfg), n, vp(stb_), vp(rs_), vp(ax_), vp(x_),
+                    vp(y_), vp(ph_), vp(o0), vp(o1), vp(oa), vp(bs), vp(dn),
+                    C.byref(r))
+    return o0, o1, oa, bs, dn
+
+
 def seq_p2r_cycle(cfg, x, y, phase):
     ox, oy = C.c_int32(), C.c_int32()
     t = lib().orc_seq_p2r_cycle(C.byref(cfg), x, y, phase,

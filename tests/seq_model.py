@@ -8,7 +8,9 @@ observe when it keeps to the protocol: with C = CLOCKS_PER_OUTPUT,
     that one clock, o_xval/o_yval (o_mag/o_phase) and o_aux change;
   * i_stb while busy is ignored -- EXCEPT on the completing clock itself,
     where the RTL keeps `idle` low and runs the datapath again over its own
-    result: that clock is reported as a violation and not modelled;
+    result: this closed-form model only counts such a clock (`violations`);
+    the register-level model that reproduces it is oracle_lib.seq_trace
+    (orc_seq_trace), which is what the GPU is checked against off protocol;
   * i_reset (wins over i_stb) drops a sample in flight, clears o_done and the
     aux register, and leaves the output registers alone -- which still load
     on a reset that hits the completing clock.

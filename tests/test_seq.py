@@ -4,7 +4,15 @@ tests/golden/seq_traces.json: clock-by-clock port traces of the emitted
 seqcordic / seqpolar RTL (vsim.py) under random i_stb / i_reset / i_aux.  CPU:
 the clock-level model (seq_model.py, on top of the oracle) reproduces them.
 GPU: cordic_seq_ticks reproduces them, fed in blocks of arbitrary length, and
-equals the model on long random traces; off-protocol i_stb is counted."""
+equals the model on long random traces.
+
+tests/golden/seq_offproto_traces.json: the same cores under strobes that do NOT
+keep to the protocol (i_stb held high, i_stb on completing clocks: the RTL then
+re-runs its datapath over its own result).  CPU: the oracle's register-level
+trace model (orc_seq_trace) reproduces both sets.  GPU: cordic_seq_ticks
+reproduces the off-protocol traces too (a register-level pass takes over for
+blocks that contain such a strobe) and equals the register-level model on long
+random traces with any strobe density."""
 import json
 import os
 import shlex
@@ -18,6 +26,8 @@ from seq_model import SeqModel
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
                                    "seq_traces.json")))
+OFFP = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "seq_offproto_traces.json")))
 MODE = {"sp2r": ca.SP2R, "sr2p": ca.SR2P}
 KEYS = ("o_busy", "o_done", "o_aux")
 
@@ -43,6 +53,42 @@ def test_handshake_model_reproduces_rtl_traces(name):
     assert oa.tolist() == g["o_aux"]
     assert busy.tolist() == g["o_busy"] and done.tolist() == g["o_done"]
     assert m.violations == 0
+
+
+def _reruns(stb, rs, done):
+    """strobes on completing clocks: o_done rises on the completing clock"""
+    return int(np.sum((np.asarray(done) != 0) & (np.asarray(stb) != 0)
+                      & (np.asarray(rs) == 0)))
+
+
+@pytest.mark.parametrize("which", ["on", "off"])
+def test_register_level_model_reproduces_rtl_traces(which):
+    """orc_seq_trace against the vsim traces of the emitted RTL, fed in one
+    piece and in pieces (the register file carries over)."""
+    gold = GOLD if which == "on" else OFFP
+    for name, g in gold.items():
+        ocfg = O.config_cli(*configs(g["args"]))
+        rot = "phase" in g
+        k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+        n = len(g["stb"])
+        for cuts in ([], [1, 7, 100, 101, n // 2, n - 3]):
+            regs = O.seq_regs()
+            parts = []
+            edges = [0] + cuts + [n]
+            for a, b in zip(edges[:-1], edges[1:]):
+                sl = slice(a, b)
+                parts.append(O.seq_trace(
+                    ocfg, g["stb"][sl], g["x"][sl], g["y"][sl],
+                    g["phase"][sl] if rot else None, g["reset"][sl],
+                    g["aux"][sl], regs=regs))
+            o0, o1, oa, bs, dn = (np.concatenate(p) for p in zip(*parts))
+            o1 = (o1.astype(np.int64) if rot else
+                  o1.view(np.uint32).astype(np.int64) & ((1 << g["PW"]) - 1))
+            assert o0.tolist() == g[k0] and o1.tolist() == g[k1], name
+            assert oa.tolist() == g["o_aux"], name
+            assert bs.tolist() == g["o_busy"] and dn.tolist() == g["o_done"], name
+        if which == "off":
+            assert _reruns(g["stb"], g["reset"], g["o_done"]) > 5, name
 
 
 def _gpu_run(seq, rot, stb, x, y, ph, rs, aux, cuts):
@@ -98,10 +144,69 @@ def test_gpu_seq_reproduces_rtl_traces(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(OFFP))
+def test_gpu_seq_reproduces_off_protocol_rtl_traces(name):
+    """i_stb held high / on completing clocks: the RTL re-runs its datapath
+    over its own result; cordic_seq_ticks must show the same ports, however
+    the trace is cut into blocks (re-runs then span calls)."""
+    g = OFFP[name]
+    cfg = ca.Config.from_cli(*configs(g["args"]))
+    rot = "phase" in g
+    k0, k1 = ("o_xval", "o_yval") if rot else ("o_mag", "o_phase")
+    n = len(g["stb"])
+    C = g["CLOCKS_PER_OUTPUT"]
+    for cuts in ([], [1, 2, 5, C, C + 1, 2 * C - 1, 3 * C, 400, 401, n // 2,
+                      n - 20, n - 1], list(range(37, n, 37))):
+        s = ca.Seq(cfg)
+        r = _gpu_run(s, rot, g["stb"], g["x"], g["y"], g.get("phase"),
+                     g["reset"], g["aux"], cuts)
+        assert r[0].tolist() == g[k0] and r[1].tolist() == g[k1]
+        assert r[2].tolist() == g["o_aux"]
+        assert r[3].tolist() == g["o_busy"] and r[4].tolist() == g["o_done"]
+        assert s.violations == _reruns(g["stb"], g["reset"], g["o_done"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,iw,ow,pw,ns", [
+    (ca.SP2R, 13, 13, -1, -1), (ca.SR2P, 13, 13, -1, -1),
+    (ca.SP2R, 32, 32, 32, 16), (ca.SR2P, 24, 24, -1, 20),
+    (ca.SP2R, 10, 12, 18, 12), (ca.SR2P, 8, 8, 14, 9)])
+@pytest.mark.parametrize("density", [1.0, 0.5, 0.05])
+def test_gpu_seq_long_random_trace_equals_register_model(mode, iw, ow, pw, ns,
+                                                         density):
+    """Any strobe density, resets anywhere: the GPU against the oracle's
+    register-level model (which the vsim traces pin)."""
+    xtra = 1 if iw < 13 else 2
+    cfg = ca.Config.from_cli(mode, iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
+    rot = mode == ca.SP2R
+    rng = np.random.RandomState(11)
+    n = 20000
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x, y = rng.randint(lo, hi, n), rng.randint(lo, hi, n)
+    ph = rng.randint(0, 1 << cfg.pw, n, dtype=np.int64)
+    aux = rng.randint(0, 2, n).astype(np.uint8)
+    stb = (rng.rand(n) < density).astype(np.uint8)
+    rs = (rng.randint(0, 1500, n) == 0).astype(np.uint8)
+    o0, o1, oa, bs, dn = O.seq_trace(ocfg, stb, x, y, ph if rot else None, rs, aux)
+    o1 = (o1.astype(np.int64) if rot else o1.view(np.uint32).astype(np.int64))
+    s = ca.Seq(cfg)
+    got = _gpu_run(s, rot, stb, x, y, ph, rs, aux,
+                   [3, 1024, 1025, 2048 + 7, 9000, 9001, n - 10])
+    assert np.array_equal(got[0], o0.astype(np.int64))
+    assert np.array_equal(got[1], o1)
+    assert np.array_equal(got[2], oa) and np.array_equal(got[3], bs)
+    assert np.array_equal(got[4], dn)
+    assert s.violations == _reruns(stb, rs, dn)
+    if density == 1.0:
+        assert s.violations > 100
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,iw,ow,pw,ns", [
     (ca.SP2R, 13, 13, -1, -1), (ca.SR2P, 13, 13, -1, -1),
     (ca.SP2R, 32, 32, 32, 16), (ca.SR2P, 24, 24, -1, 20)])
-@pytest.mark.parametrize("density", [1.0, 0.2, 0.01])
+@pytest.mark.parametrize("density", [0.2, 0.01])
 def test_gpu_seq_long_random_trace_equals_model(mode, iw, ow, pw, ns, density):
     cfg = ca.Config.from_cli(mode, iw, ow, 2, pw, ns)
     ocfg = O.config_cli(mode, iw, ow, 2, pw, ns)
@@ -115,16 +220,17 @@ def test_gpu_seq_long_random_trace_equals_model(mode, iw, ow, pw, ns, density):
     stb = (rng.rand(n) < density).astype(np.uint8)
     rs = (rng.randint(0, 2500, n) == 0).astype(np.uint8)
     cuts = [3, 1024, 1025, 2048 + 7, 15000, 15001, 29990]
-    # off-protocol strobes are ignored and counted, exactly as the model does
+    # keep this one on protocol (the closed-form model does not re-run)
+    m = SeqModel(ocfg, rot)
+    probe = m.run(stb, x, y, ph, rs, aux)
+    stb[(probe[4] != 0)] = 0            # no strobe on a completing clock
     m = SeqModel(ocfg, rot)
     want = m.run(stb, x, y, ph, rs, aux)
     s = ca.Seq(cfg)
     got = _gpu_run(s, rot, stb, x, y, ph, rs, aux, cuts)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
-    assert s.violations == m.violations
-    if density == 1.0:
-        assert m.violations > 0     # back-to-back i_stb hits every load clock
+    assert s.violations == m.violations == 0
 
 
 @pytest.mark.gpu
