@@ -264,6 +264,65 @@ def from_profile(key, samples_per_launch=1 << 30):
     return out
 
 
+KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
+             "cfg5": "rotator_seeded", "cfg5seq": "rotator_seeded",
+             "cfg1": "rotator_seeded", "cfg3": "topolar_lj",
+             "p2rxy": "rotator_unrolled", "quadtbl": "quad_lookup",
+             "quadtbl24": "quad_lookup", "sintbl": "table_lookup",
+             "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup"}
+
+
+def measure_pmc(args):
+    """`--pmc`: HBM bytes per launch of the workload's kernel, MEASURED now:
+    two separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- they do not fit
+    one pass, and PMC is never combined with tracing) over a 3-step run of
+    this same script, corrected as MI355X_MICROARCH.md prescribes for gfx950
+    (FETCH_SIZE counts half of a wide coalesced read; both are in KiB)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not found"}
+    kern = KERNEL_OF.get(args.workload)
+    if args.no_seed and kern == "rotator_seeded":
+        kern = "rotator_unrolled"
+    base = [sys.executable, os.path.abspath(__file__), "--workload",
+            args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
+            str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
+            "--no-other-paths", "--no-copy-probe", "--no-pmc"]
+    for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
+                     ("--static-chunks", args.static_chunks)):
+        if on:
+            base.append(flag)
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format",
+                                "csv", "-d", td, "--"] + base, cwd="/tmp",
+                               env=env, capture_output=True, text=True,
+                               timeout=600)
+            rows = []
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"),
+                               recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if (row["Counter_Name"] == ctr and kern
+                            and kern in row["Kernel_Name"]):
+                        rows.append(float(row["Counter_Value"]))
+            if not rows:
+                return {"error": "no %s rows for %s (rocprofv3 rc %d)"
+                        % (ctr, kern, r.returncode)}
+            vals[ctr] = (sum(rows) / len(rows), len(rows))
+    fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return {"kernel": kern, "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+            "launches_averaged": vals["FETCH_SIZE"][1],
+            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM), "
+                          "WRITE_SIZE as reported, KiB -> B"}
+
+
 _probe_lib = None
 
 
@@ -696,6 +755,17 @@ def run_group(args, w, launch):
             "kernel_ms_min": float(min(span_ms)),
             "kernel_ms_max": float(max(span_ms)),
         }
+        if not args.no_pmc and total == 1:
+            try:
+                pm = measure_pmc(args)
+            except Exception as e:            # never lose the main line
+                pm = {"error": repr(e)}
+            roof["pmc"] = pm
+            if "hbm_bytes_per_launch" in pm:
+                roof["traffic"] = pm["hbm_bytes_per_launch"] * (
+                    n / float(1 << args.log2_samples))
+                roof["traffic_over_algorithmic"] = roof["traffic"] / (
+                    w["bytes"] * n)
         if probes and probes[0]:
             # the plain-copy ceiling of THIS run on THESE arrays: best of the
             # probes before and after the timed region
@@ -811,7 +881,8 @@ def single_process_block(args, ndev, expect):
            "--single-process", "--workload", args.workload, "--steps",
            str(args.steps), "--warmup", str(args.warmup), "--log2-samples",
            str(args.log2_samples), "--input", args.input, "--gather",
-           "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe"]
+           "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
+           "--no-pmc"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks)):
         if on:
@@ -1136,6 +1207,10 @@ def main():
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip measuring roofline.traffic (two rocprofv3 --pmc "
+                    "passes, FETCH_SIZE and WRITE_SIZE, over a 3-step run of "
+                    "this workload; 1-GPU runs only, ~20 s)")
     ap.add_argument("--no-single-process-check", action="store_true",
                     help="multi-process runs: skip the extra one-process "
                     "cordic_group measurement on rank 0")

@@ -99,7 +99,7 @@ def _line(stdout):
 
 
 SMALL = ["--steps", "5", "--warmup", "1", "--log2-samples", "22",
-         "--no-cpu-baseline", "--no-other-paths"]
+         "--no-cpu-baseline", "--no-other-paths", "--no-pmc"]
 
 
 @pytest.mark.gpu
@@ -137,6 +137,21 @@ def test_single_process_path_and_direct_agree():
     assert a["digest"] == b["digest"]
     assert a["bit_exact_vs_oracle"] and b["bit_exact_vs_oracle"]
     assert "copy_frac" in b["roofline"]
+
+
+@pytest.mark.gpu
+def test_traffic_is_measured_in_the_same_run():
+    """roofline.traffic comes from two rocprofv3 --pmc passes of this very
+    command: algorithmic bytes within 1 %."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not installed")
+    d = _line(run(["--gpus", "1", "--steps", "5", "--warmup", "1",
+                   "--log2-samples", "26", "--no-cpu-baseline",
+                   "--no-other-paths"]).stdout)
+    r = d["roofline"]
+    assert "error" not in r["pmc"], r["pmc"]
+    assert 0.99 < r["traffic_over_algorithmic"] < 1.02
 
 
 @pytest.mark.gpu

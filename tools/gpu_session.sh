@@ -38,7 +38,7 @@ for task in "$@"; do
 	states)
 		for i in $(seq 1 ${STATE_ROUNDS:-10}); do
 			echo "== round $i: $(./tools/hbm_probe2 30 20 marker | grep -m1 persist)" >> $log
-			python bench.py --steps 300 --no-cpu-baseline --no-other-paths 2>/dev/null | python -c "
+			python bench.py --steps 300 --no-cpu-baseline --no-other-paths --no-pmc 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']), round(d['roofline']['frac'],3), d['roofline'].get('copy_frac'))" >> $log
 			snap >> $log
@@ -46,7 +46,7 @@ d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']
 	ab)
 		make -C cordic_amd/csrc -j8 BUILD=build_ab OUT=$PWD/cordic_amd/lib_ab.so HIPFLAGS_EXTRA="$arg" > gpurun_out/ab_build.log 2>&1
 		for r in 1 2 3; do for lib in libcordic_amd.so lib_ab.so; do
-			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-other-paths 2>/dev/null \
+			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-other-paths --no-pmc 2>/dev/null \
 			| python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['roofline']['frac'],3))" >> $log
@@ -55,7 +55,7 @@ d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['ro
 		mkdir -p gpurun_out/bench_sweep
 		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 quadtbl quadtbl24; do
 			for inp in ramp random; do
-				python bench.py --workload $w --input $inp --no-cpu-baseline --no-other-paths \
+				python bench.py --workload $w --input $inp --no-cpu-baseline --no-other-paths --no-pmc \
 					> gpurun_out/bench_sweep/${w}_${inp}.json 2>> $log
 			done
 		done
