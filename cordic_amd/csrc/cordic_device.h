@@ -930,9 +930,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				x[v] = (int64_t)(((uint64_t)se[v][1] << 32) | se[v][0]);
 				y[v] = (int64_t)(((uint64_t)se[v][3] << 32) | se[v][2]);
 				// residual = (r - off) mod 2^29, sign extended; carried
-				// as sext(residual) << 31 = sext(t) << 28
-				const int32_t t = (int32_t)((r[v] - se[v][0]) << 3);
-				p[v] = (int64_t)((uint64_t)(int64_t)t << 28);
+				// as sext(residual) << 31: high word = bits 28..1 of the
+				// difference sign-extended (one v_bfe_i32), low word =
+				// bit 0 in bit 31
+				const uint32_t d = r[v] - se[v][0];
+				const int32_t hi = __builtin_amdgcn_sbfe((int32_t)d, 1, 28);
+				p[v] = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (d << 31));
 			} else {
 				x[v] = (int64_t)se[v][0];
 				y[v] = (int64_t)se[v][1];
