@@ -714,7 +714,7 @@ def run_group(args, w, launch):
         grp2.close()
 
     gather = None
-    if args.gather and total > 1:
+    if args.gather:
         gather = time_gather(args, grp, step, launch, dist, dev, devices, n,
                              n_total, rank, world, barrier)
 
@@ -933,21 +933,39 @@ def time_gather(args, grp, step, launch, dist, dev, devices, n, n_total, rank,
                 "ms_compute_and_gather": ms, "outputs_identical": ok}
     if dist is None:
         return None
-    a = torch.empty(n, dtype=torch.int32, device=dev)
-    b = torch.empty(n, dtype=torch.int32, device=dev)
-    grp.read_into(0, 2, 0, a)
-    grp.read_into(0, 3, 0, b)
-    outs = None
+    # process-per-GPU: the C++ layer's own RCCL forwarding (ncclSend/ncclRecv
+    # piece by piece behind the compute); torch.distributed only carries the
+    # 128-byte RCCL id and the barrier
+    uid = [ca.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    grp.rccl_init(uid[0])
+    root = rp = None
     if rank == 0:
-        outs = [torch.empty(2 * n, dtype=torch.int32, device=dev)
-                for _ in range(world)]
-    ab = torch.cat([a, b])
+        root = ca.Group(grp.cfg, devices=[devices[0]], first_shard=0,
+                        total_shards=1)
+        root.reserve(n_total, 0)
+        _, rp, _ = root.buffers(0)
+    grp.set_gather_rccl(0, rp[2] if rp else None, rp[3] if rp else None, 8)
+    step(grp)
     barrier()
+    k = max(3, min(args.steps, 10))
     t1 = time.perf_counter()
-    dist.gather(ab, outs, dst=0)
+    for _ in range(k):
+        step(grp)
     barrier()
-    return {"mode": "RCCL gather of finished outputs to rank 0",
-            "ms_gather_only": (time.perf_counter() - t1) * 1e3}
+    ms = (time.perf_counter() - t1) / k * 1e3
+    grp.set_gather_rccl(-1)
+    d = grp.digest(n_total)
+    t = torch.tensor([d - (1 << 64) if d >= 1 << 63 else d],
+                     dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ok = None
+    if rank == 0:
+        ok = root.digest(n_total) == (int(t.item()) & 0xFFFFFFFFFFFFFFFF)
+        root.close()
+    return {"mode": "RCCL ncclSend/ncclRecv to shard 0, 8 pieces per shard "
+            "behind the compute (cordic_group_set_gather_rccl)",
+            "ms_compute_and_gather": ms, "outputs_identical": ok}
 
 
 def run_direct(args, w, launch):

@@ -136,6 +136,11 @@ ABI = {
                                       C.POINTER(C.c_uint64)]),
     "cordic_group_set_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_int]),
+    "cordic_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "cordic_group_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_group_set_gather_rccl": (C.c_int, [C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p,
+                                               C.c_int]),
     "cordic_group_mark": (C.c_int, [C.c_void_p, C.c_int]),
     "cordic_group_elapsed": (C.c_int, [C.c_void_p, C.c_int, C.c_int,
                                        C.POINTER(C.c_float),
@@ -432,6 +437,24 @@ class Group:
                                              addr(out1), chunks),
                "cordic_group_set_gather")
 
+    def rccl_init(self, unique_id):
+        """Join the job's RCCL communicator (collective over all shards);
+        unique_id: the 128 bytes of rccl_unique_id() from one process."""
+        if len(unique_id) != RCCL_ID_BYTES:
+            raise ValueError("an RCCL unique id is %d bytes" % RCCL_ID_BYTES)
+        buf = C.create_string_buffer(bytes(unique_id), RCCL_ID_BYTES)
+        _check(lib().cordic_group_rccl_init(self._h, buf),
+               "cordic_group_rccl_init")
+
+    def set_gather_rccl(self, root_shard, out0=None, out1=None, chunks=8):
+        """out0 / out1 (root's process only): device tensors or addresses."""
+        def addr(t):
+            return t if isinstance(t, int) or t is None else _ptr(t)
+        _check(lib().cordic_group_set_gather_rccl(self._h, root_shard,
+                                                  addr(out0), addr(out1),
+                                                  chunks),
+               "cordic_group_set_gather_rccl")
+
     def mark(self, slot):
         _check(lib().cordic_group_mark(self._h, slot), "cordic_group_mark")
 
@@ -477,6 +500,16 @@ class Group:
             addr, count = _ptr(src), src.numel()
         _check(lib().cordic_group_write(self._h, local_shard, array, offset,
                                         count, addr), "cordic_group_write")
+
+
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """128 bytes for Group.rccl_init, from ONE process of the job."""
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    _check(lib().cordic_rccl_unique_id(buf), "cordic_rccl_unique_id")
+    return buf.raw
 
 
 def device_count():

@@ -8,13 +8,21 @@
 // (a) 8-byte digests, summed on the host, and (b) optionally the results on
 // their way to one consumer device, chunk-pipelined behind the compute with
 // hipMemcpyPeerAsync (SDMA over xGMI: no CUs, no RCCL kernels competing with
-// the CORDIC kernels for the VALUs).
+// the CORDIC kernels for the VALUs).  With one process per GPU the same
+// forwarding goes over RCCL instead (ncclSend / ncclRecv pairs, RCCL has no
+// gather primitive): cordic_group_rccl_init + cordic_group_set_gather_rccl.
+// librccl is opened at run time, on first use, so programs that never gather
+// across processes do not depend on it.
 //
 // The reference has nothing of the kind (bench/cpp/cordic_tb.cpp:127-178 steps
 // one model from one thread), so there is no reference text to follow here.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>		// types only: the entry points come from dlopen
+#include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -39,7 +47,51 @@ struct Shard {
 	uint64_t *d_digest = nullptr;
 	hipEvent_t marks[kMaxMarks] = {};
 	hipEvent_t piece[kMaxChunks] = {};
+	ncclComm_t comm = nullptr;	// rank = index of total (cordic_group_rccl_init)
 };
+
+// The eight RCCL entry points the gather needs, resolved once per process.
+struct Rccl {
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t,
+			hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t,
+			hipStream_t) = nullptr;
+	bool	usable = false;
+};
+
+const Rccl &rccl()
+{
+	static Rccl api;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		// a process that already carries an RCCL (PyTorch ships its own)
+		// gets that one back from the soname lookup
+		const char *names[] = {std::getenv("CORDIC_RCCL_LIB"), "librccl.so.1",
+			"librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		void *h = nullptr;
+		for (const char *nm : names)
+			if (nm && *nm && (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+				break;
+		if (!h)
+			return;
+		auto sym = [&](const char *nm) { return dlsym(h, nm); };
+		api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+		api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+		api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+		api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+		api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+		api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+		api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+		api.usable = api.GetUniqueId && api.CommInitRank && api.CommDestroy
+			&& api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+	});
+	return api;
+}
 
 // restores the caller's current device on every exit path
 struct DeviceScope {
@@ -60,6 +112,7 @@ struct cordic_group {
 	int	root = -1;
 	int32_t	*g0 = nullptr, *g1 = nullptr;
 	int	chunks = 1;
+	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
 };
 
 namespace {
@@ -81,6 +134,7 @@ void release(Shard &s)
 		p = nullptr;
 	}
 	if (s.d_digest) (void)hipFree(s.d_digest);
+	if (s.comm) (void)rccl().CommDestroy(s.comm);
 	if (s.plan) cordic_plan_destroy(s.plan);
 	for (hipEvent_t &e : s.marks) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t &e : s.piece) if (e) (void)hipEventDestroy(e);
@@ -119,8 +173,54 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 	return CORDIC_OK;
 }
 
+// piece c of `chunks` of a shard of cnt samples: pieces start on 4096-sample
+// boundaries of the shard, so the vector kernels keep their 16-byte accesses
+bool piece_span(uint64_t cnt, int chunks, int c, uint64_t *a, uint64_t *len)
+{
+	uint64_t psize = (cnt + (uint64_t)chunks - 1) / (uint64_t)chunks;
+	psize = (psize + 4095) & ~(uint64_t)4095;
+	*a = (uint64_t)c * psize;
+	if (*a >= cnt)
+		return false;
+	*len = (cnt - *a < psize) ? cnt - *a : psize;
+	return true;
+}
+
+// Piece c of every shard of the job travels to the root shard: each local
+// shard sends its own, the root shard posts the matching receives for all
+// `total` shards (every rank derives the same piece geometry from n_total),
+// all in one RCCL group, on the copy streams.
+int rccl_forward(cordic_group *g, uint64_t n_total, int c)
+{
+	const Rccl &api = rccl();
+	bool fine = api.GroupStart() == ncclSuccess;
+	for (Shard &s : g->shards) {
+		uint64_t start, cnt, a, len;
+		shard_span(n_total, s.index, g->total, &start, &cnt);
+		if (fine && piece_span(cnt, g->chunks, c, &a, &len)) {
+			fine = api.Send(static_cast<int32_t *>(s.buf[2]) + a, (size_t)len,
+					ncclInt32, g->rroot, s.comm, s.copy) == ncclSuccess
+				&& api.Send(static_cast<int32_t *>(s.buf[3]) + a, (size_t)len,
+					ncclInt32, g->rroot, s.comm, s.copy) == ncclSuccess;
+		}
+		if (s.index != g->rroot)
+			continue;
+		for (int r = 0; r < g->total && fine; r++) {
+			shard_span(n_total, r, g->total, &start, &cnt);
+			if (!piece_span(cnt, g->chunks, c, &a, &len))
+				continue;
+			fine = api.Recv(g->g0 + start + a, (size_t)len, ncclInt32, r,
+					s.comm, s.copy) == ncclSuccess
+				&& api.Recv(g->g1 + start + a, (size_t)len, ncclInt32, r,
+					s.comm, s.copy) == ncclSuccess;
+		}
+	}
+	// always close the group that was opened
+	return (api.GroupEnd() == ncclSuccess && fine) ? CORDIC_OK : CORDIC_ERR_DEVICE;
+}
+
 // Run `launch(shard, offset, count)` over every local shard, whole or -- with
-// forwarding set -- piece by piece, each piece followed by its peer copies.
+// forwarding set -- piece by piece, each piece followed by its copies.
 template <typename F>
 int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 {
@@ -129,26 +229,21 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 	DeviceScope scope;
 	if (int rc = ensure(g, n_total, inputs))
 		return rc;
-	const int chunks = (g->root >= 0) ? g->chunks : 1;
+	const bool forward = g->root >= 0 || g->rroot >= 0;
+	const int chunks = forward ? g->chunks : 1;
 	// piece-major, so that every device has work queued before the first
 	// copy is issued
 	for (int c = 0; c < chunks; c++) {
 		for (Shard &s : g->shards) {
-			uint64_t start, cnt;
+			uint64_t start, cnt, a, len;
 			shard_span(n_total, s.index, g->total, &start, &cnt);
-			// pieces start on 4096-sample boundaries of the shard, so the
-			// vector kernels keep their 16-byte accesses
-			uint64_t psize = (cnt + (uint64_t)chunks - 1) / (uint64_t)chunks;
-			psize = (psize + 4095) & ~(uint64_t)4095;
-			const uint64_t a = (uint64_t)c * psize;
-			if (a >= cnt)
+			if (!piece_span(cnt, chunks, c, &a, &len))
 				continue;
-			const uint64_t len = (cnt - a < psize) ? cnt - a : psize;
 			if (!ok(hipSetDevice(s.device)))
 				return CORDIC_ERR_DEVICE;
 			if (int rc = launch(s, start, a, len))
 				return rc;
-			if (g->root < 0)
+			if (!forward)
 				continue;
 			if (!s.piece[c] && !ok(hipEventCreateWithFlags(&s.piece[c],
 					hipEventDisableTiming)))
@@ -156,6 +251,8 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 			if (!ok(hipEventRecord(s.piece[c], s.compute)) ||
 			    !ok(hipStreamWaitEvent(s.copy, s.piece[c], 0)))
 				return CORDIC_ERR_DEVICE;
+			if (g->root < 0)
+				continue;
 			const size_t bytes = (size_t)len * 4;
 			int32_t *o0 = static_cast<int32_t *>(s.buf[2]) + a;
 			int32_t *o1 = static_cast<int32_t *>(s.buf[3]) + a;
@@ -165,6 +262,9 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 					s.device, bytes, s.copy)))
 				return CORDIC_ERR_DEVICE;
 		}
+		if (g->rroot >= 0)
+			if (int rc = rccl_forward(g, n_total, c))
+				return rc;
 	}
 	return CORDIC_OK;
 }
@@ -401,7 +501,7 @@ int cordic_group_set_gather(cordic_group *grp, int root_device, int32_t *d_out0,
 	if (!grp)
 		return CORDIC_ERR_ARGS;
 	if (root_device < 0) {
-		grp->root = -1;
+		grp->root = grp->rroot = -1;
 		grp->g0 = grp->g1 = nullptr;
 		grp->chunks = 1;
 		return CORDIC_OK;
@@ -409,6 +509,7 @@ int cordic_group_set_gather(cordic_group *grp, int root_device, int32_t *d_out0,
 	if (!d_out0 || !d_out1 || chunks < 1 || chunks > kMaxChunks
 			|| root_device >= cordic_device_count())
 		return CORDIC_ERR_ARGS;
+	grp->rroot = -1;
 	DeviceScope scope;
 	// let the copy engines move device to device directly over xGMI; where
 	// peer access cannot be enabled hipMemcpyPeerAsync still works (staged)
@@ -424,6 +525,78 @@ int cordic_group_set_gather(cordic_group *grp, int root_device, int32_t *d_out0,
 		}
 	}
 	grp->root = root_device;
+	grp->g0 = d_out0;
+	grp->g1 = d_out1;
+	grp->chunks = chunks;
+	return CORDIC_OK;
+}
+
+int cordic_rccl_unique_id(void *id)
+{
+	if (!id)
+		return CORDIC_ERR_ARGS;
+	const Rccl &api = rccl();
+	if (!api.usable)
+		return CORDIC_ERR_UNSUPPORTED;	// no librccl in this process / image
+	ncclUniqueId u;
+	if (api.GetUniqueId(&u) != ncclSuccess)
+		return CORDIC_ERR_DEVICE;
+	static_assert(sizeof u == CORDIC_RCCL_ID_BYTES, "ncclUniqueId size");
+	std::memcpy(id, &u, sizeof u);
+	return CORDIC_OK;
+}
+
+int cordic_group_rccl_init(cordic_group *grp, const void *id)
+{
+	if (!grp || !id)
+		return CORDIC_ERR_ARGS;
+	const Rccl &api = rccl();
+	if (!api.usable)
+		return CORDIC_ERR_UNSUPPORTED;
+	for (const Shard &s : grp->shards)
+		if (s.comm)
+			return CORDIC_ERR_ARGS;	// once per group
+	ncclUniqueId u;
+	std::memcpy(&u, id, sizeof u);
+	DeviceScope scope;
+	// one communicator per local shard, rank = global shard index; several
+	// in one process have to be created inside one RCCL group
+	bool fine = api.GroupStart() == ncclSuccess;
+	for (Shard &s : grp->shards) {
+		if (!fine)
+			break;
+		fine = ok(hipSetDevice(s.device)) &&
+			api.CommInitRank(&s.comm, grp->total, u, s.index) == ncclSuccess;
+	}
+	if (api.GroupEnd() != ncclSuccess || !fine) {
+		for (Shard &s : grp->shards) {
+			if (s.comm) (void)api.CommDestroy(s.comm);
+			s.comm = nullptr;
+		}
+		return CORDIC_ERR_DEVICE;
+	}
+	return CORDIC_OK;
+}
+
+int cordic_group_set_gather_rccl(cordic_group *grp, int root_shard,
+		int32_t *d_out0, int32_t *d_out1, int chunks)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	if (root_shard < 0)
+		return cordic_group_set_gather(grp, -1, nullptr, nullptr, 1);
+	if (root_shard >= grp->total || chunks < 1 || chunks > kMaxChunks)
+		return CORDIC_ERR_ARGS;
+	bool holds_root = false;
+	for (const Shard &s : grp->shards) {
+		if (!s.comm)
+			return CORDIC_ERR_ARGS;	// cordic_group_rccl_init first
+		holds_root = holds_root || s.index == root_shard;
+	}
+	if (holds_root && (!d_out0 || !d_out1))
+		return CORDIC_ERR_ARGS;
+	grp->root = -1;
+	grp->rroot = root_shard;
 	grp->g0 = d_out0;
 	grp->g1 = d_out1;
 	grp->chunks = chunks;

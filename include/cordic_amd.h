@@ -530,6 +530,28 @@ int	cordic_group_digest(cordic_group *grp, uint64_t n_total, uint64_t *digest);
  * < 0 clears it. */
 int	cordic_group_set_gather(cordic_group *grp, int root_device,
 		int32_t *d_out0, int32_t *d_out1, int chunks);
+/* The same forwarding when the shards of the job live in DIFFERENT processes
+ * (one process per GPU): RCCL point-to-point over xGMI.  Bootstrap as RCCL
+ * prescribes: ONE process -- normally the one holding shard 0 -- calls
+ * cordic_rccl_unique_id and hands the CORDIC_RCCL_ID_BYTES bytes to every
+ * process of the job by whatever means it has (a file, a pipe, MPI_Bcast,
+ * torch.distributed); every process then calls cordic_group_rccl_init
+ * (collective: returns when all total_shards ranks have joined; rank = global
+ * shard index, one communicator per local shard).  While
+ * cordic_group_set_gather_rccl is set, every job call computes its shards in
+ * `chunks` pieces and sends each finished piece to shard root_shard
+ * (ncclSend on the copy stream; RCCL has no gather primitive), whose process
+ * posts the matching ncclRecv into d_out0 / d_out1 (device memory of the root
+ * shard's device, n_total words each; ignored, may be NULL, elsewhere).
+ * EVERY process of the job has to issue the same job calls with the same
+ * n_total and chunks.  root_shard < 0 clears it.  librccl is opened at run
+ * time on first use (CORDIC_RCCL_LIB overrides the name);
+ * CORDIC_ERR_UNSUPPORTED when it cannot be. */
+#define CORDIC_RCCL_ID_BYTES 128
+int	cordic_rccl_unique_id(void *id);
+int	cordic_group_rccl_init(cordic_group *grp, const void *id);
+int	cordic_group_set_gather_rccl(cordic_group *grp, int root_shard,
+		int32_t *d_out0, int32_t *d_out1, int chunks);
 /* Timing marks: `slot` (0..255) is recorded on every local shard's compute
  * stream; elapsed = max over the local shards of the time between two marks
  * (synchronises), per_shard_ms (may be NULL) receives nlocal values. */

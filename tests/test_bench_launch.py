@@ -115,6 +115,19 @@ def test_self_spawn_path_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["--spawn", "--single-process"])
+def test_gather_goes_through_the_c_abi(layout):
+    """--gather: RCCL send/recv of the C++ layer in the process-per-GPU
+    layout (a world of one here), peer copies in the one-process layout; what
+    arrives equals what the shards hold."""
+    r = run(["--gpus", "1", layout, "--gather"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = _line(r.stdout)["gather"]
+    assert g["outputs_identical"] is True and g["ms_compute_and_gather"] > 0
+    assert ("set_gather_rccl" if layout == "--spawn" else "set_gather)") in g["mode"]
+
+
+@pytest.mark.gpu
 def test_multi_process_run_also_measures_the_one_process_layer():
     """What a >1-GPU torchrun line carries: rank 0 runs `bench.py
     --single-process` as a guarded subprocess while the other ranks wait on

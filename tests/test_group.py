@@ -148,3 +148,59 @@ def test_bad_arguments():
     with pytest.raises(ca.CordicError):
         g.set_gather(0, 0, 0, 8)                        # NULL destination
     g.close()
+
+
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_rccl_forwarding_one_rank(chunks):
+    """The process-per-GPU gather (ncclSend / ncclRecv behind the compute)
+    with a world of one: the box has one GPU and RCCL refuses two ranks on
+    one device, so this covers bootstrap, piece geometry and the send/recv
+    pairing of the root with itself; the N-rank case is examples/multi_proc.c
+    on a multi-GPU node."""
+    cfg, ocfg = both(*CFG4)
+    n_total = (1 << 20) + 4101
+    g = ca.Group(cfg, devices=[0])
+    with pytest.raises(ca.CordicError):
+        g.set_gather_rccl(0, 0, 0, chunks)              # rccl_init first
+    uid = ca.rccl_unique_id()
+    assert len(uid) == ca.RCCL_ID_BYTES
+    g.rccl_init(uid)
+    with pytest.raises(ca.CordicError):
+        g.rccl_init(uid)                                # once per group
+    with pytest.raises(ca.CordicError):
+        g.set_gather_rccl(0, 0, 0, chunks)              # root needs arrays
+    root = ca.Group(cfg, devices=[0])
+    root.reserve(n_total, 0)
+    _, rp, _ = root.buffers(0)
+    g.fill_phase_ramp(n_total, 0)
+    g.set_gather_rccl(0, rp[2], rp[3], chunks)
+    for _ in range(2):
+        g.p2r_const(n_total, AMP, 0)
+    g.sync()
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    assert np.array_equal(root.read(0, root.OUT0, 0, n_total), rx)
+    assert np.array_equal(root.read(0, root.OUT1, 0, n_total), ry)
+    g.set_gather_rccl(-1)
+    g.p2r_const(n_total, AMP, 0)                        # plain job again
+    assert root.digest(n_total) == g.digest(n_total)
+    g.close()
+    root.close()
+
+
+def test_multi_proc_example_one_worker():
+    """examples/multi_proc.c: fork-per-GPU launcher, RCCL id through pipes,
+    gathered digest == sum of the shard digests (exit status 0)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "multi_proc")
+    if not os.path.exists(exe):
+        pytest.skip("tools/multi_proc not built")
+    r = subprocess.run([exe, "-r", "1", "-l", "22", "-k", "3", "-c", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(equal)" in r.stdout
+    cfg, ocfg = both(*CFG4)
+    rx, ry = oracle_p2r(ocfg, 0, 1 << 22)
+    want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
+    assert "digest of the gathered  : %016x" % want in r.stdout
