@@ -818,13 +818,23 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	static_assert(M <= NLIVE, "seed deeper than the core");
 
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *lds_buckets = lds;				// nbuckets x 4
-	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 4;	// 4L x 4 words
+	uint32_t *lds_buckets = lds;				// nbuckets x 2
+	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 2;	// 4L x 4 words
 	const int L = sa.nleaves;
+	const uint32_t seed_base = (uint32_t)sa.nbuckets * 8u;
 
-	for (int i = threadIdx.x; i < sa.nbuckets * 4; i += kSeedBlock)
-		lds_buckets[i] = sa.table[4 + i];
-	const uint32_t *leafmeta = sa.table + 4 + (size_t)sa.nbuckets * 4;
+	// bucket entries as the lookup wants them: {bound - 1, byte address of
+	// the bucket's first leaf in quadrant 0}.  A bucket without a boundary
+	// gets its own last phase as the bound (the compare below looks at bit
+	// 29 of a difference, so the bound has to stay within 2^29 of every
+	// phase of the bucket -- the table's 0x7fffffff would not).
+	for (int i = threadIdx.x; i < sa.nbuckets * 2; i += kSeedBlock) {
+		const uint32_t w = sa.table[4 + i];
+		const uint32_t b = (uint32_t)i >> 1;
+		lds_buckets[i] = (i & 1) ? seed_base + w * 16u
+			: (w == 0x7fffffffu ? ((b + 1u) << sa.S) - 1u : w);
+	}
+	const uint32_t *leafmeta = sa.table + 4 + (size_t)sa.nbuckets * 2;
 	for (int e = threadIdx.x; e < 4 * L; e += kSeedBlock) {
 		const int q = e / L, j = e - q * L;
 		const uint32_t pattern = leafmeta[2 * j];
@@ -880,49 +890,67 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		ljc.bit = vgpr_const(LjConst<C::lj>::bit);
 		ljc.maskbit = vgpr_const(LjConst<C::lj>::mask | LjConst<C::lj>::bit);
 	}
-	const uint32_t bshift = (uint32_t)sa.S - 4;	// bucket -> byte offset
-	const uint32_t seed_base = (uint32_t)sa.nbuckets * 16u;
+	const uint32_t k45 = vgpr_const(0x20000000u);	// 45 degrees (VOP3 has no literal)
+	const uint32_t bshift = (uint32_t)sa.S - 3;	// bucket -> byte offset
+	const uint32_t bmask = ((uint32_t)sa.nbuckets - 1u) << 3;
 	const uint32_t qstride = (uint32_t)L * 16u;
 	// LDS is addressed by byte offset: this kernel has no static LDS, so the
 	// dynamic array starts at LDS address 0 and the per-sample address needs
 	// no base added to it (the add of the array's link-time address was one
 	// VALU instruction per read).  Checked once per wave.
 	typedef const __attribute__((address_space(3))) u32x4 lds_entry;
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+	typedef const __attribute__((address_space(3))) u32x2 lds_bucket;
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
 		__builtin_trap();
 
 	// One tile pass: 4 samples per lane of vector g, phases in tph; results in
 	// rx / ry (the caller stores them).
 	auto pass = [&](size_t g, const u32x4 tph, i32x4 &rx, i32x4 &ry) {
-		uint32_t P[kVec];
+		// pb = folded phase + 45 deg: bits 31..30 the quadrant q, bits 29..0
+		// r = p0 + 2^29.  Nothing below needs r on its own -- the bucket
+		// index is a bit field of pb, the compare and the residual work
+		// modulo 2^30 resp. 2^29 -- which saves the masking.
+		uint32_t pb[kVec];
 		if constexpr (FEED == Feed::Nco_ConstXY) {
 			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
-			P[0] = kp.phase0 + s0 * kp.fcw;
+			pb[0] = (kp.phase0 + 0x20000000u) + s0 * kp.fcw;
 #pragma unroll
 			for (int v = 1; v < kVec; v++)
-				P[v] = P[v - 1] + kp.fcw;
+				pb[v] = pb[v - 1] + kp.fcw;
 		} else {
-			left_justify(tph, P, kp.pw_shl);
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(pb[v])
+					: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
 		}
 
 		// three passes so that the four bucket reads, then the four seed
-		// reads, are in flight together (one s_waitcnt each, not eight)
+		// reads, are in flight together (one s_waitcnt each, not eight).
+		// Per sample: lshl_add, lshr, lshr, and | sub, bfe, lshl_add,
+		// mad_u24 | sub, bfe, lshl = 11 VALU instructions.
 		int64_t x[kVec], y[kVec], p[kVec];
-		uint32_t r[kVec], qoff[kVec];
-		u32x4 bk[kVec], se[kVec];
+		uint32_t q[kVec];
+		u32x2 bk[kVec];
+		u32x4 se[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
-			const uint32_t pb = P[v] + 0x20000000u;
-			qoff[v] = __umul24(pb >> 30, qstride) + seed_base;
-			r[v] = pb & 0x3fffffffu;		// p0 + 2^29
-			bk[v] = *(lds_entry *)(uintptr_t)((r[v] >> bshift) & ~15u);
+			q[v] = pb[v] >> 30;
+			bk[v] = *(lds_bucket *)(uintptr_t)((pb[v] >> bshift) & bmask);
 		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
-			// r >= bound  <=>  (bound-1) - r < 0
-			const uint32_t j16 = (bk[v][2] + ((bk[v][0] - r[v]) >> 31)
-						+ ((bk[v][1] - r[v]) >> 31)) << 4;
-			se[v] = *(lds_entry *)(uintptr_t)(qoff[v] + j16);
+			// r >= bound  <=>  (bound-1) - r < 0; the difference is
+			// smaller than a bucket, so its sign is also its bit 29, where
+			// the quadrant bits of pb do not reach
+			// (written out: the compiler's own selection is one
+			// instruction longer)
+			uint32_t c, a;
+			asm("v_bfe_u32 %0, %1, 29, 1" : "=v"(c) : "v"(bk[v][0] - pb[v]));
+			asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a) : "v"(c), "v"(bk[v][1]));
+			asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a)
+				: "v"(q[v]), "s"(qstride), "v"(a));
+			se[v] = *(lds_entry *)(uintptr_t)a;
 		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
@@ -933,13 +961,15 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				// as sext(residual) << 31: high word = bits 28..1 of the
 				// difference sign-extended (one v_bfe_i32), low word =
 				// bit 0 in bit 31
-				const uint32_t d = r[v] - se[v][0];
+				const uint32_t d = pb[v] - se[v][0];
 				const int32_t hi = __builtin_amdgcn_sbfe((int32_t)d, 1, 28);
 				p[v] = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (d << 31));
 			} else {
 				x[v] = (int64_t)se[v][0];
 				y[v] = (int64_t)se[v][1];
-				p[v] = (int64_t)(r[v] - se[v][2]);
+				// residual = (r - off) mod 2^30, sign extended
+				p[v] = (int64_t)__builtin_amdgcn_sbfe(
+					(int32_t)(pb[v] - se[v][2]), 0, 30);
 			}
 		}
 

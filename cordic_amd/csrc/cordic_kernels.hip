@@ -542,7 +542,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets,
 					j.seed_nleaves, queue};
 			// buckets, seeds and the three tile-id slots of the queue
-			const size_t lds = (size_t)j.seed_nbuckets * 16
+			const size_t lds = (size_t)j.seed_nbuckets * 8
 					+ (size_t)j.seed_nleaves * 4 * 16 + 16;
 			// blocks per CU: 32 waves and 160 KiB of LDS to share
 			int per_cu = 32 / (kSeedBlock / 64);

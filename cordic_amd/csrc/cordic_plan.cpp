@@ -9,7 +9,7 @@
 // splits into at most 2^M consecutive intervals ("leaves"), one per reachable
 // direction pattern, whose end points are exact integers (partial sums of
 // +/- a_i).  A kernel can therefore replace the first M micro-rotations by:
-// find the leaf of p0 (bucket table + at most two compares), fetch (x_M, y_M)
+// find the leaf of p0 (bucket table + one compare), fetch (x_M, y_M)
 // for (q, leaf) from a table that the kernel itself fills by running the exact
 // recurrence once per entry, and continue with stage M.  Results are
 // bit-identical for every phase; only the per-sample work changes.
@@ -17,8 +17,10 @@
 // This file builds the phase-side tables (they depend on the arctan table
 // only) as a flat array of 32-bit words:
 //   [0] M  [1] S (bucket shift)  [2] nbuckets  [3] nleaves
-//   buckets: nbuckets x {b1-1, b2-1, first_leaf, 0}   in the r-domain
-//            r = p0 + 2^29 in [0, 2^30); unused bounds are 0x7fffffff
+//   buckets: nbuckets x {bound-1, first_leaf}   in the r-domain
+//            r = p0 + 2^29 in [0, 2^30); a bucket holds at most ONE leaf
+//            boundary (the narrowest leaf of a real arctan table is ~0.85 *
+//            2^20 wide at M = 10, so S = 19 does); no boundary: 0x7fffffff
 //   leaves : nleaves  x {pattern (M bits, stage 0 = MSB), off + 2^29}
 //            where p_M = p0 - off
 #include <algorithm>
@@ -94,23 +96,26 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 			return 0;
 	}
 
-	// largest bucket (2^S phase units) holding at most two leaf boundaries
+	// largest bucket (2^S phase units) holding at most one leaf boundary
+	// (boundaries on a bucket edge do not count: they are the bucket's
+	// first_leaf)
 	int S = 26;
 	std::vector<int> count;
-	for (; S >= 18; S--) {
+	for (; S >= 17; S--) {
 		count.assign((size_t)1 << (30 - S), 0);
 		int worst = 0;
 		for (size_t j = 1; j < L; j++) {
 			const int64_t r = leaves[j].lo - LO;
-			worst = std::max(worst, ++count[(size_t)(r >> S)]);
+			if (r & (((int64_t)1 << S) - 1))
+				worst = std::max(worst, ++count[(size_t)(r >> S)]);
 		}
-		if (worst <= 2)
+		if (worst <= 1)
 			break;
 	}
-	if (S < 18)
+	if (S < 17)
 		return 0;
 	const size_t nb = (size_t)1 << (30 - S);
-	const size_t words = 4 + nb * 4 + L * 2;
+	const size_t words = 4 + nb * 2 + L * 2;
 	if (!buf || words > cap)
 		return 0;
 
@@ -120,10 +125,8 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	buf[3] = (uint32_t)L;
 	uint32_t *bk = buf + 4;
 	for (size_t b = 0; b < nb; b++) {
-		bk[4 * b + 0] = 0x7fffffffu;
-		bk[4 * b + 1] = 0x7fffffffu;
-		bk[4 * b + 2] = 0;
-		bk[4 * b + 3] = 0;
+		bk[2 * b + 0] = 0x7fffffffu;
+		bk[2 * b + 1] = 0;
 	}
 	// first_leaf[b] = leaf containing the first phase of bucket b
 	size_t j = 0;
@@ -131,20 +134,16 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 		const int64_t start = LO + ((int64_t)b << S);
 		while (j + 1 < L && leaves[j + 1].lo <= start)
 			j++;
-		bk[4 * b + 2] = (uint32_t)j;
+		bk[2 * b + 1] = (uint32_t)j;
 	}
 	for (size_t k = 1; k < L; k++) {
 		const int64_t r = leaves[k].lo - LO;		// boundary, r-domain
 		const size_t b = (size_t)(r >> S);
 		if ((r & (((int64_t)1 << S) - 1)) == 0)
 			continue;	// on a bucket edge: already in first_leaf
-		uint32_t *e = bk + 4 * b;
-		if (e[0] == 0x7fffffffu)
-			e[0] = (uint32_t)(r - 1);
-		else
-			e[1] = (uint32_t)(r - 1);
+		bk[2 * b] = (uint32_t)(r - 1);
 	}
-	uint32_t *lf = bk + 4 * nb;
+	uint32_t *lf = bk + 2 * nb;
 	for (size_t k = 0; k < L; k++) {
 		lf[2 * k + 0] = leaves[k].pattern;
 		lf[2 * k + 1] = (uint32_t)(leaves[k].off - LO);	// off + 2^29

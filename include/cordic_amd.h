@@ -279,7 +279,8 @@ int	cordic_plan_nco16(const cordic_plan *plan, size_t n,
 
 /* Host only: the phase-side seed table of a core as 32-bit words
  *   [0] stages M  [1] bucket shift S  [2] nbuckets  [3] nleaves
- *   nbuckets x {bound1-1, bound2-1, first_leaf, 0}   (r = phase + 2^29 domain)
+ *   nbuckets x {bound-1, first_leaf}   (r = phase + 2^29 domain; at most one
+ *            leaf boundary per bucket, 0x7fffffff where there is none)
  *   nleaves  x {direction pattern, offset + 2^29}
  * on the left-justified phase (phase << (32-PW)) after the octant fold.
  * Returns the number of words, or 0 if the core is not eligible / cap is too

@@ -456,9 +456,9 @@ def breakpoint_phases(cfg):
     pairs, as PW-bit phase values."""
     words = ca.seed_table(cfg)
     m, S, nb, L = (int(v) for v in words[:4])
-    buckets = words[4:4 + nb * 4].reshape(nb, 4).astype(np.int64)
+    buckets = words[4:4 + nb * 2].reshape(nb, 2).astype(np.int64)
     lsb = 1 << (32 - cfg.pw)
-    bounds = np.concatenate([buckets[:, 0], buckets[:, 1]])
+    bounds = buckets[:, 0]
     bounds = bounds[bounds != 0x7fffffff] + 1           # r-domain boundaries
     starts = (np.arange(nb, dtype=np.int64) << S)        # bucket edges too
     r = np.concatenate([bounds, starts, [0, (1 << 30) - lsb]])

@@ -15,8 +15,8 @@ CASES = [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
 
 def parse(words):
     m, S, nb, L = (int(v) for v in words[:4])
-    buckets = words[4:4 + nb * 4].reshape(nb, 4).astype(np.int64)
-    leaves = words[4 + nb * 4:4 + nb * 4 + L * 2].reshape(L, 2).astype(np.int64)
+    buckets = words[4:4 + nb * 2].reshape(nb, 2).astype(np.int64)
+    leaves = words[4 + nb * 2:4 + nb * 2 + L * 2].reshape(L, 2).astype(np.int64)
     return m, S, nb, L, buckets, leaves
 
 
@@ -54,10 +54,19 @@ def test_lookup_matches_recurrence(args):
     r = np.concatenate([r, np.array(extra, dtype=np.int64),
                         np.array([0, 1, (1 << 30) - 1], dtype=np.int64)])
     b = r >> S
-    t1 = buckets[b, 0] - r
-    t2 = buckets[b, 1] - r
-    j = buckets[b, 2] + (t1 < 0) + (t2 < 0)
+    # at most one leaf boundary per bucket: one compare
+    j = buckets[b, 1] + (buckets[b, 0] - r < 0)
     assert j.max() < L
+    # what the kernel does with it (cordic_device.h: rotator_seeded): a
+    # bucket without a boundary gets its last phase as the bound, and the
+    # compare is bit 29 of (bound-1) - pb with the quadrant bits still in pb
+    bound = np.where(buckets[:, 0] == 0x7fffffff,
+                     ((np.arange(nb, dtype=np.int64) + 1) << S) - 1,
+                     buckets[:, 0])
+    for q in range(4):
+        pb = r + (q << 30)
+        c = (((bound[b] - pb) & 0xffffffff) >> 29) & 1
+        assert np.array_equal(buckets[b, 1] + c, j)
     pat, pm = recurrence(r - (1 << 29), ang, m)
     assert np.array_equal(leaves[j, 0], pat)
     off = leaves[j, 1] - (1 << 29)
