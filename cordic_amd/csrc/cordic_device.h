@@ -1066,24 +1066,31 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			slot[1] = resolve(draw());
 		}
 		lds_barrier();
-		uint32_t cur = slot[0];
+		// Tile ids are block-uniform: kept in SGPRs (readfirstlane), so the
+		// tile's base addresses are scalar arithmetic and the per-lane part
+		// of every address is the constant 32-bit offset threadIdx.x * 16
+		// (global_load / global_store with an SGPR base) -- no 64-bit VALU
+		// address arithmetic in the pass.
+		uint32_t cur = __builtin_amdgcn_readfirstlane(slot[0]);
 		int ring = 0;
-		typename IO::uvec nph{};
-		if constexpr (FEED != Feed::Nco_ConstXY) {
-			const size_t g0 = (size_t)cur * kSeedBlock + threadIdx.x;
-			if (cur != kEnd && g0 < nvec)
-				nph = CORDIC_LOAD_IN(&phin[g0]);
-		}
+		const uint32_t lane = threadIdx.x;
+		// vectors of the tile that exist (only the batch's last tile is partial)
+		const uint32_t last_live = (uint32_t)(nvec - (size_t)(ntiles - 1) * kSeedBlock);
+		auto live = [&](uint32_t tile) -> uint32_t {
+			return tile == ntiles - 1 ? last_live : (uint32_t)kSeedBlock;
+		};
+		// One pass over tile `cur` with its phases in `in`; the phases of the
+		// next tile are prefetched into `pre` (which may be `in` itself: the
+		// phases are widened into registers first).
 		// (Storing the results one pass late, so that the compiler's
 		// vmcnt(0) wait for the prefetch never meets a young store, measured
 		// no gain: same-box A/B in profiles/r02/ab_delayed_stores.txt.)
-		while (cur != kEnd) {
-			const uint32_t nxt = slot[(ring + 1) % 3];
-			const u32x4 tph = IO::widen(nph);
+		auto tile_pass = [&](const typename IO::uvec &in, typename IO::uvec &pre) {
+			const uint32_t nxt = __builtin_amdgcn_readfirstlane(slot[(ring + 1) % 3]);
+			const u32x4 tph = IO::widen(in);
 			if constexpr (FEED != Feed::Nco_ConstXY) {
-				const size_t gn = (size_t)nxt * kSeedBlock + threadIdx.x;
-				if (nxt != kEnd && gn < nvec)
-					nph = CORDIC_LOAD_IN(&phin[gn]);
+				if (nxt != kEnd && lane < live(nxt))
+					pre = CORDIC_LOAD_IN(&(phin + (size_t)nxt * kSeedBlock)[lane]);
 			}
 			// the ticket for the tile after next: drawn now (behind the
 			// prefetch, so that nothing waits for it here), looked at after
@@ -1091,19 +1098,29 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			uint32_t ahead = 0;
 			if (threadIdx.x == 0)
 				ahead = draw();
-			const size_t g = (size_t)cur * kSeedBlock + threadIdx.x;
-			if (g < nvec) {		// only the batch's last tile is partial
+			if (lane < live(cur)) {
+				const size_t base = (size_t)cur * kSeedBlock;
 				i32x4 rx, ry;
-				pass(g, tph, rx, ry);
-				CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
-				CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
+				pass(base + lane, tph, rx, ry);
+				CORDIC_STORE_OUT(false, &(ox + base)[lane], IO::narrow(rx));
+				CORDIC_STORE_OUT(false, &(oy + base)[lane], IO::narrow(ry));
 			}
 			if (threadIdx.x == 0)
 				slot[(ring + 2) % 3] = resolve(ahead);
 			lds_barrier();
 			cur = nxt;
 			ring = (ring + 1) % 3;
+		};
+		typename IO::uvec pa{};
+		if constexpr (FEED != Feed::Nco_ConstXY) {
+			if (cur != kEnd && lane < live(cur))
+				pa = CORDIC_LOAD_IN(&(phin + (size_t)cur * kSeedBlock)[lane]);
 		}
+		// (Alternating two register sets, so that the compiler needs no
+		// copies between passes, doubles the loop body: -8 % on the 24-stage
+		// core, nothing elsewhere -- profiles/r02/ab_pingpong.txt.)
+		while (cur != kEnd)
+			tile_pass(pa, pa);
 		if (threadIdx.x == 0)
 			queue_leave(sa.queue);
 		return;
