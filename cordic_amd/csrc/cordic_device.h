@@ -1295,6 +1295,31 @@ template <int NLIVE, int I, bool DYN> struct PolChainLJ {
 	}
 };
 
+// Stage 1 on the left-justified pairs: (y >>> 1) is bits 62..31 of y~, one
+// v_alignbit_b32 (the value fits 32 bits because y does).
+__device__ __forceinline__ void pol_stage1_lj(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a, const PolLjRegs &c)
+{
+	const uint32_t yh = (uint32_t)((uint64_t)y >> 32);
+	const uint32_t xh = (uint32_t)((uint64_t)x >> 32);
+	const int32_t t = (int32_t)op_and_or(yh, c.p30, c.sign);
+	const int32_t nt = (int32_t)((uint32_t)t ^ c.sign);
+	const int32_t sy = (int32_t)__builtin_amdgcn_alignbit(yh, (uint32_t)y, 31);
+	const int32_t sx = (int32_t)__builtin_amdgcn_alignbit(xh, (uint32_t)x, 31);
+	op_mad(x, sy, t);
+	op_mad(y, sx, nt);
+	op_mad_s(p, a, t);
+}
+
+// acc = a * b (v_mad_i64_i32 with the inline constant 0 as addend: no zeroed
+// register pair)
+__device__ __forceinline__ int64_t op_mul(int32_t a, int32_t b)
+{
+	int64_t d;
+	asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+	return d;
+}
+
 template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 		const typename IO::ivec *__restrict__ xin,
@@ -1305,6 +1330,11 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	PolLjRegs c;
 	c.sign = vgpr_const(0x80000000u);
 	c.p30 = vgpr_const(0x40000000u);
+	// rounding at the 2^30 scale: the retained bits start at bit r-2 of the
+	// high word (cores with r < 2 take the 32-bit form below)
+	const uint32_t rbw = vgpr_const(kp.round_bit);	// width of the tie bit: 0 or 1
+	const int up = 32 - kp.iw;			// port -> sign bit of the word
+	const int down = up - kp.in_shl;		// ... and back to e = i << in_shl
 
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1321,37 +1351,63 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 			ny = yin[gn];
 		}
 		int64_t x[kVec], y[kVec], p[kVec];
-		uint32_t p1[kVec];
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
-			const int32_t ix = sext32(tx[v], kp.iw);
-			const int32_t iy = sext32(ty[v], kp.iw);
-			const int32_t ex = (int32_t)((uint32_t)ix << kp.in_shl);
-			const int32_t ey = (int32_t)((uint32_t)iy << kp.in_shl);
-			int32_t fx, fy;
-			uint32_t p0;
-			fold_quadrant_masks<int32_t>(ex, ey, ix, iy, fx, fy, p0);
-			// stage 1 (shift 1) on the 32-bit values, rtl/topolar.v:226-243
-			const uint32_t d = (uint32_t)(fy >> 31);
-			const int32_t sy = fy >> 1, sx = fx >> 1;
-			const int32_t x1 = fx + (int32_t)(((uint32_t)sy ^ d) - d);	// x + t*sy
-			const int32_t y1 = fy - (int32_t)(((uint32_t)sx ^ d) - d);	// y - t*sx
-			p1[v] = kp.nlive > 0 ? p0 + ((kp.angle[0] ^ d) - d) : p0;	// p + t*a_0
-			x[v] = (int64_t)((uint64_t)(int64_t)x1 << 30);
-			y[v] = (int64_t)((uint64_t)(int64_t)y1 << 30);
-			p[v] = 0;
+			// e = sext(i, IW) << in_shl  (rtl/topolar.v:83-84, 122-123)
+			const int32_t ex = (int32_t)((uint32_t)tx[v] << up) >> down;
+			const int32_t ey = (int32_t)((uint32_t)ty[v] << up) >> down;
+			// rtl/topolar.v:122-152 as four multiply-adds.  With sx, sy =
+			// +1 / -1 the signs of e_x, e_y (zero counts as +, as in the
+			// case arms):  x0 = |e_x| + |e_y| = e_x sx + e_y sy;  y0 =
+			// |e_y| - |e_x| where the signs agree, |e_x| - |e_y| where not
+			// = e_y sx - e_x sy.  The multipliers +/-2^30 come off the sign
+			// bits (one v_bitop3_b32 each) and leave x0, y0 left-justified
+			// where the stages want them.
+			const int32_t mx = (int32_t)op_and_or((uint32_t)ex, c.p30, c.sign);
+			const int32_t my = (int32_t)op_and_or((uint32_t)ey, c.p30, c.sign);
+			const int32_t nmy = (int32_t)((uint32_t)my ^ c.sign);
+			x[v] = op_mul(ex, mx);
+			op_mad(x[v], ey, my);
+			y[v] = op_mul(ey, mx);
+			op_mad(y[v], ex, nmy);
+			// p0 = {1,7,3,5} * 2^29 for {++,+-,-+,--}
+			//    = 2^31 - 2^29 sy (2 + sx)   (mod 2^32),
+			// carried like the stage angles at the 2^30 scale: the product
+			// of -sy 2^30 (at hand) and 2^29 (2 + sx) = (mx ^ 2^31) >>> 1;
+			// the 2^31 joins in the final add.
+			const uint32_t l = ((uint32_t)mx ^ c.sign) >> 1;
+			p[v] = op_mul(nmy, (int32_t)l);
 		}
+#pragma unroll
+		for (int v = 0; v < kVec; v++)		// rtl/topolar.v:226-243, k = 1
+			pol_stage1_lj(x[v], y[v], p[v], kp.angle[0], c);
 
 		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp);
 
 		i32x4 rm;
 		u32x4 rp;
+		if (kp.r >= 2) {
+			// rtl/topolar.v:251-263 at the 2^30 scale: tie bit r of x is
+			// bit r-2 of the high word
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				const uint32_t xh = (uint32_t)((uint64_t)x[v] >> 32);
+				uint32_t b;
+				asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(b)
+					: "v"(xh), "s"(kp.r - 2), "v"(rbw));
+				op_mad_s(x[v], 0x40000000u, (int32_t)(b + (uint32_t)kp.round_base));
+				rm[v] = (int32_t)((uint64_t)x[v] >> 32) >> (kp.r - 2);
+			}
+		} else {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				rm[v] = round_to_ow<int32_t>((int32_t)(x[v] >> 30), kp);
+		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
-			rm[v] = round_to_ow<int32_t>((int32_t)(x[v] >> 30), kp);
-			// sum of t*a_k over the stages 2.., accumulated at 2^30
+			// p0 - 2^31 + sum of t*a_k over the stages, accumulated at 2^30
 			const uint32_t acc = (uint32_t)((uint64_t)p[v] >> 30);
-			rp[v] = (p1[v] + acc) >> kp.pw_shl;	// rtl/topolar.v:269
+			rp[v] = (acc + 0x80000000u) >> kp.pw_shl;	// rtl/topolar.v:269
 		}
 		apply_unit_gain<UG>(rm, kp);
 		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
