@@ -13,6 +13,8 @@
 #   sweep      every bench.py workload x {ramp, random} + the default line
 #   states     alternate copy probe / bench while logging clocks and power
 #   ab:<flags> build a second library with HIPFLAGS_EXTRA=<flags> and A/B it
+#   power      rocm-smi power / sclk sampled WHILE each workload runs 6000 steps
+#              [POWER_WORKLOADS="cfg5 cfg2 ..."]
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -42,6 +44,19 @@ for task in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']), round(d['roofline']['frac'],3), d['roofline'].get('copy_frac'))" >> $log
 			snap >> $log
+		done ;;
+	power)	# is a kernel power-limited?  sample while it runs (steady state: ~8 s in)
+		for w in ${POWER_WORKLOADS:-cfg5 cfg2 cfg4 cfg1 cfg3 p2rxy quadtbl}; do
+			echo "== $w" >> $log
+			python bench.py --workload $w --steps 6000 --warmup 5 --no-cpu-baseline --no-other-paths \
+				--no-pmc --no-copy-probe > gpurun_out/power_$w.json 2>/dev/null &
+			pid=$!
+			sleep 8
+			for i in 1 2 3 4; do snap >> $log; sleep 0.5; done
+			wait $pid
+			python -c "
+import json
+d=json.loads(open('gpurun_out/power_$w.json').readline()); print('   value', round(d['value']), round(d['roofline']['frac'],3))" >> $log
 		done ;;
 	ab)
 		make -C cordic_amd/csrc -j8 BUILD=build_ab OUT=$PWD/cordic_amd/lib_ab.so HIPFLAGS_EXTRA="$arg" > gpurun_out/ab_build.log 2>&1

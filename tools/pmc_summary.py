@@ -5,6 +5,13 @@ gpurun_out/prof/<tag>/summary.json (+ the kernel_stats.csv next to it).
 HBM bytes per launch = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024: both counters
 are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced
 read (MI355X_MICROARCH.md, section HBM), WRITE_SIZE is taken as reported.
+
+Shader clock under the kernel's own load: GRBM_GUI_ACTIVE is reported summed
+over the 8 XCDs (SQ_BUSY_CYCLES, summed over the 32 shader engines, is 3.9-4.0
+times it), so GRBM_GUI_ACTIVE / 8 / (End - Start of the same dispatch in the
+same pass) is the clock the chip sustained; the LAST dispatch of the pass is
+taken (the first ones ramp up).  valu_cycles_per_inst = those cycles / the
+VALU instructions one SIMD issued (SQ_INSTS_VALU / 1024 SIMDs).
 """
 import collections
 import csv
@@ -59,5 +66,22 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"),
         if sk and sk in res["kernels"]:
             res["kernels"][sk]["kernel_trace_avg_ns"] = float(row["AverageNs"])
             res["kernels"][sk]["kernel_trace_calls"] = int(row["Calls"])
+# clock and issue rate from the pass that collected GRBM_GUI_ACTIVE
+for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"),
+                   recursive=True):
+    last = {}
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            last[row["Kernel_Name"]] = (float(row["Counter_Value"]),
+                                        int(row["End_Timestamp"])
+                                        - int(row["Start_Timestamp"]))
+    for k, (cyc, dur) in last.items():
+        sk = short(k)
+        if sk and sk in res["kernels"] and dur > 0:
+            e = res["kernels"][sk]
+            e["pmc_pass_last_dispatch_ns"] = dur
+            e["shader_clock_ghz"] = cyc / 8.0 / dur
+            if e.get("SQ_INSTS_VALU"):
+                e["valu_cycles_per_inst"] = (cyc / 8.0) / (e["SQ_INSTS_VALU"] / 1024.0)
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
