@@ -261,6 +261,12 @@ def from_profile(key, samples_per_launch=1 << 30):
     if "SQ_INSTS_VALU" in e:
         out["valu_instr_per_sample"] = (e["SQ_INSTS_VALU"] * 64.0
                                         / samples_per_launch)
+    # clock the chip sustained under this kernel (GRBM_GUI_ACTIVE / 8 XCDs /
+    # dispatch duration of the PMC pass; the kernels run at the 1400 W socket
+    # limit) and VALU issue interval per SIMD at that clock
+    for k in ("shader_clock_ghz", "valu_cycles_per_inst"):
+        if k in e:
+            out[k] = round(e[k], 3)
     return out
 
 
