@@ -297,7 +297,7 @@ def measure_pmc(args):
     base = [sys.executable, os.path.abspath(__file__), "--workload",
             args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
             str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
-            "--no-other-paths", "--no-copy-probe", "--no-pmc"]
+            "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks)):
         if on:
@@ -330,6 +330,84 @@ def measure_pmc(args):
 
 
 _probe_lib = None
+
+
+class PowerSampler(threading.Thread):
+    """Socket power and shader clock of one GPU while it works, read by a host
+    thread from the amdgpu hwmon files of THAT device (matched by PCI bus id):
+    power1_input (microwatts), freq1_input (sclk, Hz), power1_cap (the limit).
+    Plain file reads: nothing is launched on the GPU and no tool is started,
+    so the timed region is not disturbed.  The CORDIC kernels turn out to run
+    at the power limit with the clock below its 2.4 GHz maximum (DESIGN.md
+    4.7); this puts the evidence into the bench line itself."""
+
+    def __init__(self, device, period=0.002):
+        super().__init__(daemon=True)
+        self.period = period
+        self.dir = self._find(device)
+        self.rows = []                  # (t, watts, sclk MHz)
+        self._halt = threading.Event()
+
+    @staticmethod
+    def _bus_id(device):
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+                return None
+            return buf.value.decode().lower()
+        except OSError:
+            return None
+
+    @classmethod
+    def _find(cls, device):
+        import glob
+        cands = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+        cands = [c for c in cands
+                 if os.path.exists(os.path.join(c, "power1_input"))
+                 and os.path.exists(os.path.join(c, "freq1_input"))]
+        bus = cls._bus_id(device)
+        for c in cands:
+            real = os.path.realpath(os.path.dirname(os.path.dirname(c))).lower()
+            if bus and real.endswith(bus):
+                return c
+        return cands[0] if len(cands) == 1 else None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def run(self):
+        while not self._halt.is_set():
+            try:
+                self.rows.append((time.perf_counter(),
+                                  self._read("power1_input") / 1e6,
+                                  self._read("freq1_input") / 1e6))
+            except (OSError, ValueError):
+                pass
+            time.sleep(self.period)
+
+    def stop(self):
+        self._halt.set()
+        self.join()
+
+    def window(self, t0, t1):
+        """Statistics of the samples taken in [t0, t1]."""
+        w = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not w:
+            return None
+        pw = sorted(r[1] for r in w)
+        ck = sorted(r[2] for r in w)
+        return {"samples": len(w), "seconds": t1 - t0,
+                "socket_w_median": pw[len(pw) // 2], "socket_w_max": pw[-1],
+                "sclk_mhz_median": ck[len(ck) // 2], "sclk_mhz_min": ck[0]}
+
+    def limit_w(self):
+        try:
+            return self._read("power1_cap") / 1e6
+        except (OSError, ValueError):
+            return None
 
 
 def hbm_probe(in0, in1, out0, out1, nwords, r, w, mode, reps, stream=0):
@@ -560,6 +638,8 @@ def run_group(args, w, launch):
     kind = w["kind"]
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
+    if args.no_placement:
+        grp.set_placement(False)
     seeded = False
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
         seeded = ca.Plan(cfg).seed_info["stages"] > 0
@@ -610,6 +690,14 @@ def run_group(args, w, launch):
         with torch.cuda.device(devices[0]):
             probes.append(copy_probe(ptrs, n, RW[kind]))
 
+    sampler = None
+    if rank == 0 and not args.no_power:
+        sampler = PowerSampler(devices[0])
+        if sampler.dir is None:
+            sampler = None
+        else:
+            sampler.start()
+
     for _ in range(args.warmup):
         step(grp)
     barrier()
@@ -627,6 +715,28 @@ def run_group(args, w, launch):
             marks.append(k + 1)
     barrier()
     elapsed = time.perf_counter() - t0
+    power = None
+    if sampler is not None:
+        # the timed region is short (the governor is still settling); keep
+        # the same kernel going for two more seconds and sample that as well
+        t1 = time.perf_counter()
+        ms_step = elapsed / args.steps
+        more = max(1, min(4000, int(2.0 / max(ms_step, 1e-6))))
+        for _ in range(more):
+            step(grp)
+        grp.sync()
+        t2 = time.perf_counter()
+        sampler.stop()
+        power = {"source": "amdgpu hwmon of the device (power1_input, "
+                           "freq1_input), host thread, every 2 ms",
+                 "limit_w": sampler.limit_w(),
+                 "timed_region": sampler.window(t0, t1),
+                 "sustained": sampler.window(t1 + (t2 - t1) / 2, t2)}
+        if power["sustained"]:
+            # for information only: `value` is the K timed steps above
+            power["sustained"]["steps"] = more
+            power["sustained"]["msamples_per_s_local_shards"] = (
+                float(nlocal) * n * more / (t2 - t1) / 1e6)
     per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -730,6 +840,7 @@ def run_group(args, w, launch):
         with torch.cuda.device(devices[0]):
             probes.append(copy_probe(ptrs, n, RW[kind]))
 
+    grp_placement = grp.placement(0)
     grp.close()
     single = None
     if (launch == "torchrun" and not args.no_single_process_check
@@ -761,6 +872,15 @@ def run_group(args, w, launch):
             "kernel_ms_min": float(min(span_ms)),
             "kernel_ms_max": float(max(span_ms)),
         }
+        if power is not None:
+            roof["power"] = power
+        # which of its candidate allocations the group gave which role
+        # (cordic_group placement: include/cordic_amd.h)
+        roof["placement"] = dict(
+            grp_placement,
+            what="arrays allocated +2 spare, arithmetic-free probes of the "
+                 "job's traffic over the role assignments, best kept "
+                 "(--no-placement: as hipMalloc hands them out)")
         if not args.no_pmc and total == 1:
             try:
                 pm = measure_pmc(args)
@@ -888,7 +1008,7 @@ def single_process_block(args, ndev, expect):
            str(args.steps), "--warmup", str(args.warmup), "--log2-samples",
            str(args.log2_samples), "--input", args.input, "--gather",
            "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
-           "--no-pmc"]
+           "--no-pmc", "--no-power"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks)):
         if on:
@@ -1231,6 +1351,12 @@ def main():
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="take the group's arrays as hipMalloc hands them out "
+                         "instead of probing candidate allocations")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the hwmon power / clock samples and the two "
+                         "seconds of sustained running behind the timed region")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip measuring roofline.traffic (two rocprofv3 --pmc "
                     "passes, FETCH_SIZE and WRITE_SIZE, over a 3-step run of "

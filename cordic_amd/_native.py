@@ -122,6 +122,10 @@ ABI = {
                                      C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint64)]),
     "cordic_group_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "cordic_group_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
+    "cordic_group_placement": (C.c_int, [C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+                               + [C.POINTER(C.c_float)] * 4),
     "cordic_group_fill_phase_ramp": (C.c_int, [C.c_void_p, C.c_uint64,
                                                C.c_int]),
     "cordic_group_fill_iq_ramp": (C.c_int, [C.c_void_p, C.c_uint64,
@@ -436,6 +440,24 @@ class Group:
         _check(lib().cordic_group_set_gather(self._h, root_device, addr(out0),
                                              addr(out1), chunks),
                "cordic_group_set_gather")
+
+    def set_placement(self, enable):
+        _check(lib().cordic_group_set_placement(self._h, 1 if enable else 0),
+               "cordic_group_set_placement")
+
+    def placement(self, local_shard=0):
+        """What the last allocation of the shard's arrays saw."""
+        c, p = C.c_int(), C.c_int()
+        wb, ww, b, w = (C.c_float() for _ in range(4))
+        _check(lib().cordic_group_placement(self._h, local_shard, C.byref(c),
+                                            C.byref(p), C.byref(wb),
+                                            C.byref(ww), C.byref(b),
+                                            C.byref(w)),
+               "cordic_group_placement")
+        return {"candidates": c.value, "probes": p.value,
+                "written_pair_best_ms": wb.value,
+                "written_pair_worst_ms": ww.value,
+                "best_ms": b.value, "worst_ms": w.value}
 
     def rccl_init(self, unique_id):
         """Join the job's RCCL communicator (collective over all shards);

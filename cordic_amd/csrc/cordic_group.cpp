@@ -14,6 +14,18 @@
 // librccl is opened at run time, on first use, so programs that never gather
 // across processes do not depend on it.
 //
+// Placement.  What HBM delivers to a job's streams depends on WHICH allocations
+// they run over: pure read or pure write sweeps reach 0.89 of the 8 TB/s peak
+// on every 4 GiB hipMalloc alike, but the same 1R2W stream over different
+// choices of three out of eight such arrays ranges from 0.75 to 0.82 -- a
+// property of the combination (the two written arrays most of all), stable
+// for the life of the allocations, not predictable from the virtual addresses
+// (tools/hbm_alloc_probe*.py, profiles/r02/hbm_placement.txt).  Since the
+// group owns its arrays it can choose: when it allocates the arrays of a
+// shard it allocates two more than it needs, times the arithmetic-free twin of
+// the job's traffic (launch_stream_probe) over the candidate assignments,
+// keeps the best and frees the rest.
+//
 // The reference has nothing of the kind (bench/cpp/cordic_tb.cpp:127-178 steps
 // one model from one thread), so there is no reference text to follow here.
 #include <hip/hip_runtime_api.h>
@@ -48,7 +60,14 @@ struct Shard {
 	hipEvent_t marks[kMaxMarks] = {};
 	hipEvent_t piece[kMaxChunks] = {};
 	ncclComm_t comm = nullptr;	// rank = index of total (cordic_group_rccl_init)
+	// what the last placement of this shard's arrays saw
+	int	place_candidates = 0, place_probes = 0;
+	float	place_best_ms = 0.f, place_worst_ms = 0.f;	// the job's full pattern
+	float	place_wbest_ms = 0.f, place_wworst_ms = 0.f;	// its written pair (0R2W)
 };
+
+constexpr uint64_t kPlaceMinWords = (uint64_t)1 << 24;	// arrays of 64 MiB and up
+constexpr int kPlaceSpare = 2;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
 struct Rccl {
@@ -113,6 +132,7 @@ struct cordic_group {
 	int32_t	*g0 = nullptr, *g1 = nullptr;
 	int	chunks = 1;
 	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
+	bool	placement = true;
 };
 
 namespace {
@@ -143,6 +163,104 @@ void release(Shard &s)
 	s = Shard{};
 }
 
+// Average milliseconds of the `reads`R 2W probe over the given arrays on the
+// shard's compute stream (one warm-up launch, two timed), or a negative value.
+float probe_ms(Shard &s, int reads, const void *r0, const void *r1, void *w0,
+		void *w1, uint64_t words)
+{
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	float ms = -1.f;
+	if (ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))
+	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
+	    && ok(hipEventRecord(e0, s.compute))
+	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
+	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
+	    && ok(hipEventRecord(e1, s.compute)) && ok(hipEventSynchronize(e1))
+	    && ok(hipEventElapsedTime(&ms, e0, e1)))
+		ms *= 0.5f;
+	else
+		ms = -1.f;
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return ms;
+}
+
+// Hand the arrays of `pool` (more than needed) to the roles of `need` so that
+// the job's streams run fastest: first the two written arrays (every pair,
+// 0R2W), then the read ones over what is left (1R2W each, or every pair 2R2W).
+// Arrays left in the pool afterwards are the caller's to free.  Falls back to
+// "in order" if a probe cannot run.
+void place(Shard &s, const std::vector<int> &need, std::vector<void *> &pool,
+		uint64_t words)
+{
+	auto take = [&](int role, size_t k) {
+		s.buf[role] = pool[k];
+		pool.erase(pool.begin() + (long)k);
+	};
+	auto in_order = [&]() {
+		for (int role : need)
+			if (!s.buf[role])
+				take(role, 0);
+	};
+	s.place_candidates = (int)pool.size();
+	s.place_probes = 0;
+	s.place_best_ms = s.place_worst_ms = 0.f;
+	s.place_wbest_ms = s.place_wworst_ms = 0.f;
+	const bool outs = !s.buf[2] && !s.buf[3];
+	if (!outs) {		// results of an earlier job may live there: no probing
+		in_order();
+		return;
+	}
+	float best = -1.f, worst = 0.f;
+	size_t bi = 0, bj = 1;
+	for (size_t i = 0; i < pool.size(); i++)
+		for (size_t j = i + 1; j < pool.size(); j++) {
+			const float ms = probe_ms(s, 0, nullptr, nullptr, pool[i], pool[j], words);
+			if (ms < 0.f) {
+				(void)hipGetLastError();
+				in_order();
+				return;
+			}
+			s.place_probes++;
+			if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
+			if (ms > worst) worst = ms;
+		}
+	take(3, bj);		// the larger index first: bi stays valid
+	take(2, bi);
+	s.place_wbest_ms = s.place_best_ms = best;
+	s.place_wworst_ms = s.place_worst_ms = worst;
+	std::vector<int> ins;
+	for (int role : need)
+		if (role < 2)
+			ins.push_back(role);
+	if (ins.empty())
+		return;
+	best = -1.f; worst = 0.f; bi = 0; bj = 1;
+	if (ins.size() == 1) {
+		for (size_t i = 0; i < pool.size(); i++) {
+			const float ms = probe_ms(s, 1, pool[i], nullptr, s.buf[2], s.buf[3], words);
+			if (ms < 0.f) { (void)hipGetLastError(); in_order(); return; }
+			s.place_probes++;
+			if (best < 0.f || ms < best) { best = ms; bi = i; }
+			if (ms > worst) worst = ms;
+		}
+		take(ins[0], bi);
+	} else {
+		for (size_t i = 0; i < pool.size(); i++)
+			for (size_t j = i + 1; j < pool.size(); j++) {
+				const float ms = probe_ms(s, 2, pool[i], pool[j], s.buf[2], s.buf[3], words);
+				if (ms < 0.f) { (void)hipGetLastError(); in_order(); return; }
+				s.place_probes++;
+				if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
+				if (ms > worst) worst = ms;
+			}
+		take(ins[1], bj);
+		take(ins[0], bi);
+	}
+	s.place_best_ms = best;		// of the job's full pattern
+	s.place_worst_ms = worst;
+}
+
 int ensure(cordic_group *g, uint64_t n_total, int inputs)
 {
 	for (Shard &s : g->shards) {
@@ -157,16 +275,39 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			return CORDIC_ERR_DEVICE;
 		const uint64_t cap = cnt > s.cap ? cnt : s.cap;
 		const int nin = inputs > s.inputs ? inputs : s.inputs;
+		std::vector<int> need;
 		for (int a = 0; a < 4; a++) {
 			const bool wanted = (a >= 2) || (a < nin);
 			if (s.buf[a] && cap > s.cap) {
 				(void)hipFree(s.buf[a]);
 				s.buf[a] = nullptr;
 			}
-			if (wanted && !s.buf[a] &&
-			    !ok(hipMalloc(&s.buf[a], (cap ? cap : 1) * 4)))
-				return CORDIC_ERR_DEVICE;
+			if (wanted && !s.buf[a])
+				need.push_back(a);
 		}
+		const bool tune = g->placement && cap >= kPlaceMinWords && !need.empty();
+		std::vector<void *> pool;
+		const size_t want = need.size() + (tune ? (size_t)kPlaceSpare : 0);
+		for (size_t k = 0; k < want; k++) {
+			void *p = nullptr;
+			if (!ok(hipMalloc(&p, (cap ? cap : 1) * 4))) {
+				(void)hipGetLastError();
+				if (k >= need.size())
+					break;		// no room for spares: place what there is
+				for (void *q : pool) (void)hipFree(q);
+				return CORDIC_ERR_DEVICE;
+			}
+			pool.push_back(p);
+		}
+		if (tune && pool.size() > need.size()) {
+			place(s, need, pool, cap);
+		} else {
+			for (int role : need) {
+				s.buf[role] = pool.front();
+				pool.erase(pool.begin());
+			}
+		}
+		for (void *q : pool) (void)hipFree(q);
 		s.cap = cap;
 		s.inputs = nin;
 	}
@@ -323,6 +464,8 @@ int cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices
 	g->cfg = *cfg;
 	g->first = first_shard;
 	g->total = total_shards;
+	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
+		g->placement = !(e[0] == '0' && e[1] == 0);
 	DeviceScope scope;
 	g->shards.resize((size_t)nlocal);
 	int rc = CORDIC_OK;
@@ -368,6 +511,30 @@ int cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs)
 		return CORDIC_ERR_ARGS;
 	DeviceScope scope;
 	return ensure(grp, n_total, inputs);
+}
+
+int cordic_group_set_placement(cordic_group *grp, int enable)
+{
+	if (!grp)
+		return CORDIC_ERR_ARGS;
+	grp->placement = enable != 0;
+	return CORDIC_OK;
+}
+
+int cordic_group_placement(const cordic_group *grp, int local_shard, int *candidates,
+		int *probes, float *written_best_ms, float *written_worst_ms,
+		float *best_ms, float *worst_ms)
+{
+	if (!grp || local_shard < 0 || local_shard >= (int)grp->shards.size())
+		return CORDIC_ERR_ARGS;
+	const Shard &s = grp->shards[(size_t)local_shard];
+	if (candidates) *candidates = s.place_candidates;
+	if (probes) *probes = s.place_probes;
+	if (written_best_ms) *written_best_ms = s.place_wbest_ms;
+	if (written_worst_ms) *written_worst_ms = s.place_wworst_ms;
+	if (best_ms) *best_ms = s.place_best_ms;
+	if (worst_ms) *worst_ms = s.place_worst_ms;
+	return CORDIC_OK;
 }
 
 int cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift)

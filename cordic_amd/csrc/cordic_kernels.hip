@@ -791,6 +791,54 @@ int launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 	return check_launch();
 }
 
+// Arithmetic-free stand-in for a job's memory traffic: R arrays read, W arrays
+// written, 16 bytes per lane, one 256-thread block per 4 KiB tile, tiles dealt
+// XCD-contiguously -- the best streaming pattern found on MI355X (DESIGN.md
+// 4.3).  cordic_group times it over candidate arrays to decide which
+// allocation plays which role (cordic_group.cpp: placement).  The written
+// arrays are overwritten.
+template <int R, int W>
+__global__ __launch_bounds__(256) void stream_probe(const dev::u32x4 *__restrict__ a,
+		const dev::u32x4 *__restrict__ b, dev::u32x4 *__restrict__ c,
+		dev::u32x4 *__restrict__ d, size_t nvec, int xcd)
+{
+	size_t t = blockIdx.x;
+	if (xcd)
+		t = (size_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	const size_t g = t * 256 + threadIdx.x;
+	if (g >= nvec)
+		return;
+	dev::u32x4 v = dev::u32x4{(uint32_t)g, 1, 2, 3};
+	if (R >= 1) v = a[g];
+	if (R >= 2) v += b[g];
+	if (W >= 1) c[g] = v;
+	if (W >= 2) d[g] = v + 1;
+}
+
+int launch_stream_probe(int reads, int writes, const void *r0, const void *r1,
+		void *w0, void *w1, size_t nwords, void *stream)
+{
+	clear_stale_error();
+	const size_t nvec = nwords / 4;
+	if (nvec == 0)
+		return CORDIC_OK;
+	const size_t blocks = (nvec + 255) / 256;
+	if (blocks > 0x7fffffffu)
+		return CORDIC_ERR_ARGS;
+	const int xcd = (blocks % 8 == 0) ? 1 : 0;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	auto go = [&](auto kern) {
+		hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st,
+			static_cast<const dev::u32x4 *>(r0), static_cast<const dev::u32x4 *>(r1),
+			static_cast<dev::u32x4 *>(w0), static_cast<dev::u32x4 *>(w1), nvec, xcd);
+	};
+	if (reads == 0 && writes == 2) go(stream_probe<0, 2>);
+	else if (reads == 1 && writes == 2) go(stream_probe<1, 2>);
+	else if (reads == 2 && writes == 2) go(stream_probe<2, 2>);
+	else return CORDIC_ERR_ARGS;
+	return check_launch();
+}
+
 int launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream)
 {

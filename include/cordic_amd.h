@@ -502,6 +502,25 @@ int	cordic_group_range(const cordic_group *grp, uint64_t n_total, int shard,
 /* (re)allocate the shards' buffers for jobs of n_total samples with `inputs`
  * (0, 1 or 2) input arrays; job calls do this implicitly on first use */
 int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
+/* Placement of the shards' arrays.  What HBM delivers to a job's streams
+ * depends on which allocations they run over (a property of the combination of
+ * arrays, stable for their lifetime, not visible in the addresses: 0.75-0.82 of
+ * the 8 TB/s peak for one and the same 1R2W stream, profiles/r02/
+ * hbm_placement.txt).  When a group allocates arrays of 64 MiB or more it
+ * therefore allocates two more than it needs, times an arithmetic-free twin of
+ * the job's traffic over the candidate role assignments (tens of
+ * milliseconds, once per allocation), keeps the fastest and frees the rest.
+ * On by default; cordic_group_set_placement(grp, 0) before the first
+ * reserve / job call, or CORDIC_GROUP_PLACEMENT=0 in the environment, takes
+ * the arrays as hipMalloc hands them out.  cordic_group_placement reports
+ * what the last allocation of a shard saw: candidate arrays, probes run, the
+ * times of the best and the worst pair of written arrays (0R2W over every
+ * pair) and, with those chosen, of the best and the worst choice of the read
+ * arrays (the job's full pattern); 0 candidates: not tuned. */
+int	cordic_group_set_placement(cordic_group *grp, int enable);
+int	cordic_group_placement(const cordic_group *grp, int local_shard,
+		int *candidates, int *probes, float *written_best_ms,
+		float *written_worst_ms, float *best_ms, float *worst_ms);
 /* in0[i] = ((start+i) << shift) mod 2^32            (cordic_fill_phase_ramp) */
 int	cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift);
 /* in0 / in1 = the deterministic I/Q ramps of cordic_fill_iq_ramp            */

@@ -99,7 +99,7 @@ def _line(stdout):
 
 
 SMALL = ["--steps", "5", "--warmup", "1", "--log2-samples", "22",
-         "--no-cpu-baseline", "--no-other-paths", "--no-pmc"]
+         "--no-cpu-baseline", "--no-other-paths", "--no-pmc", "--no-power"]
 
 
 @pytest.mark.gpu
@@ -165,6 +165,24 @@ def test_traffic_is_measured_in_the_same_run():
     r = d["roofline"]
     assert "error" not in r["pmc"], r["pmc"]
     assert 0.99 < r["traffic_over_algorithmic"] < 1.02
+
+
+@pytest.mark.gpu
+def test_power_and_clock_are_sampled_in_the_same_run():
+    """roofline.power: socket power and shader clock from the device's hwmon
+    files while the kernel runs (timed region + two more seconds)."""
+    import glob
+    if not glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        pytest.skip("no amdgpu hwmon files in this container")
+    args = ["--steps", "20", "--warmup", "2", "--log2-samples", "26",
+            "--no-cpu-baseline", "--no-other-paths", "--no-pmc"]
+    d = _line(run(["--gpus", "1"] + args).stdout)
+    pw = d["roofline"]["power"]
+    assert 500 <= pw["limit_w"] <= 3000
+    su = pw["sustained"]
+    assert su["samples"] >= 50
+    assert 50 < su["socket_w_median"] <= pw["limit_w"] * 1.05
+    assert 90 <= su["sclk_mhz_median"] <= 2500
 
 
 @pytest.mark.gpu

@@ -204,3 +204,43 @@ def test_multi_proc_example_one_worker():
     rx, ry = oracle_p2r(ocfg, 0, 1 << 22)
     want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
     assert "digest of the gathered  : %016x" % want in r.stdout
+
+
+def test_placement_of_the_arrays():
+    """Arrays of 64 MiB and up are placed by measurement (two spare
+    candidates, probes of the job's traffic); results do not depend on it."""
+    cfg, ocfg = both(*CFG4)
+    n_total = 1 << 24
+    digests = []
+    for enable in (True, False):
+        g = ca.Group(cfg, devices=[0])
+        g.set_placement(enable)
+        g.fill_phase_ramp(n_total, 0)           # in0, out0, out1 at once
+        g.p2r_const(n_total, AMP, 0)
+        info = g.placement(0)
+        if enable:
+            assert info["candidates"] == 5 and info["probes"] == 10 + 3
+            assert 0 < info["written_pair_best_ms"] <= info["written_pair_worst_ms"]
+            assert 0 < info["best_ms"] <= info["worst_ms"]
+        else:
+            assert info["candidates"] == 0 and info["probes"] == 0
+        digests.append(g.digest(n_total))
+        g.close()
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
+    assert digests == [want, want]
+    # store-only job: two written arrays out of four candidates, every pair
+    g = ca.Group(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16), devices=[0])
+    g.nco(n_total, 0, 0x01234567, AMP, 0)
+    assert g.placement(0)["candidates"] == 4 and g.placement(0)["probes"] == 6
+    # a later job that needs an input leaves the results alone: no probing
+    before = g.read(0, g.OUT0, 0, 1024).copy()
+    g.reserve(n_total, 1)
+    assert g.placement(0)["probes"] == 0
+    assert np.array_equal(g.read(0, g.OUT0, 0, 1024), before)
+    g.close()
+    # small arrays are taken as they come
+    g = ca.Group(cfg, devices=[0])
+    g.fill_phase_ramp(1 << 20, 0)
+    assert g.placement(0)["candidates"] == 0
+    g.close()

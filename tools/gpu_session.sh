@@ -40,7 +40,7 @@ for task in "$@"; do
 	states)
 		for i in $(seq 1 ${STATE_ROUNDS:-10}); do
 			echo "== round $i: $(./tools/hbm_probe2 30 20 marker | grep -m1 persist)" >> $log
-			python bench.py --steps 300 --no-cpu-baseline --no-other-paths --no-pmc 2>/dev/null | python -c "
+			python bench.py --steps 300 --no-cpu-baseline --no-other-paths --no-pmc --no-power 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']), round(d['roofline']['frac'],3), d['roofline'].get('copy_frac'))" >> $log
 			snap >> $log
@@ -49,7 +49,7 @@ d=json.loads(sys.stdin.readline()); print('   bench 300 steps', round(d['value']
 		for w in ${POWER_WORKLOADS:-cfg5 cfg2 cfg4 cfg1 cfg3 p2rxy quadtbl}; do
 			echo "== $w" >> $log
 			python bench.py --workload $w --steps 6000 --warmup 5 --no-cpu-baseline --no-other-paths \
-				--no-pmc --no-copy-probe > gpurun_out/power_$w.json 2>/dev/null &
+				--no-pmc --no-copy-probe --no-power > gpurun_out/power_$w.json 2>/dev/null &
 			pid=$!
 			sleep 8
 			for i in 1 2 3 4; do snap >> $log; sleep 0.5; done
@@ -61,7 +61,7 @@ d=json.loads(open('gpurun_out/power_$w.json').readline()); print('   value', rou
 	ab)
 		make -C cordic_amd/csrc -j8 BUILD=build_ab OUT=$PWD/cordic_amd/lib_ab.so HIPFLAGS_EXTRA="$arg" > gpurun_out/ab_build.log 2>&1
 		for r in 1 2 3; do for lib in libcordic_amd.so lib_ab.so; do
-			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-other-paths --no-pmc 2>/dev/null \
+			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-other-paths --no-pmc --no-power 2>/dev/null \
 			| python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['roofline']['frac'],3))" >> $log

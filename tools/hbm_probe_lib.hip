@@ -33,6 +33,10 @@ __global__ __launch_bounds__(256) void tiles(const u32x4 *__restrict__ a,
 	if (R >= 2) v += b[g];
 	if (W >= 1) c[g] = v;
 	if (W >= 2) d[g] = v + 1;
+	// read-only sweeps: keep the loads alive (the condition never holds for
+	// the zero / ramp contents the probes run on)
+	if (W == 0 && (v.x ^ v.y ^ v.z ^ v.w) == 0x5bd1e995u && c)
+		c[0] = v;
 }
 
 template <int R, int W>
@@ -149,5 +153,7 @@ extern "C" float hbm_probe(const void *in0, const void *in1, void *out0, void *o
 	if (R == 2 && W == 2) return run<2, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
 	if (R == 0 && W == 2) return run<0, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
 	if (R == 1 && W == 1) return run<1, 1>(in0, in1, out0, out1, nvec, mode, reps, st);
+	if (R == 1 && W == 0) return run<1, 0>(in0, in1, out0, out1, nvec, mode, reps, st);
+	if (R == 0 && W == 1) return run<0, 1>(in0, in1, out0, out1, nvec, mode, reps, st);
 	return -1.f;
 }
