@@ -67,7 +67,11 @@ struct Shard {
 };
 
 constexpr uint64_t kPlaceMinWords = (uint64_t)1 << 24;	// arrays of 64 MiB and up
-constexpr int kPlaceSpare = 2;
+constexpr int kPlaceSpare = 2;		// candidates beyond the need, always
+constexpr int kPlaceSpareMax = 6;	// ... and at most, while no good pair shows
+// a pair of written arrays is good enough at 0.88 of the 8 TB/s peak (single
+// arrays sweep at 0.88-0.89, good pairs reach 0.90)
+constexpr double kPlaceGoodBytesPerMs = 0.88 * 8e9;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
 struct Rccl {
@@ -187,9 +191,11 @@ float probe_ms(Shard &s, int reads, const void *r0, const void *r1, void *w0,
 
 // Hand the arrays of `pool` (more than needed) to the roles of `need` so that
 // the job's streams run fastest: first the two written arrays (every pair,
-// 0R2W), then the read ones over what is left (1R2W each, or every pair 2R2W).
-// Arrays left in the pool afterwards are the caller's to free.  Falls back to
-// "in order" if a probe cannot run.
+// 0R2W; while no pair is good enough, up to kPlaceSpareMax - kPlaceSpare more
+// candidates are allocated and tried against the ones at hand), then the read
+// ones over what is left (1R2W each, or every pair 2R2W).  Arrays left in the
+// pool afterwards are the caller's to free.  Falls back to "in order" if a
+// probe cannot run.
 void place(Shard &s, const std::vector<int> &need, std::vector<void *> &pool,
 		uint64_t words)
 {
@@ -213,18 +219,38 @@ void place(Shard &s, const std::vector<int> &need, std::vector<void *> &pool,
 	}
 	float best = -1.f, worst = 0.f;
 	size_t bi = 0, bj = 1;
-	for (size_t i = 0; i < pool.size(); i++)
-		for (size_t j = i + 1; j < pool.size(); j++) {
-			const float ms = probe_ms(s, 0, nullptr, nullptr, pool[i], pool[j], words);
-			if (ms < 0.f) {
-				(void)hipGetLastError();
-				in_order();
-				return;
-			}
-			s.place_probes++;
-			if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
-			if (ms > worst) worst = ms;
+	bool failed = false;
+	auto try_pair = [&](size_t i, size_t j) {
+		const float ms = probe_ms(s, 0, nullptr, nullptr, pool[i], pool[j], words);
+		if (ms < 0.f) {
+			(void)hipGetLastError();
+			failed = true;
+			return;
 		}
+		s.place_probes++;
+		if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
+		if (ms > worst) worst = ms;
+	};
+	for (size_t i = 0; i < pool.size() && !failed; i++)
+		for (size_t j = i + 1; j < pool.size() && !failed; j++)
+			try_pair(i, j);
+	const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
+	const size_t most = need.size() + (size_t)kPlaceSpareMax;
+	while (!failed && best > good && pool.size() < most) {
+		void *p = nullptr;
+		if (!ok(hipMalloc(&p, (size_t)words * 4))) {
+			(void)hipGetLastError();
+			break;			// no room: make do with what there is
+		}
+		pool.push_back(p);
+		s.place_candidates++;
+		for (size_t i = 0; i + 1 < pool.size() && !failed; i++)
+			try_pair(i, pool.size() - 1);
+	}
+	if (failed) {
+		in_order();
+		return;
+	}
 	take(3, bj);		// the larger index first: bi stays valid
 	take(2, bi);
 	s.place_wbest_ms = s.place_best_ms = best;

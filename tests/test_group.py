@@ -219,7 +219,9 @@ def test_placement_of_the_arrays():
         g.p2r_const(n_total, AMP, 0)
         info = g.placement(0)
         if enable:
-            assert info["candidates"] == 5 and info["probes"] == 10 + 3
+            # two spare candidates at least, more while no good pair shows
+            k = info["candidates"]
+            assert 5 <= k <= 9 and info["probes"] == k * (k - 1) // 2 + (k - 2)
             assert 0 < info["written_pair_best_ms"] <= info["written_pair_worst_ms"]
             assert 0 < info["best_ms"] <= info["worst_ms"]
         else:
@@ -232,7 +234,8 @@ def test_placement_of_the_arrays():
     # store-only job: two written arrays out of four candidates, every pair
     g = ca.Group(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16), devices=[0])
     g.nco(n_total, 0, 0x01234567, AMP, 0)
-    assert g.placement(0)["candidates"] == 4 and g.placement(0)["probes"] == 6
+    k = g.placement(0)["candidates"]
+    assert 4 <= k <= 8 and g.placement(0)["probes"] == k * (k - 1) // 2
     # a later job that needs an input leaves the results alone: no probing
     before = g.read(0, g.OUT0, 0, 1024).copy()
     g.reserve(n_total, 1)
