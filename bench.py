@@ -458,8 +458,10 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         tab = ca.Table(kind, iw, ow, pw)
     n = 1 << args.log2_samples
     index0 = rank * n
-    phase = torch.empty(n, dtype=torch.int32, device=dev)
-    out = torch.empty(n, dtype=torch.int32, device=dev)
+    # one read + one written array, placed by measurement (cordic_arrays_alloc)
+    arrays = ca.Arrays(4 * n, 1, 1)
+    phase = arrays.tensor(0, torch.int32)
+    out = arrays.tensor(1, torch.int32)
     ca.fill_phase_ramp(phase, index0, w["shift"])
     if args.input == "random":
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -638,8 +640,6 @@ def run_group(args, w, launch):
     kind = w["kind"]
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
-    if args.no_placement:
-        grp.set_placement(False)
     seeded = False
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
         seeded = ca.Plan(cfg).seed_info["stages"] > 0
@@ -1131,24 +1131,30 @@ def run_direct(args, w, launch):
     # ---- resident inputs / outputs
     io16 = bool(w.get("io16"))
     sdt = torch.int16 if io16 else torch.int32
-    a = torch.empty(n, dtype=sdt, device=dev)
-    b = torch.empty(n, dtype=sdt, device=dev)
+    # the arrays of the job, placed by measurement (cordic_arrays_alloc: up to
+    # two read + two written arrays; a third input is taken as it comes)
+    nread = {"p2r": 1, "p2rxy": 2, "r2p": 2}[w["kind"]]
+    arrays = ca.Arrays((2 if io16 else 4) * n, nread, 2)
+    a = arrays.tensor(nread, sdt)
+    b = arrays.tensor(nread + 1, sdt)
     if w["kind"] == "p2r":
-        phase = torch.empty(n, dtype=torch.int32, device=dev)
-        ca.fill_phase_ramp(phase, index0, w["shift"])
+        p32 = torch.empty(n, dtype=torch.int32, device=dev)
+        ca.fill_phase_ramp(p32, index0, w["shift"])
         if args.input == "random":
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-            phase.random_(-2**31, 2**31 - 1, generator=gen)
-        if io16:
-            phase = phase.to(torch.int16)   # the low 16 bits: n mod 2^16
+            p32.random_(-2**31, 2**31 - 1, generator=gen)
+        phase = arrays.tensor(0, sdt)
+        phase.copy_(p32.to(sdt))            # io16: the low 16 bits, n mod 2^16
+        del p32
+        torch.cuda.empty_cache()
 
         plan = ca.Plan(cfg)
 
         def step():
             plan.p2r_const(x0, y0, phase, a, b)
     elif w["kind"] == "p2rxy":
-        phase = torch.empty(n, dtype=torch.int32, device=dev)
-        xin = torch.empty(n, dtype=torch.int32, device=dev)
+        phase = arrays.tensor(0, torch.int32)
+        xin = arrays.tensor(1, torch.int32)
         yin = torch.empty(n, dtype=torch.int32, device=dev)
         ca.fill_phase_ramp(phase, index0, w["shift"])
         ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
@@ -1159,8 +1165,8 @@ def run_direct(args, w, launch):
         def step():
             ca.p2r(cfg, xin, yin, phase, a, b)
     elif w["kind"] == "r2p":
-        xin = torch.empty(n, dtype=torch.int32, device=dev)
-        yin = torch.empty(n, dtype=torch.int32, device=dev)
+        xin = arrays.tensor(0, torch.int32)
+        yin = arrays.tensor(1, torch.int32)
         ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
         if args.input == "random":
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -1379,6 +1385,10 @@ def main():
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
     args = ap.parse_args()
+    if args.no_placement:
+        # read by cordic_group_create / cordic_arrays_alloc (and inherited by
+        # the ranks and sub-runs this process starts)
+        os.environ["CORDIC_GROUP_PLACEMENT"] = "0"
 
     launch = resolve_launch(args)
     if launch == "spawn":

@@ -123,6 +123,9 @@ ABI = {
                                      C.POINTER(C.c_uint64)]),
     "cordic_group_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
     "cordic_group_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
+    "cordic_arrays_alloc": (C.c_int, [C.c_size_t, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p), C.c_void_p]),
+    "cordic_arrays_free": (None, [C.POINTER(C.c_void_p), C.c_int]),
     "cordic_group_placement": (C.c_int, [C.c_void_p, C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
                                + [C.POINTER(C.c_float)] * 4),
@@ -522,6 +525,40 @@ class Group:
             addr, count = _ptr(src), src.numel()
         _check(lib().cordic_group_write(self._h, local_shard, array, offset,
                                         count, addr), "cordic_group_write")
+
+
+class Arrays:
+    """cordic_arrays_alloc: n_read + n_write device arrays of `nbytes` bytes,
+    placed by measurement (include/cordic_amd.h, "Placement"), as torch tensor
+    views; read arrays first."""
+
+    class _View:
+        def __init__(self, ptr, count, typestr):
+            self.__cuda_array_interface__ = {
+                "shape": (count,), "typestr": typestr, "data": (ptr, False),
+                "version": 2}
+
+    def __init__(self, nbytes, n_read, n_write, stream=None):
+        self.nbytes, self.count = int(nbytes), n_read + n_write
+        self._p = (C.c_void_p * self.count)()
+        _check(lib().cordic_arrays_alloc(self.nbytes, n_read, n_write, self._p,
+                                         stream), "cordic_arrays_alloc")
+        self.ptrs = [int(self._p[i]) for i in range(self.count)]
+
+    def tensor(self, k, dtype):
+        import torch
+        code = {torch.int32: "<i4", torch.int16: "<i2"}[dtype]
+        per = 4 if dtype == torch.int32 else 2
+        return torch.as_tensor(Arrays._View(self.ptrs[k], self.nbytes // per, code),
+                               device="cuda")
+
+    def close(self):
+        if getattr(self, "_p", None) is not None:
+            lib().cordic_arrays_free(self._p, self.count)
+            self._p = None
+
+    def __del__(self):
+        self.close()
 
 
 RCCL_ID_BYTES = 128

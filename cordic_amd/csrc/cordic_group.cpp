@@ -167,19 +167,26 @@ void release(Shard &s)
 	s = Shard{};
 }
 
-// Average milliseconds of the `reads`R 2W probe over the given arrays on the
-// shard's compute stream (one warm-up launch, two timed), or a negative value.
-float probe_ms(Shard &s, int reads, const void *r0, const void *r1, void *w0,
-		void *w1, uint64_t words)
+struct PlaceStats {
+	int	candidates = 0, probes = 0;
+	float	wbest = 0.f, wworst = 0.f;	// written arrays alone
+	float	best = 0.f, worst = 0.f;	// the job's full pattern
+};
+
+// Average milliseconds of the `reads`R `writes`W probe over the given arrays
+// on `st` (one warm-up launch, two timed), or a negative value.
+float probe_ms(hipStream_t st, int reads, int writes, const void *r0, const void *r1,
+		void *w0, void *w1, uint64_t words)
 {
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	float ms = -1.f;
-	if (ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))
-	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
-	    && ok(hipEventRecord(e0, s.compute))
-	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
-	    && launch_stream_probe(reads, 2, r0, r1, w0, w1, (size_t)words, s.compute) == CORDIC_OK
-	    && ok(hipEventRecord(e1, s.compute)) && ok(hipEventSynchronize(e1))
+	auto go = [&]() {
+		return launch_stream_probe(reads, writes, r0, r1, w0, w1, (size_t)words, st)
+			== CORDIC_OK;
+	};
+	if (ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1)) && go()
+	    && ok(hipEventRecord(e0, st)) && go() && go()
+	    && ok(hipEventRecord(e1, st)) && ok(hipEventSynchronize(e1))
 	    && ok(hipEventElapsedTime(&ms, e0, e1)))
 		ms *= 0.5f;
 	else
@@ -189,102 +196,149 @@ float probe_ms(Shard &s, int reads, const void *r0, const void *r1, void *w0,
 	return ms;
 }
 
-// Hand the arrays of `pool` (more than needed) to the roles of `need` so that
-// the job's streams run fastest: first the two written arrays (every pair,
-// 0R2W; while no pair is good enough, up to kPlaceSpareMax - kPlaceSpare more
-// candidates are allocated and tried against the ones at hand), then the read
-// ones over what is left (1R2W each, or every pair 2R2W).  Arrays left in the
-// pool afterwards are the caller's to free.  Falls back to "in order" if a
-// probe cannot run.
-void place(Shard &s, const std::vector<int> &need, std::vector<void *> &pool,
-		uint64_t words)
+// Allocate nread (0..2) + nwrite (1..2) arrays of `words` 32-bit words on the
+// current device.  With `tune`, allocate kPlaceSpare more than needed, time the
+// arithmetic-free twin of the traffic over the candidate assignments -- first
+// the written arrays (two: every pair, 0R2W; while no pair is good enough, up
+// to kPlaceSpareMax - kPlaceSpare more candidates, each tried against the ones
+// at hand), then the read ones over what is left -- keep the best and free the
+// rest.  A probe that cannot run just means "in order".
+int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tune,
+		void **reads, void **writes, PlaceStats *stats)
 {
-	auto take = [&](int role, size_t k) {
-		s.buf[role] = pool[k];
-		pool.erase(pool.begin() + (long)k);
-	};
-	auto in_order = [&]() {
-		for (int role : need)
-			if (!s.buf[role])
-				take(role, 0);
-	};
-	s.place_candidates = (int)pool.size();
-	s.place_probes = 0;
-	s.place_best_ms = s.place_worst_ms = 0.f;
-	s.place_wbest_ms = s.place_wworst_ms = 0.f;
-	const bool outs = !s.buf[2] && !s.buf[3];
-	if (!outs) {		// results of an earlier job may live there: no probing
-		in_order();
-		return;
-	}
-	float best = -1.f, worst = 0.f;
-	size_t bi = 0, bj = 1;
-	bool failed = false;
-	auto try_pair = [&](size_t i, size_t j) {
-		const float ms = probe_ms(s, 0, nullptr, nullptr, pool[i], pool[j], words);
-		if (ms < 0.f) {
-			(void)hipGetLastError();
-			failed = true;
-			return;
-		}
-		s.place_probes++;
-		if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
-		if (ms > worst) worst = ms;
-	};
-	for (size_t i = 0; i < pool.size() && !failed; i++)
-		for (size_t j = i + 1; j < pool.size() && !failed; j++)
-			try_pair(i, j);
-	const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
-	const size_t most = need.size() + (size_t)kPlaceSpareMax;
-	while (!failed && best > good && pool.size() < most) {
+	const size_t need = (size_t)(nread + nwrite);
+	const size_t bytes = (size_t)(words ? words : 1) * 4;
+	std::vector<void *> pool;
+	const size_t want = need + (tune ? (size_t)kPlaceSpare : 0);
+	for (size_t k = 0; k < want; k++) {
 		void *p = nullptr;
-		if (!ok(hipMalloc(&p, (size_t)words * 4))) {
+		if (!ok(hipMalloc(&p, bytes))) {
 			(void)hipGetLastError();
-			break;			// no room: make do with what there is
+			if (k >= need)
+				break;		// no room for spares: place what there is
+			for (void *q : pool) (void)hipFree(q);
+			return CORDIC_ERR_DEVICE;
 		}
 		pool.push_back(p);
-		s.place_candidates++;
-		for (size_t i = 0; i + 1 < pool.size() && !failed; i++)
-			try_pair(i, pool.size() - 1);
 	}
-	if (failed) {
-		in_order();
-		return;
+	PlaceStats ps;
+	auto take = [&](void **slot, size_t k) {
+		*slot = pool[k];
+		pool.erase(pool.begin() + (long)k);
+	};
+	auto finish = [&](bool in_order) {
+		if (in_order) {
+			for (int i = 0; i < nwrite; i++) if (!writes[i]) take(&writes[i], 0);
+			for (int i = 0; i < nread; i++) if (!reads[i]) take(&reads[i], 0);
+		}
+		for (void *q : pool) (void)hipFree(q);
+		if (stats) *stats = ps;
+		return CORDIC_OK;
+	};
+	for (int i = 0; i < nwrite; i++) writes[i] = nullptr;
+	for (int i = 0; i < nread; i++) reads[i] = nullptr;
+	if (!tune || pool.size() == need)
+		return finish(true);
+	ps.candidates = (int)pool.size();
+	bool failed = false;
+	float best = -1.f, worst = 0.f;
+	size_t bi = 0, bj = 1;
+	if (nwrite == 2) {
+		auto try_pair = [&](size_t i, size_t j) {
+			const float ms = probe_ms(st, 0, 2, nullptr, nullptr, pool[i], pool[j], words);
+			if (ms < 0.f) { failed = true; return; }
+			ps.probes++;
+			if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
+			if (ms > worst) worst = ms;
+		};
+		for (size_t i = 0; i < pool.size() && !failed; i++)
+			for (size_t j = i + 1; j < pool.size() && !failed; j++)
+				try_pair(i, j);
+		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
+		while (!failed && best > good && pool.size() < need + (size_t)kPlaceSpareMax) {
+			void *p = nullptr;
+			if (!ok(hipMalloc(&p, bytes))) {
+				(void)hipGetLastError();
+				break;		// no room: make do with what there is
+			}
+			pool.push_back(p);
+			ps.candidates++;
+			for (size_t i = 0; i + 1 < pool.size() && !failed; i++)
+				try_pair(i, pool.size() - 1);
+		}
+		if (failed) {
+			(void)hipGetLastError();
+			ps = PlaceStats{};
+			return finish(true);
+		}
+		take(&writes[1], bj);	// the larger index first: bi stays valid
+		take(&writes[0], bi);
+		ps.wbest = ps.best = best;
+		ps.wworst = ps.worst = worst;
+	} else {
+		// one written array: nothing to pair it with yet; it is chosen
+		// together with the read arrays below (or taken as it comes)
+		if (nread == 0)
+			return finish(true);
 	}
-	take(3, bj);		// the larger index first: bi stays valid
-	take(2, bi);
-	s.place_wbest_ms = s.place_best_ms = best;
-	s.place_wworst_ms = s.place_worst_ms = worst;
-	std::vector<int> ins;
-	for (int role : need)
-		if (role < 2)
-			ins.push_back(role);
-	if (ins.empty())
-		return;
+	if (nread == 0)
+		return finish(false);
 	best = -1.f; worst = 0.f; bi = 0; bj = 1;
-	if (ins.size() == 1) {
-		for (size_t i = 0; i < pool.size(); i++) {
-			const float ms = probe_ms(s, 1, pool[i], nullptr, s.buf[2], s.buf[3], words);
-			if (ms < 0.f) { (void)hipGetLastError(); in_order(); return; }
-			s.place_probes++;
+	size_t bw = 0;
+	if (nwrite == 1) {
+		// (read array[s], written array) together: every ordered choice
+		for (size_t w = 0; w < pool.size() && !failed; w++)
+			for (size_t i = 0; i < pool.size() && !failed; i++) {
+				if (i == w) continue;
+				for (size_t j = (nread == 2 ? i + 1 : i); j < (nread == 2 ? pool.size() : i + 1)
+						&& !failed; j++) {
+					if (j == w) continue;
+					const float ms = probe_ms(st, nread, 1, pool[i],
+						nread == 2 ? pool[j] : nullptr, pool[w], nullptr, words);
+					if (ms < 0.f) { failed = true; break; }
+					ps.probes++;
+					if (best < 0.f || ms < best) { best = ms; bw = w; bi = i; bj = j; }
+					if (ms > worst) worst = ms;
+				}
+			}
+		if (failed) {
+			(void)hipGetLastError();
+			ps = PlaceStats{};
+			return finish(true);
+		}
+		void *pw = pool[bw], *p0 = pool[bi], *p1 = nread == 2 ? pool[bj] : nullptr;
+		writes[0] = pw;
+		reads[0] = p0;
+		if (nread == 2) reads[1] = p1;
+		for (size_t k = pool.size(); k-- > 0;)
+			if (pool[k] == pw || pool[k] == p0 || (p1 && pool[k] == p1))
+				pool.erase(pool.begin() + (long)k);
+	} else if (nread == 1) {
+		for (size_t i = 0; i < pool.size() && !failed; i++) {
+			const float ms = probe_ms(st, 1, 2, pool[i], nullptr, writes[0], writes[1], words);
+			if (ms < 0.f) { failed = true; break; }
+			ps.probes++;
 			if (best < 0.f || ms < best) { best = ms; bi = i; }
 			if (ms > worst) worst = ms;
 		}
-		take(ins[0], bi);
+		if (failed) { (void)hipGetLastError(); return finish(true); }
+		take(&reads[0], bi);
 	} else {
-		for (size_t i = 0; i < pool.size(); i++)
-			for (size_t j = i + 1; j < pool.size(); j++) {
-				const float ms = probe_ms(s, 2, pool[i], pool[j], s.buf[2], s.buf[3], words);
-				if (ms < 0.f) { (void)hipGetLastError(); in_order(); return; }
-				s.place_probes++;
+		for (size_t i = 0; i < pool.size() && !failed; i++)
+			for (size_t j = i + 1; j < pool.size() && !failed; j++) {
+				const float ms = probe_ms(st, 2, 2, pool[i], pool[j], writes[0], writes[1], words);
+				if (ms < 0.f) { failed = true; break; }
+				ps.probes++;
 				if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
 				if (ms > worst) worst = ms;
 			}
-		take(ins[1], bj);
-		take(ins[0], bi);
+		if (failed) { (void)hipGetLastError(); return finish(true); }
+		take(&reads[1], bj);
+		take(&reads[0], bi);
 	}
-	s.place_best_ms = best;		// of the job's full pattern
-	s.place_worst_ms = worst;
+	ps.best = best;
+	ps.worst = worst;
+	return finish(false);
 }
 
 int ensure(cordic_group *g, uint64_t n_total, int inputs)
@@ -301,39 +355,34 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			return CORDIC_ERR_DEVICE;
 		const uint64_t cap = cnt > s.cap ? cnt : s.cap;
 		const int nin = inputs > s.inputs ? inputs : s.inputs;
-		std::vector<int> need;
-		for (int a = 0; a < 4; a++) {
-			const bool wanted = (a >= 2) || (a < nin);
-			if (s.buf[a] && cap > s.cap) {
-				(void)hipFree(s.buf[a]);
-				s.buf[a] = nullptr;
+		if (cap > s.cap)
+			for (void *&p : s.buf) {
+				if (p) (void)hipFree(p);
+				p = nullptr;
 			}
-			if (wanted && !s.buf[a])
-				need.push_back(a);
-		}
-		const bool tune = g->placement && cap >= kPlaceMinWords && !need.empty();
-		std::vector<void *> pool;
-		const size_t want = need.size() + (tune ? (size_t)kPlaceSpare : 0);
-		for (size_t k = 0; k < want; k++) {
-			void *p = nullptr;
-			if (!ok(hipMalloc(&p, (cap ? cap : 1) * 4))) {
-				(void)hipGetLastError();
-				if (k >= need.size())
-					break;		// no room for spares: place what there is
-				for (void *q : pool) (void)hipFree(q);
-				return CORDIC_ERR_DEVICE;
-			}
-			pool.push_back(p);
-		}
-		if (tune && pool.size() > need.size()) {
-			place(s, need, pool, cap);
+		s.place_candidates = s.place_probes = 0;
+		s.place_best_ms = s.place_worst_ms = 0.f;
+		s.place_wbest_ms = s.place_wworst_ms = 0.f;
+		if (!s.buf[2] && !s.buf[3]) {
+			// everything at once: place the arrays by measurement
+			void *rd[2] = {nullptr, nullptr}, *wr[2] = {nullptr, nullptr};
+			PlaceStats ps;
+			const bool tune = g->placement && cap >= kPlaceMinWords;
+			if (int rc = alloc_placed(s.compute, cap, nin, 2, tune, rd, wr, &ps))
+				return rc;
+			s.buf[0] = rd[0]; s.buf[1] = rd[1];
+			s.buf[2] = wr[0]; s.buf[3] = wr[1];
+			s.place_candidates = ps.candidates;
+			s.place_probes = ps.probes;
+			s.place_best_ms = ps.best; s.place_worst_ms = ps.worst;
+			s.place_wbest_ms = ps.wbest; s.place_wworst_ms = ps.wworst;
 		} else {
-			for (int role : need) {
-				s.buf[role] = pool.front();
-				pool.erase(pool.begin());
-			}
+			// inputs added behind a job whose results may still be wanted:
+			// no probing (it writes), the arrays as they come
+			for (int a = 0; a < nin; a++)
+				if (!s.buf[a] && !ok(hipMalloc(&s.buf[a], (cap ? cap : 1) * 4)))
+					return CORDIC_ERR_DEVICE;
 		}
-		for (void *q : pool) (void)hipFree(q);
 		s.cap = cap;
 		s.inputs = nin;
 	}
@@ -537,6 +586,37 @@ int cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs)
 		return CORDIC_ERR_ARGS;
 	DeviceScope scope;
 	return ensure(grp, n_total, inputs);
+}
+
+int cordic_arrays_alloc(size_t bytes, int n_read, int n_write, void **ptrs,
+		void *stream)
+{
+	if (!ptrs || n_read < 0 || n_read > 2 || n_write < 1 || n_write > 2)
+		return CORDIC_ERR_ARGS;
+	const uint64_t words = ((uint64_t)bytes + 3) / 4;
+	bool tune = words >= kPlaceMinWords;
+	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
+		if (e[0] == '0' && e[1] == 0)
+			tune = false;
+	void *rd[2] = {nullptr, nullptr}, *wr[2] = {nullptr, nullptr};
+	if (int rc = alloc_placed(static_cast<hipStream_t>(stream), words, n_read, n_write,
+			tune, rd, wr, nullptr))
+		return rc;
+	if (!ok(hipStreamSynchronize(static_cast<hipStream_t>(stream))))
+		return CORDIC_ERR_DEVICE;
+	for (int i = 0; i < n_read; i++) ptrs[i] = rd[i];
+	for (int i = 0; i < n_write; i++) ptrs[n_read + i] = wr[i];
+	return CORDIC_OK;
+}
+
+void cordic_arrays_free(void **ptrs, int count)
+{
+	if (!ptrs)
+		return;
+	for (int i = 0; i < count; i++) {
+		if (ptrs[i]) (void)hipFree(ptrs[i]);
+		ptrs[i] = nullptr;
+	}
 }
 
 int cordic_group_set_placement(cordic_group *grp, int enable)

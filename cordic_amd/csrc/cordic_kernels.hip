@@ -835,6 +835,8 @@ int launch_stream_probe(int reads, int writes, const void *r0, const void *r1,
 	if (reads == 0 && writes == 2) go(stream_probe<0, 2>);
 	else if (reads == 1 && writes == 2) go(stream_probe<1, 2>);
 	else if (reads == 2 && writes == 2) go(stream_probe<2, 2>);
+	else if (reads == 1 && writes == 1) go(stream_probe<1, 1>);
+	else if (reads == 2 && writes == 1) go(stream_probe<2, 1>);
 	else return CORDIC_ERR_ARGS;
 	return check_launch();
 }

@@ -518,6 +518,14 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
  * pair) and, with those chosen, of the best and the worst choice of the read
  * arrays (the job's full pattern); 0 candidates: not tuned. */
 int	cordic_group_set_placement(cordic_group *grp, int enable);
+/* The same for callers of the stateless entry points: n_read (0..2) +
+ * n_write (1..2) arrays of `bytes` bytes each on the current device, placed as
+ * above (arrays under 64 MiB: plain hipMalloc); ptrs receives the read arrays
+ * first, then the written ones.  Synchronises `stream`, on which the probes
+ * run.  cordic_arrays_free releases them (plain hipFree would do). */
+int	cordic_arrays_alloc(size_t bytes, int n_read, int n_write, void **ptrs,
+		void *stream);
+void	cordic_arrays_free(void **ptrs, int count);
 int	cordic_group_placement(const cordic_group *grp, int local_shard,
 		int *candidates, int *probes, float *written_best_ms,
 		float *written_worst_ms, float *best_ms, float *worst_ms);

@@ -247,3 +247,31 @@ def test_placement_of_the_arrays():
     g.fill_phase_ramp(1 << 20, 0)
     assert g.placement(0)["candidates"] == 0
     g.close()
+
+
+def test_placed_arrays_for_stateless_callers():
+    """cordic_arrays_alloc: the same placement for callers who bring their own
+    arrays to the stateless entry points."""
+    import torch
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n = 1 << 24
+    arr = ca.Arrays(4 * n, 1, 2)
+    assert len(set(arr.ptrs)) == 3 and all(p % 256 == 0 for p in arr.ptrs)
+    ph, ox, oy = (arr.tensor(k, torch.int32) for k in range(3))
+    ca.fill_phase_ramp(ph, 0, 4)
+    ca.p2r_const(cfg, AMP, 0, ph, ox, oy)
+    torch.cuda.synchronize()
+    rx, ry = oracle_p2r(ocfg, 0, n, shift=4)
+    assert np.array_equal(ox.cpu().numpy(), rx) and np.array_equal(oy.cpu().numpy(), ry)
+    arr.close()
+    for nr, nw in ((0, 2), (2, 2), (1, 1), (2, 1), (0, 1)):
+        a = ca.Arrays(4 * n, nr, nw)
+        assert len(set(a.ptrs)) == nr + nw
+        a.close()
+    small = ca.Arrays(4096, 1, 2)               # under 64 MiB: plain hipMalloc
+    assert len(set(small.ptrs)) == 3
+    small.close()
+    with pytest.raises(ca.CordicError):
+        ca.Arrays(4 * n, 3, 2)
+    with pytest.raises(ca.CordicError):
+        ca.Arrays(4 * n, 1, 0)
