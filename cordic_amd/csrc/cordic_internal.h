@@ -48,9 +48,17 @@ int	quad_write_header(const cordic_quad_config *q, const char *name,
 
 // Seed tables: stages replaced by the lookup and threads per block of the
 // seeded kernels (one table per block).
+// M = 11: 1618 leaves x 4 quadrants x 16 B of seeds + 32 KiB of buckets = 136 KiB
+// of LDS, ONE 1024-thread block per CU.  Measured against M = 10 (68 KiB, two
+// blocks per CU) on one box: cfg2 +1 %, cfg5 +2 %, cfg1 +3 %, cfg4 +4 %
+// (profiles/r02/ab_seed_depth.txt): the kernels are instruction- and
+// power-bound, one micro-rotation less per sample outweighs the lost
+// occupancy.  M = 12 does not fit the 160 KiB.
 #ifndef CORDIC_SEED_STAGES
-#define CORDIC_SEED_STAGES 10
+#define CORDIC_SEED_STAGES 11
 #endif
+// LDS the seeded kernels may use per block: buckets + seeds + tile-id slots
+#define CORDIC_SEED_LDS_BYTES (160u * 1024u)
 #ifndef CORDIC_SEED_BLOCK
 #define CORDIC_SEED_BLOCK 1024
 #endif

@@ -115,6 +115,10 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	if (S < 17)
 		return 0;
 	const size_t nb = (size_t)1 << (30 - S);
+	// what the kernel keeps in LDS: 8 B per bucket, 4 quadrants x 16 B per
+	// leaf, the tile-id slots (cordic_device.h: rotator_seeded)
+	if (nb * 8 + L * 64 + 64 > CORDIC_SEED_LDS_BYTES)
+		return 0;
 	const size_t words = 4 + nb * 2 + L * 2;
 	if (!buf || words > cap)
 		return 0;

@@ -476,7 +476,7 @@ def test_seeded_plan_is_bit_exact(name):
     cfg, ocfg = both(*SEED_CASES[name])
     plan = ca.Plan(cfg)
     info = plan.seed_info
-    assert info["stages"] == 10 and info["nleaves"] >= 100
+    assert info["stages"] == 11 and info["nleaves"] >= 100
     rng = np.random.RandomState(21)
     n = (1 << 19) + 5
     _, _, ph = rand_inputs(rng, cfg.iw, cfg.pw, n)

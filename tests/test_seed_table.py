@@ -37,7 +37,8 @@ def test_lookup_matches_recurrence(args):
     words = ca.seed_table(cfg)
     assert words is not None
     m, S, nb, L, buckets, leaves = parse(words)
-    assert m == 10 and nb == 1 << (30 - S) and 1 <= L <= 1024
+    assert m == 11 and nb == 1 << (30 - S) and 1 <= L <= 2048
+    assert nb * 8 + L * 64 + 64 <= 160 * 1024       # fits the LDS of one CU
     ang = [a << (32 - cfg.pw) for a in cfg.angles]
     rng = np.random.RandomState(1)
     r = rng.randint(0, 1 << 30, 200000).astype(np.int64)
@@ -69,8 +70,10 @@ def test_lookup_matches_recurrence(args):
         assert np.array_equal(buckets[b, 1] + c, j)
     pat, pm = recurrence(r - (1 << 29), ang, m)
     assert np.array_equal(leaves[j, 0], pat)
+    # off + 2^29 is stored modulo 2^32 (a leaf at the lower edge can have an
+    # offset a little below -2^29); the kernels use it modulo 2^29 / 2^30
     off = leaves[j, 1] - (1 << 29)
-    assert np.array_equal((r - (1 << 29)) - off, pm)
+    assert np.array_equal(((r - (1 << 29)) - off) & 0xffffffff, pm & 0xffffffff)
     # residual phase stays far inside 32 bits (the kernels rely on it)
     assert np.abs(pm).max() <= 1 << 29
 
@@ -78,7 +81,7 @@ def test_lookup_matches_recurrence(args):
 def test_ineligible_cores_have_no_table():
     assert ca.seed_table(ca.Config.from_cli(ca.R2P, 13, 13, 2)) is None
     assert ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 3, 32, 16)) is None  # WW 36
-    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 10 stages
+    assert ca.seed_table(ca.Config.from_cli(ca.P2R, 8, 8, 2, 12, 6)) is None    # < 11 stages
 
 
 def test_degenerate_angle_tables_are_not_seeded():
