@@ -20,7 +20,7 @@
 //   buckets: nbuckets x {bound-1, first_leaf}   in the r-domain
 //            r = p0 + 2^29 in [0, 2^30); a bucket holds at most ONE leaf
 //            boundary (the narrowest leaf of a real arctan table is ~0.85 *
-//            2^20 wide at M = 10, so S = 19 does); no boundary: 0x7fffffff
+//            2^19 wide at M = 11, so S = 18 does); no boundary: 0x7fffffff
 //   leaves : nleaves  x {pattern (M bits, stage 0 = MSB), off + 2^29}
 //            where p_M = p0 - off
 #include <algorithm>

@@ -218,13 +218,13 @@ int	cordic_r2p(const cordic_config *cfg, size_t n,
  * it; cordic_plan_create is that generation step for the GPU.  For rotators it
  * uploads a small "seed table" (cordic_seed_table) that lets the constant-
  * vector entry points -- the sin/cos generator use of the core, i_xval/i_yval
- * fixed as in bench/cpp/cordic_tb.cpp:68-69 -- replace the first 10
- * micro-rotations by an exact table lookup: the (x, y) state after 10 stages
- * depends only on the octant and on the 10 rotation directions, which are a
+ * fixed as in bench/cpp/cordic_tb.cpp:68-69 -- replace the first 11
+ * micro-rotations by an exact table lookup: the (x, y) state after 11 stages
+ * depends only on the octant and on the 11 rotation directions, which are a
  * monotone step function of the phase with integer break points.  The kernel
  * fills the (x, y) table itself on every launch with the exact recurrence, so
  * results are bit-identical for every phase and nothing is cached across
- * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 10 live
+ * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 11 live
  * stages) simply run the ordinary kernels.
  */
 typedef struct cordic_plan cordic_plan;
