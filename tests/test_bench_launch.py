@@ -192,3 +192,37 @@ def test_two_gpus_on_a_one_gpu_box_is_refused():
         pytest.skip("box has several GPUs")
     r = run(["--gpus", "2"] + SMALL)
     assert r.returncode != 0 and "needs 2 visible GPUs, found 1" in r.stderr
+
+
+def test_power_sampler_host_logic(tmp_path, monkeypatch):
+    """PowerSampler on a fake hwmon directory: units, windows, limit."""
+    import importlib.util
+    import time as _time
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hw = tmp_path / "hwmon0"
+    hw.mkdir()
+    (hw / "power1_input").write_text("1396000000\n")     # microwatts
+    (hw / "freq1_input").write_text("2145000000\n")      # Hz
+    (hw / "power1_cap").write_text("1400000000\n")
+    monkeypatch.setattr(bench.PowerSampler, "_find",
+                        classmethod(lambda cls, device: str(hw)))
+    s = bench.PowerSampler(0, period=0.001)
+    t0 = _time.perf_counter()
+    s.start()
+    _time.sleep(0.05)
+    (hw / "power1_input").write_text("1400000000\n")
+    _time.sleep(0.05)
+    s.stop()
+    t1 = _time.perf_counter()
+    w = s.window(t0, t1)
+    assert w["samples"] >= 10
+    assert w["socket_w_max"] == 1400.0 and 1396.0 <= w["socket_w_median"] <= 1400.0
+    assert w["sclk_mhz_median"] == 2145.0 and s.limit_w() == 1400.0
+    assert s.window(t1 + 1, t1 + 2) is None
+    # no hwmon files at all (this container): the sampler reports nothing
+    monkeypatch.undo()
+    import glob
+    if not glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        assert bench.PowerSampler(0).dir is None
