@@ -113,6 +113,15 @@ __device__ __forceinline__ void op_mad(int64_t &acc, int32_t a, int32_t b)
 	asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
 }
 // same with the multiplicand in an SGPR (the arctan table entry)
+// acc = a * b (v_mad_i64_i32 with the inline constant 0 as addend: no zeroed
+// register pair)
+__device__ __forceinline__ int64_t op_mul(int32_t a, int32_t b)
+{
+	int64_t d;
+	asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+	return d;
+}
+
 __device__ __forceinline__ void op_mad_s(int64_t &acc, uint32_t a_sgpr, int32_t b)
 {
 	asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "s"(a_sgpr), "v"(b) : "vcc");
@@ -555,7 +564,18 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 	// table indexed by the quadrant.  Exact: every product fits 64 bits and
 	// the additions are the same two's-complement additions (in_shl <= 30).
 	constexpr bool kMadFold = !kConstXY && C::wide;
-	__shared__ int32_t rot_tab[4][4];
+	// The left-justified kernels fold the FIRST micro-rotation into the same
+	// four multiply-adds.  With in_shl >= 1 the folded vector is even, so
+	// (y0 >>> 1) and (x0 >>> 1) are exact and stage 1 (rtl/cordic.v:262-280,
+	// shift 1, direction s = +1 where the folded phase is >= 0) is linear:
+	//     x1 = x0 - s*(y0/2) = A*i_x - B*i_y,   y1 = y0 + s*(x0/2) = B*i_x + A*i_y
+	//     A = c - s*sn/2,  B = sn + s*c/2   (|A|, |B| <= 1.5 * 2^in_shl),
+	// and p1 = p0 - s*a_0: eight table rows (quadrant x direction) instead
+	// of four, one 32-bit add for the phase, and one GENERAL 64-bit stage
+	// (~15 instructions) less per sample.
+	const int live = DYN ? kp.nlive : NLIVE;
+	const bool fold1 = kMadFold && C::lj != 0 && kp.in_shl >= 1 && live >= 1;
+	__shared__ int32_t rot_tab[8][4];
 	if constexpr (kConstXY) {
 		if (threadIdx.x < 4) {
 			const T ex = (T)((U)(T)kp.x0 << kp.in_shl);
@@ -568,15 +588,23 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		}
 		__syncthreads();
 	} else if constexpr (kMadFold) {
-		if (threadIdx.x < 4) {
+		if (threadIdx.x < 8) {
 			// q = 0: (x, y); 1: (-y, x); 2: (-x, -y); 3: (y, -x)
+			const int q = threadIdx.x >> 1;
+			const int32_t dir = (threadIdx.x & 1) ? 1 : -1;	// phase >= 0 : < 0
 			const int32_t k = (int32_t)(1u << (kp.in_shl & 31));
-			const int32_t c = (threadIdx.x == 0) ? k : (threadIdx.x == 2) ? -k : 0;
-			const int32_t sn = (threadIdx.x == 1) ? k : (threadIdx.x == 3) ? -k : 0;
-			rot_tab[threadIdx.x][0] = c;
-			rot_tab[threadIdx.x][1] = sn;
-			rot_tab[threadIdx.x][2] = -sn;
-			rot_tab[threadIdx.x][3] = 0;
+			const int32_t c = (q == 0) ? k : (q == 2) ? -k : 0;
+			const int32_t sn = (q == 1) ? k : (q == 3) ? -k : 0;
+			int32_t a = c, b = sn, dp = 0;
+			if (fold1) {
+				a = c - dir * (sn / 2);
+				b = sn + dir * (c / 2);
+				dp = -dir * (int32_t)kp.angle[0];
+			}
+			rot_tab[threadIdx.x][0] = a;
+			rot_tab[threadIdx.x][1] = b;
+			rot_tab[threadIdx.x][2] = -b;
+			rot_tab[threadIdx.x][3] = dp;
 		}
 		__syncthreads();
 	}
@@ -642,17 +670,19 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				const int32_t ix = sext32(tx[v], kp.iw);
 				const int32_t iy = sext32(ty[v], kp.iw);
 				const uint32_t pb = P[v] + 0x20000000u;
-				const uint32_t q16 = ((uint32_t)((int32_t)pb >> 26)) & 0x30u;
+				// row = quadrant (bits 31..30) x direction (bit 29 of pb
+				// set <=> folded phase >= 0), 16 bytes each
+				const uint32_t row = (pb >> 25) & 0x70u;
 				const i32x4 m = *reinterpret_cast<const i32x4 *>(
-					reinterpret_cast<const char *>(&rot_tab[0][0]) + q16);
-				int64_t fx = 0, fy = 0;
-				op_mad(fx, iy, m[2]);		// -s * i_y
-				op_mad(fx, ix, m[0]);		// + c * i_x
-				op_mad(fy, iy, m[0]);		//  c * i_y
-				op_mad(fy, ix, m[1]);		// + s * i_x
+					reinterpret_cast<const char *>(&rot_tab[0][0]) + row);
+				int64_t fx = op_mul(iy, m[2]);	// -B * i_y
+				op_mad(fx, ix, m[0]);		// + A * i_x
+				int64_t fy = op_mul(iy, m[0]);	//  A * i_y
+				op_mad(fy, ix, m[1]);		// + B * i_x
 				x[v] = fx;
 				y[v] = fy;
-				p[v] = (int64_t)((pb & 0x3fffffffu) - 0x20000000u);
+				p[v] = (int64_t)((pb & 0x3fffffffu) - 0x20000000u
+						+ (uint32_t)m[3]);
 			} else {
 				const int32_t ix = sext32(tx[v], kp.iw);
 				const int32_t iy = sext32(ty[v], kp.iw);
@@ -678,7 +708,9 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		} else {
 			constexpr int LJ = C::lj;
 			constexpr int G = (NGEN < NLIVE) ? NGEN : NLIVE;
-			RotChain<Wide64, G, G, 0, DYN>::run(x, y, p, kp);
+			if (!fold1)	// else stage 1 came out of the fold's multiply-adds
+				RotChain<Wide64, (G < 1 ? G : 1), G, 0, DYN>::run(x, y, p, kp);
+			RotChain<Wide64, G, G, 1, DYN>::run(x, y, p, kp);
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {
 				x[v] = (int64_t)((uint64_t)x[v] << LJ);
@@ -1309,15 +1341,6 @@ __device__ __forceinline__ void pol_stage1_lj(int64_t &x, int64_t &y, int64_t &p
 	op_mad(x, sy, t);
 	op_mad(y, sx, nt);
 	op_mad_s(p, a, t);
-}
-
-// acc = a * b (v_mad_i64_i32 with the inline constant 0 as addend: no zeroed
-// register pair)
-__device__ __forceinline__ int64_t op_mul(int32_t a, int32_t b)
-{
-	int64_t d;
-	asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
-	return d;
 }
 
 template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false>
