@@ -341,6 +341,40 @@ __device__ __forceinline__ void rot_stage_lj(int64_t &x, int64_t &y, int64_t &p,
 	op_mad_s(p, a_scaled, ns);
 }
 
+// The first 31-LJ stages (k < 32-LJ) on the same left-justified pairs:
+// (y >>> k) no longer fits the high word alone,
+//     y >>> k = hi(y~) * 2^D + r,   D = 32-LJ-k,   r = the top D bits of lo(y~),
+// so (y >>> k) << LJ = hi * 2^(32-k) + r * 2^LJ: two more multiply-adds per
+// coordinate (three for k = 1, whose 2^31 is applied as 2 * 2^30) and one
+// shift for r, against ~18 instructions for the explicit 64-bit shift /
+// conditional negate / add of the GENERAL form.
+template <int LJ, int K>
+__device__ __forceinline__ void rot_stage_lj_early(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a_scaled, const LjRegs &c)
+{
+	static_assert(K >= 1 && K < LjConst<LJ>::first, "late stages use rot_stage_lj");
+	constexpr int D = LjConst<LJ>::first - K;
+	const uint32_t ph = (uint32_t)((uint64_t)p >> 32);
+	const int32_t s = (int32_t)op_and_or(ph, c.bit, c.mask);	// +/- 2^LJ
+	const int32_t ns = (int32_t)op_and_xor(ph, c.maskbit, c.mask);	// -s
+	// +/- 2^(32-k), halved for k = 1 and applied twice
+	constexpr int up = (K == 1) ? 30 - LJ : 32 - K - LJ;
+	const int32_t sh = (int32_t)((uint32_t)s << up);
+	const int32_t nsh = (int32_t)((uint32_t)ns << up);
+	const int32_t yh = (int32_t)((uint64_t)y >> 32), xh = (int32_t)((uint64_t)x >> 32);
+	const int32_t yr = (int32_t)((uint32_t)y >> (32 - D));
+	const int32_t xr = (int32_t)((uint32_t)x >> (32 - D));
+	op_mad(x, yh, nsh);
+	op_mad(y, xh, sh);
+	if constexpr (K == 1) {
+		op_mad(x, yh, nsh);
+		op_mad(y, xh, sh);
+	}
+	op_mad(x, yr, ns);
+	op_mad(y, xr, s);
+	op_mad_s(p, a_scaled, ns);
+}
+
 template <int LJ, int NLIVE, int I, bool DYN = false> struct RotChainLJ {
 	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
 			int64_t (&y)[kVec], int64_t (&p)[kVec], const CoreParams &kp,
@@ -350,8 +384,12 @@ template <int LJ, int NLIVE, int I, bool DYN = false> struct RotChainLJ {
 			if (!DYN || I < kp.nlive) {
 				const uint32_t a = kp.angle[I] << (31 - LJ);
 #pragma unroll
-				for (int v = 0; v < kVec; v++)
-					rot_stage_lj<LJ, I + 1>(x[v], y[v], p[v], a, c);
+				for (int v = 0; v < kVec; v++) {
+					if constexpr (I + 1 < LjConst<LJ>::first)
+						rot_stage_lj_early<LJ, I + 1>(x[v], y[v], p[v], a, c);
+					else
+						rot_stage_lj<LJ, I + 1>(x[v], y[v], p[v], a, c);
+				}
 				RotChainLJ<LJ, NLIVE, I + 1, DYN>::run(x, y, p, kp, c);
 			}
 		}
@@ -583,8 +621,9 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			T fx, fy;
 			uint32_t fp;
 			fold_octant<T>(ex, ey, (uint32_t)threadIdx.x << 30, fx, fy, fp);
-			fold_tab[threadIdx.x][0] = (int64_t)(Z)fx;
-			fold_tab[threadIdx.x][1] = (int64_t)(Z)fy;
+			// (left-justified kernels: stored as the stages carry them)
+			fold_tab[threadIdx.x][0] = (int64_t)((uint64_t)(int64_t)(Z)fx << C::lj);
+			fold_tab[threadIdx.x][1] = (int64_t)((uint64_t)(int64_t)(Z)fy << C::lj);
 		}
 		__syncthreads();
 	} else if constexpr (kMadFold) {
@@ -707,18 +746,21 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 			}
 		} else {
 			constexpr int LJ = C::lj;
-			constexpr int G = (NGEN < NLIVE) ? NGEN : NLIVE;
-			if (!fold1)	// else stage 1 came out of the fold's multiply-adds
-				RotChain<Wide64, (G < 1 ? G : 1), G, 0, DYN>::run(x, y, p, kp);
-			RotChain<Wide64, G, G, 1, DYN>::run(x, y, p, kp);
+			// left-justified from the first stage on (rot_stage_lj_early
+			// serves the stages whose shift is below 32-LJ); the constant
+			// vectors come out of their table already shifted
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {
-				x[v] = (int64_t)((uint64_t)x[v] << LJ);
-				y[v] = (int64_t)((uint64_t)y[v] << LJ);
+				if constexpr (!kConstXY) {
+					x[v] = (int64_t)((uint64_t)x[v] << LJ);
+					y[v] = (int64_t)((uint64_t)y[v] << LJ);
+				}
 				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)(uint32_t)p[v]
 						<< 31);
 			}
-			RotChainLJ<LJ, NLIVE, G, DYN>::run(x, y, p, kp, ljc);
+			if (!fold1)	// else stage 1 came out of the fold's multiply-adds
+				RotChainLJ<LJ, (NLIVE < 1 ? NLIVE : 1), 0, DYN>::run(x, y, p, kp, ljc);
+			RotChainLJ<LJ, NLIVE, 1, DYN>::run(x, y, p, kp, ljc);
 			if (kp.r_lj == 32) {
 #pragma unroll
 				for (int v = 0; v < kVec; v++) {
