@@ -1315,7 +1315,8 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 //
 // topolar_unrolled spends 8 VALU instructions per micro-rotation (sign mask,
 // |1, ^-2, two shifts, three multiply-adds).  For cores whose registers cannot
-// overflow and fit 32 bits (WW <= 32, cfg.needs_wrap == 0) this form needs 7:
+// overflow and fit 34 bits (WW <= 34, cfg.needs_wrap == 0: the folded ports
+// e = i << in_shl then still fit 32 bits) this form needs 7:
 // x, y are carried LEFT-justified by 30 bits in their register pairs
 // (x~ = x << 30) from stage 2 on, so that (y >>> k) is an arithmetic shift of
 // the HIGH word by k-2 and the multipliers +/-2^30 come straight off the sign
@@ -1385,6 +1386,26 @@ __device__ __forceinline__ void pol_stage1_lj(int64_t &x, int64_t &y, int64_t &p
 	op_mad_s(p, a, t);
 }
 
+// Stage 1 of a core with WW = 33 or 34: (y >>> 1) has 32 or 33 bits and does
+// not fit the multiplicand; with hi = the high word (= y >>> 2) and r = the top
+// bit of the low word (= bit 1 of y),  (y >>> 1) << 30 = hi * 2^31 + r * 2^30:
+// the high word twice and r once at +/-2^30 (cf. rot_stage_lj_early).
+__device__ __forceinline__ void pol_stage1_lj_early(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a, const PolLjRegs &c)
+{
+	const int32_t yh = (int32_t)((uint64_t)y >> 32), xh = (int32_t)((uint64_t)x >> 32);
+	const int32_t t = (int32_t)op_and_or((uint32_t)yh, c.p30, c.sign);
+	const int32_t nt = (int32_t)((uint32_t)t ^ c.sign);
+	const int32_t yr = (int32_t)((uint32_t)y >> 31), xr = (int32_t)((uint32_t)x >> 31);
+	op_mad(x, yh, t);
+	op_mad(y, xh, nt);
+	op_mad(x, yh, t);
+	op_mad(y, xh, nt);
+	op_mad(x, yr, t);
+	op_mad(y, xr, nt);
+	op_mad_s(p, a, t);
+}
+
 template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false>
 __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 		const typename IO::ivec *__restrict__ xin,
@@ -1396,7 +1417,7 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	c.sign = vgpr_const(0x80000000u);
 	c.p30 = vgpr_const(0x40000000u);
 	// rounding at the 2^30 scale: the retained bits start at bit r-2 of the
-	// high word (cores with r < 2 take the 32-bit form below)
+	// high word (cores with r < 2 or r > 31 take the plain 64-bit form below)
 	const uint32_t rbw = vgpr_const(kp.round_bit);	// width of the tie bit: 0 or 1
 	const int up = 32 - kp.iw;			// port -> sign bit of the word
 	const int down = up - kp.in_shl;		// ... and back to e = i << in_shl
@@ -1443,17 +1464,24 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 			const uint32_t l = ((uint32_t)mx ^ c.sign) >> 1;
 			p[v] = op_mul(nmy, (int32_t)l);
 		}
+		if (down >= 2) {	// WW <= 32
 #pragma unroll
-		for (int v = 0; v < kVec; v++)		// rtl/topolar.v:226-243, k = 1
-			pol_stage1_lj(x[v], y[v], p[v], kp.angle[0], c);
+			for (int v = 0; v < kVec; v++)	// rtl/topolar.v:226-243, k = 1
+				pol_stage1_lj(x[v], y[v], p[v], kp.angle[0], c);
+		} else {		// WW = 33, 34: (y >>> 1) needs more than 32 bits
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				pol_stage1_lj_early(x[v], y[v], p[v], kp.angle[0], c);
+		}
 
 		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp);
 
 		i32x4 rm;
 		u32x4 rp;
-		if (kp.r >= 2) {
+		if (kp.r >= 2 && kp.r <= 31) {
 			// rtl/topolar.v:251-263 at the 2^30 scale: tie bit r of x is
-			// bit r-2 of the high word
+			// bit r-2 of the high word (r <= 31: base + tie bit <= 2^30
+			// is a valid signed multiplicand)
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {
 				const uint32_t xh = (uint32_t)((uint64_t)x[v] >> 32);
@@ -1465,8 +1493,8 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 			}
 		} else {
 #pragma unroll
-			for (int v = 0; v < kVec; v++)
-				rm[v] = round_to_ow<int32_t>((int32_t)(x[v] >> 30), kp);
+			for (int v = 0; v < kVec; v++)	// x may have 34 bits
+				rm[v] = round_to_ow<int64_t>(x[v] >> 30, kp);
 		}
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {

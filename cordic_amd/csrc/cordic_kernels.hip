@@ -667,7 +667,7 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 			if (io16)
 				done = launch_pol_narrow16(cfg.nlive, grid, st, kp, x, y,
 						mag, phase, n);
-			else if (cfg.ww <= 32 && !cfg.needs_wrap
+			else if (cfg.ww <= 34 && !cfg.needs_wrap
 					&& !(cfg.flags & CORDIC_FLAG_NO_LJ)
 					&& cfg.nlive >= 1)
 				done = launch_pol_lj(cfg.nlive, grid, st, kp, x, y, mag,

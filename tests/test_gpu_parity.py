@@ -130,13 +130,18 @@ def test_exhaustive_p2r_checked_in_core_and_bench_criteria():
     assert abs(q["cnr"] - cfg.best_possible_cnr) < 0.5
 
 
-POL_LJ_CASES = [   # (iw, ow, xtra, pw, nstages): WW <= 32
+POL_LJ_CASES = [   # (iw, ow, xtra, pw, nstages): WW <= 34 (the last rows: 33, 34)
     (24, 24, 2, -1, 20), (24, 24, 2, -1, 16), (24, 24, 2, -1, 18),
     (24, 24, 2, -1, 24), (24, 24, 2, -1, 22), (13, 13, 2, -1, -1),
     (16, 16, 2, -1, -1), (20, 24, 1, 30, 19), (26, 26, 0, -1, 24),
     (8, 8, 2, -1, -1), (12, 16, 3, -1, 12), (24, 24, 2, 32, 3),
     (24, 24, 2, 32, 2), (24, 24, 2, 32, 11), (24, 24, 2, 32, 1),
     (24, 24, 2, 32, 30), (22, 22, 3, 32, 37), (10, 10, 2, 32, 28),
+    (25, 25, 2, 32, 20), (26, 26, 2, 32, 20), (27, 27, 1, 32, 24),
+    (26, 24, 2, 32, 1), (28, 28, 0, 32, 31), (26, 13, 2, 24, 16),
+    # WW - OW >= 32: the rounding increment no longer fits a signed
+    # multiplicand (found by tools/fuzz_gpu.py: r2p -i 28 -o 2 -x 1 -p 7 -n 55)
+    (28, 2, 1, 7, 55), (26, 1, 2, 24, 16), (26, 2, 2, 24, 16), (25, 2, 2, 24, 9),
 ]
 
 
@@ -151,7 +156,9 @@ def test_r2p_left_justified_form(args, mode):
         cfg, ocfg = both(mode, *args)
     except ca.CordicError:
         pytest.skip("core refused (sequential corner case)")
-    assert cfg.ww <= 32 and not cfg.needs_wrap and cfg.nlive >= 1
+    if cfg.needs_wrap:
+        pytest.skip("registers can overflow: the explicit-wrap kernels serve this core")
+    assert cfg.ww <= 34 and cfg.nlive >= 1
     rng = np.random.RandomState(7)
     n = (1 << 17) + 3
     lim = 1 << (cfg.iw - 1)

@@ -65,7 +65,14 @@ for t in range(ncfg):
     else:
         a = gpu_r2p(cfg, x, y)
         b = O.topolar(ocfg, x, y)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (t, "r2p")
+        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            bad = np.nonzero((a[0] != b[0]) | (a[1] != b[1]))[0]
+            raise SystemExit("r2p mismatch: cli=%r ww=%d nlive=%d n=%d first bad %d "
+                             "x=%d y=%d gpu=(%d,%#x) oracle=(%d,%#x) (%d bad)"
+                             % ((mode, iw, ow, xtra, pw, ns), cfg.ww, cfg.nlive, n,
+                                bad[0], x[bad[0]], y[bad[0]], a[0][bad[0]],
+                                int(a[1][bad[0]]) & 0xffffffff, b[0][bad[0]],
+                                int(b[1][bad[0]]) & 0xffffffff, bad.size))
     done += 1
 print("fuzz ok: %d cores checked, %d refused by both; paths %s" % (done, refused, paths))
 
