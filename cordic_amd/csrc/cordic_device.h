@@ -1508,6 +1508,153 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	}
 }
 
+// ------------------------- converter, left-justified form for WW = 35 .. 40
+//
+// Same idea as topolar_lj with the justification LJ = 64 - WW (29 .. 24; one
+// dynamic-exit instance per width: 32-bit I/Q at the default two extra bits is
+// WW = 40):
+//   * the ports are left-justified in their 32-bit words (e' = i << (32-IW));
+//     with multipliers +/-2^30 the fold's four multiply-adds then deliver
+//     x0 << LJ exactly (32 - IW + 30 = in_shl + LJ);
+//   * the sign of y no longer reaches bit LJ+1 of the high word, so the stage
+//     multiplier takes two instructions (sign mask, v_bitop3_b32) instead of
+//     one: 8 per regular stage;
+//   * stages with k < 32 - LJ take the early form (cf. rot_stage_lj_early):
+//     (y >>> k) << LJ = hi * 2^(32-k) + r * 2^LJ, r = the top 32-LJ-k bits of
+//     the low word -- 12 instructions (14 for k = 1) against ~18 for the explicit
+//     64-bit form of topolar_unrolled<Wide64>.
+// rtl/topolar.v:122-152, 217-243, 251-271: same values, bit for bit.
+struct PolWideRegs { uint32_t mask, bit; };	// ~(2^(LJ+1) - 1), 2^LJ in VGPRs
+
+template <int LJ, int K>
+__device__ __forceinline__ void pol_stage_w(int64_t &x, int64_t &y, int64_t &p,
+		uint32_t a, const PolWideRegs &c)
+{
+	constexpr int first = 32 - LJ;
+	const int32_t yh = (int32_t)((uint64_t)y >> 32), xh = (int32_t)((uint64_t)x >> 32);
+	const uint32_t d = (uint32_t)(yh >> 31);
+	const int32_t t = (int32_t)op_and_or(d, c.bit, c.mask);		// +/- 2^LJ
+	const int32_t nt = (int32_t)((uint32_t)t ^ c.mask);		// -t
+	if constexpr (K >= first) {
+		constexpr int sh = (K - first > 31) ? 31 : K - first;
+		const int32_t sy = yh >> sh, sx = xh >> sh;
+		op_mad(x, sy, t);
+		op_mad(y, sx, nt);
+	} else {
+		constexpr int dbits = first - K;
+		constexpr int up = (K == 1) ? 30 - LJ : 32 - K - LJ;
+		const int32_t th = (int32_t)((uint32_t)t << up);
+		const int32_t nth = (int32_t)((uint32_t)nt << up);
+		const int32_t yr = (int32_t)((uint32_t)y >> (32 - dbits));
+		const int32_t xr = (int32_t)((uint32_t)x >> (32 - dbits));
+		op_mad(x, yh, th);
+		op_mad(y, xh, nth);
+		if constexpr (K == 1) {
+			op_mad(x, yh, th);
+			op_mad(y, xh, nth);
+		}
+		op_mad(x, yr, t);
+		op_mad(y, xr, nt);
+	}
+	op_mad_s(p, a, t);		// p' = p + t * a_k
+}
+
+template <int LJ, int NLIVE, int I> struct PolChainW {
+	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
+			int64_t (&y)[kVec], int64_t (&p)[kVec], const PolWideRegs &c,
+			const CoreParams &kp)
+	{
+		if constexpr (I < NLIVE) {
+			if (I < kp.nlive) {
+#pragma unroll
+				for (int v = 0; v < kVec; v++)
+					pol_stage_w<LJ, I + 1>(x[v], y[v], p[v], kp.angle[I], c);
+				PolChainW<LJ, NLIVE, I + 1>::run(x, y, p, c, kp);
+			}
+		}
+	}
+};
+
+template <int LJ, int NLIVE, typename IO = Io32, bool UG = false>
+__global__ __launch_bounds__(kBlock) void topolar_ljw(CoreParams kp,
+		const typename IO::ivec *__restrict__ xin,
+		const typename IO::ivec *__restrict__ yin,
+		typename IO::ivec *__restrict__ omag,
+		typename IO::uvec *__restrict__ oph, size_t nvec)
+{
+	PolWideRegs c;
+	c.bit = vgpr_const(1u << LJ);
+	c.mask = vgpr_const(~((2u << LJ) - 1u));
+	const uint32_t sign = vgpr_const(0x80000000u), p30 = vgpr_const(0x40000000u);
+	const uint32_t rbw = vgpr_const(kp.round_bit);
+	const int up = 32 - kp.iw;
+	// the rounded magnitude is bits r+LJ .. of x~: in the high word if
+	// r + LJ >= 32, with the increment (base + tie) a signed multiplicand
+	const bool round_hi = kp.r + LJ >= 32 && kp.r <= 31;
+
+	const size_t stride = (size_t)gridDim.x * kBlock;
+	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	typename IO::ivec nx{}, ny{};		// software prefetch
+	if (g < nvec) {
+		nx = xin[g];
+		ny = yin[g];
+	}
+	for (; g < nvec; g += stride) {
+		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
+		const size_t gn = g + stride;
+		if (gn < nvec) {
+			nx = xin[gn];
+			ny = yin[gn];
+		}
+		int64_t x[kVec], y[kVec], p[kVec];
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const int32_t ex = (int32_t)((uint32_t)tx[v] << up);
+			const int32_t ey = (int32_t)((uint32_t)ty[v] << up);
+			// fold and quadrant phase exactly as in topolar_lj, the phase
+			// at the 2^LJ scale of the stages
+			const int32_t mx = (int32_t)op_and_or((uint32_t)ex, p30, sign);
+			const int32_t my = (int32_t)op_and_or((uint32_t)ey, p30, sign);
+			const int32_t nmy = (int32_t)((uint32_t)my ^ sign);
+			x[v] = op_mul(ex, mx);
+			op_mad(x[v], ey, my);
+			y[v] = op_mul(ey, mx);
+			op_mad(y[v], ex, nmy);
+			const uint32_t l = ((uint32_t)mx ^ sign) >> 1;	// 2^29 (2 + sx)
+			p[v] = op_mul(nmy >> (30 - LJ), (int32_t)l);	// -sy 2^LJ
+		}
+
+		PolChainW<LJ, NLIVE, 0>::run(x, y, p, c, kp);
+
+		i32x4 rm;
+		u32x4 rp;
+		if (round_hi) {
+			const int sh = kp.r + LJ - 32;
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				const uint32_t xh = (uint32_t)((uint64_t)x[v] >> 32);
+				uint32_t b;
+				asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(b)
+					: "v"(xh), "s"(sh), "v"(rbw));
+				op_mad_s(x[v], 1u << LJ, (int32_t)(b + (uint32_t)kp.round_base));
+				rm[v] = (int32_t)((uint64_t)x[v] >> 32) >> sh;
+			}
+		} else {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				rm[v] = round_to_ow<int64_t>(x[v] >> LJ, kp);
+		}
+#pragma unroll
+		for (int v = 0; v < kVec; v++) {
+			const uint32_t acc = (uint32_t)((uint64_t)p[v] >> LJ);
+			rp[v] = (acc + 0x80000000u) >> kp.pw_shl;	// rtl/topolar.v:269
+		}
+		apply_unit_gain<UG>(rm, kp);
+		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
+		CORDIC_STORE_OUT(true, &oph[g], IO::narrow(rp));
+	}
+}
+
 } // namespace dev
 } // namespace cordic_amd
 #endif

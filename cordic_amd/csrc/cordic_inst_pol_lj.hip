@@ -1,6 +1,6 @@
 // cordic_inst_pol_lj.hip -- instances of the left-justified converter
-// (cordic_device.h: topolar_lj): r2p / sr2p cores with WW <= 32 whose registers
-// cannot overflow.
+// (cordic_device.h: topolar_lj, topolar_ljw): r2p / sr2p cores with WW <= 34 /
+// WW 35 .. 40 whose registers cannot overflow.
 #include <hip/hip_runtime.h>
 
 #include "cordic_device.h"
@@ -34,6 +34,42 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y,
 			(i32x4 *)mag, (u32x4 *)ph, n / kVec);
 		return true;
+	}
+}
+
+// WW = 35 .. 40: one dynamic-exit instance per width (LJ = 64 - WW)
+namespace {
+template <int LJ>
+void launch_ljw(int grid, hipStream_t st, const dev::CoreParams &kp, const int32_t *x,
+		const int32_t *y, int32_t *mag, uint32_t *ph, size_t n)
+{
+	using namespace dev;
+	if (kp.post_mul != 0)
+		hipLaunchKernelGGL((topolar_ljw<LJ, kDynStages, Io32, true>), dim3(grid),
+			dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y,
+			(i32x4 *)mag, (u32x4 *)ph, n / kVec);
+	else
+		hipLaunchKernelGGL((topolar_ljw<LJ, kDynStages>), dim3(grid),
+			dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y,
+			(i32x4 *)mag, (u32x4 *)ph, n / kVec);
+}
+} // namespace
+
+bool launch_pol_ljw(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
+		const int32_t *x, const int32_t *y, int32_t *mag, uint32_t *ph,
+		size_t n)
+{
+	using namespace dev;
+	if (nlive < 1 || nlive > kDynStages)
+		return false;
+	switch (kp.iw + kp.in_shl + 2) {	// WW (r2p: in_shl = WW - IW - 2)
+	case 35: launch_ljw<29>(grid, st, kp, x, y, mag, ph, n); return true;
+	case 36: launch_ljw<28>(grid, st, kp, x, y, mag, ph, n); return true;
+	case 37: launch_ljw<27>(grid, st, kp, x, y, mag, ph, n); return true;
+	case 38: launch_ljw<26>(grid, st, kp, x, y, mag, ph, n); return true;
+	case 39: launch_ljw<25>(grid, st, kp, x, y, mag, ph, n); return true;
+	case 40: launch_ljw<24>(grid, st, kp, x, y, mag, ph, n); return true;
+	default: return false;
 	}
 }
 

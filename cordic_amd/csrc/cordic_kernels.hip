@@ -664,14 +664,21 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		bool done = false;
 		if (n >= (size_t)kVec) {
 			const int ngen = general_stages_for(cfg.ww);
+			const bool lj_ok = !io16 && !cfg.needs_wrap && cfg.nlive >= 1
+					&& !(cfg.flags & CORDIC_FLAG_NO_LJ);
 			if (io16)
 				done = launch_pol_narrow16(cfg.nlive, grid, st, kp, x, y,
 						mag, phase, n);
-			else if (cfg.ww <= 34 && !cfg.needs_wrap
-					&& !(cfg.flags & CORDIC_FLAG_NO_LJ)
-					&& cfg.nlive >= 1)
+			else if (lj_ok && cfg.ww <= 34)
 				done = launch_pol_lj(cfg.nlive, grid, st, kp, x, y, mag,
 						phase, n);
+			else if (lj_ok && cfg.ww <= 40)
+				done = launch_pol_ljw(cfg.nlive, grid, st, kp, x, y, mag,
+						phase, n);
+			if (done)
+				;
+			else if (io16)
+				;
 			else if (cfg.ww <= 32)
 				done = launch_pol_narrow(cfg.nlive, grid, st, kp, x, y,
 						mag, phase, n);

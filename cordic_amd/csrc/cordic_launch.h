@@ -46,6 +46,7 @@ CORDIC_POL_LAUNCHER(launch_pol_narrow);
 // WW <= 32, no reachable overflow: left-justified form, 7 instructions per
 // micro-rotation (cordic_device.h: topolar_lj)
 CORDIC_POL_LAUNCHER(launch_pol_lj);
+CORDIC_POL_LAUNCHER(launch_pol_ljw);
 CORDIC_POL_LAUNCHER(launch_pol_wide8);
 CORDIC_POL_LAUNCHER(launch_pol_wideall);
 // int16 / uint16 sample arrays (WW <= 32 only: the ports are <= 16 bits);

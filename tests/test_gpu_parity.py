@@ -180,6 +180,49 @@ def test_r2p_left_justified_form(args, mode):
     assert np.array_equal(m, m2) and np.array_equal(p, p2)
 
 
+POL_LJW_CASES = [  # (iw, ow, xtra, pw, nstages): WW 35 .. 40, run-time justification
+    (27, 27, 2, 32, 20), (28, 28, 2, 32, 20), (29, 29, 2, 32, 24),
+    (30, 30, 2, 32, 18), (31, 31, 1, 32, 22), (32, 32, 2, 32, 20),
+    (32, 32, 2, 32, 32), (32, 32, 0, 32, 16), (32, 16, 2, 32, 12),
+    (32, 32, 2, 32, 1), (32, 32, 2, 32, 2), (32, 32, 2, 32, 7),
+    (32, 32, 2, 32, 8), (32, 32, 2, 32, 9), (30, 2, 2, 24, 16),
+    (32, 1, 2, 16, 11), (32, 32, 2, 32, 45), (29, 32, 1, 30, 26),
+]
+
+
+@pytest.mark.parametrize("mode", [ca.R2P, ca.SR2P])
+@pytest.mark.parametrize("args", POL_LJW_CASES)
+def test_r2p_wide_left_justified_form(args, mode):
+    """topolar_ljw (WW 35..40: justification 64 - WW at run time, early stages
+    as extra multiply-adds) against the oracle and against the round-1 wide
+    kernels (CORDIC_FLAG_NO_LJ)."""
+    try:
+        cfg, ocfg = both(mode, *args)
+    except ca.CordicError:
+        pytest.skip("core refused (sequential corner case)")
+    if cfg.needs_wrap:
+        pytest.skip("registers can overflow: the explicit-wrap kernels serve this core")
+    assert 35 <= cfg.ww <= 40 and cfg.nlive >= 1
+    rng = np.random.RandomState(11)
+    n = (1 << 17) + 3
+    lim = 1 << (cfg.iw - 1)
+    x = rng.randint(-lim, lim, size=n, dtype=np.int64).astype(np.int32)
+    y = rng.randint(-lim, lim, size=n, dtype=np.int64).astype(np.int32)
+    sp = np.array([0, 1, -1, lim - 1, -lim, lim // 2, -(lim // 2), 2, -2, 3],
+                  dtype=np.int64).astype(np.int32)
+    gx, gy = np.meshgrid(sp, sp)
+    x[:100], y[:100] = gx.ravel(), gy.ravel()
+    small = rng.randint(-8, 8, size=(2, 4096)).astype(np.int32)
+    x[100:4196], y[100:4196] = small[0], small[1]
+    x[4196:8292] = rng.randint(-lim, lim, size=4096, dtype=np.int64).astype(np.int32)
+    y[4196:8292] = 0
+    m, p = gpu_r2p(cfg, x, y)
+    rm, rp = O.topolar(ocfg, x, y)
+    assert np.array_equal(m, rm) and np.array_equal(p, rp)
+    m2, p2 = gpu_r2p(cfg.with_flags(ca.FLAG_NO_LJ), x, y)
+    assert np.array_equal(m, m2) and np.array_equal(p, p2)
+
+
 def test_exhaustive_r2p_checked_in_core_and_bench_criteria():
     cfg, ocfg = both(ca.R2P, 13, 13, 2)
     x, y, mg = Q.r2p_bench_inputs(cfg.iw, cfg.pw)
