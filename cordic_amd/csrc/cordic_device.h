@@ -155,6 +155,13 @@ template <int LJ> struct WideLJ {
 	static constexpr int lj = LJ;
 	static constexpr int ngen = 31 - LJ;	// stages with k < 32-LJ
 };
+// Scale of the residual phase in those kernels: p~ = sext(P) << ps.  The stage
+// multipliers are read off the bits of hi(p~) above bit LJ, which therefore
+// have to be sign bits: |P| <= 2^29 gives |hi(p~)| <= 2^(ps-3), so ps <= LJ+2
+// (31 for LJ = 29, 30; the angles are applied as a << (ps - LJ)).
+template <int LJ> struct LjPhase {
+	static constexpr int ps = (LJ + 2 > 31) ? 31 : LJ + 2;
+};
 
 // ------------------------------------------------------- rotator: p2r stage
 
@@ -382,7 +389,7 @@ template <int LJ, int NLIVE, int I, bool DYN = false> struct RotChainLJ {
 	{
 		if constexpr (I < NLIVE) {
 			if (!DYN || I < kp.nlive) {
-				const uint32_t a = kp.angle[I] << (31 - LJ);
+				const uint32_t a = kp.angle[I] << (LjPhase<LJ>::ps - LJ);
 #pragma unroll
 				for (int v = 0; v < kVec; v++) {
 					if constexpr (I + 1 < LjConst<LJ>::first)
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 					y[v] = (int64_t)((uint64_t)y[v] << LJ);
 				}
 				p[v] = (int64_t)((uint64_t)(int64_t)(int32_t)(uint32_t)p[v]
-						<< 31);
+						<< LjPhase<LJ>::ps);
 			}
 			if (!fold1)	// else stage 1 came out of the fold's multiply-adds
 				RotChainLJ<LJ, (NLIVE < 1 ? NLIVE : 1), 0, DYN>::run(x, y, p, kp, ljc);

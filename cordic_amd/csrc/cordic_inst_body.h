@@ -36,6 +36,7 @@ bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 		return true;
 	}
 	switch (nlive) {
+#ifndef CORDIC_INST_DYN_ONLY	// (units that carry the dynamic-exit instance only)
 #define X(N) case N: \
 	hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER, N, \
 			(G > N ? N : G), FEED>), dim3(grid), dim3(kBlock), 0, st, \
@@ -44,6 +45,7 @@ bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 	return true;
 	CORDIC_ROT_STAGES(X)
 #undef X
+#endif
 	default:
 		// any other count up to kDynStages: the dynamic-exit instance
 		if (nlive < 1 || nlive > kDynStages)

@@ -477,8 +477,8 @@ CoreParams make_params(const cordic_config &c)
 	kp.round_bit = rounding ? 1u : 0u;
 	kp.round_base = rounding ? (((int64_t)1 << (kp.r - 1)) - 1) : 0;
 	kp.wrap = c.needs_wrap && c.ww < 64;
-	// left-justified wide form (WW 33..35): LJ = 29 for WW 35, else 30
-	const int lj = (c.ww == 35) ? 29 : 30;
+	// left-justified wide form: LJ = 64 - WW for WW 35..40, 30 for WW 33, 34
+	const int lj = (c.ww >= 35 && c.ww <= 40) ? 64 - c.ww : 30;
 	kp.r_lj = kp.r + lj;
 	kp.round_base_lj = (int64_t)((uint64_t)kp.round_base << lj);
 	kp.post_mul = (c.flags & CORDIC_FLAG_UNIT_GAIN) ? core_gain_annihilator(c) : 0u;
@@ -569,20 +569,37 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		}
 		if (!done && j.n >= (size_t)kVec) {
 			const int ngen = general_stages_for(cfg.ww);
-			if (j.io16)
+			if (j.io16) {
 				done = launch_rot_narrow16(FEED, cfg.nlive, grid, st, kp, j);
-			else if (cfg.ww <= 32)
+			} else if (cfg.ww <= 32) {
 				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);
-			else if (cfg.ww == 35 && !(cfg.flags & CORDIC_FLAG_NO_LJ))
-				done = launch_rot_lj29(FEED, cfg.nlive, grid, st, kp, j);
-			else if (cfg.ww < 35 && !(cfg.flags & CORDIC_FLAG_NO_LJ))
-				done = launch_rot_lj30(FEED, cfg.nlive, grid, st, kp, j);
-			else if (ngen == 2)
-				done = launch_rot_wide2(FEED, cfg.nlive, grid, st, kp, j);
-			else if (ngen == 8)
-				done = launch_rot_wide8(FEED, cfg.nlive, grid, st, kp, j);
-			else
-				done = launch_rot_wideall(FEED, cfg.nlive, grid, st, kp, j);
+			} else {
+				// left-justified forms first (WW 33..40), the plain
+				// 64-bit kernels for everything else
+				if (cfg.flags & CORDIC_FLAG_NO_LJ)
+					;
+				else if (cfg.ww == 35)
+					done = launch_rot_lj29(FEED, cfg.nlive, grid, st, kp, j);
+				else if (cfg.ww < 35)
+					done = launch_rot_lj30(FEED, cfg.nlive, grid, st, kp, j);
+				else if (cfg.ww <= 40 && !cfg.needs_wrap) {
+					switch (cfg.ww) {
+					case 36: done = launch_rot_lj28(FEED, cfg.nlive, grid, st, kp, j); break;
+					case 37: done = launch_rot_lj27(FEED, cfg.nlive, grid, st, kp, j); break;
+					case 38: done = launch_rot_lj26(FEED, cfg.nlive, grid, st, kp, j); break;
+					case 39: done = launch_rot_lj25(FEED, cfg.nlive, grid, st, kp, j); break;
+					default: done = launch_rot_lj24(FEED, cfg.nlive, grid, st, kp, j); break;
+					}
+				}
+				if (done)
+					;
+				else if (ngen == 2)
+					done = launch_rot_wide2(FEED, cfg.nlive, grid, st, kp, j);
+				else if (ngen == 8)
+					done = launch_rot_wide8(FEED, cfg.nlive, grid, st, kp, j);
+				else
+					done = launch_rot_wideall(FEED, cfg.nlive, grid, st, kp, j);
+			}
 		}
 		if (done) {
 			// 0..3 trailing samples: generic kernel on the remainder

@@ -32,6 +32,11 @@ constexpr int kAllGeneral = 1 << 20;
 CORDIC_ROT_LAUNCHER(launch_rot_narrow);		// WW <= 32
 CORDIC_ROT_LAUNCHER(launch_rot_lj29);		// WW == 35
 CORDIC_ROT_LAUNCHER(launch_rot_lj30);		// WW == 33, 34
+CORDIC_ROT_LAUNCHER(launch_rot_lj28);		// WW == 36 .. 40: LJ = 64 - WW,
+CORDIC_ROT_LAUNCHER(launch_rot_lj27);		// dynamic-exit instances only
+CORDIC_ROT_LAUNCHER(launch_rot_lj26);
+CORDIC_ROT_LAUNCHER(launch_rot_lj25);
+CORDIC_ROT_LAUNCHER(launch_rot_lj24);
 CORDIC_ROT_LAUNCHER(launch_rot_wide2);		// WW <= 35 (kept for A/B)
 CORDIC_ROT_LAUNCHER(launch_rot_wide8);		// WW <= 41
 CORDIC_ROT_LAUNCHER(launch_rot_wideall);	// WW <= 64

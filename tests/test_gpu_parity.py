@@ -338,10 +338,20 @@ def test_tiny_cores_wrap_like_the_registers():
 
 
 def test_left_justified_kernel_equals_right_justified_kernel():
-    """WW 33..35: the LJ kernels against the plain 64-bit unrolled kernel."""
+    """WW 33..40: the LJ kernels (early stages as extra multiply-adds; WW 36..40
+    with the justification 64 - WW and the phase at 2^(LJ+2)) against the plain
+    64-bit unrolled kernel and the oracle: per-sample vectors, constant vectors
+    with and without the seed table, the fused NCO."""
     for args in [(ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
                  (ca.SP2R, 32, 32, 2, 32, 16), (ca.P2R, 30, 30, 2, 32, 16),
-                 (ca.P2R, 31, 31, 2, 30, 20)]:
+                 (ca.P2R, 31, 31, 2, 30, 20),
+                 (ca.P2R, 32, 32, 3, 32, 16), (ca.P2R, 32, 32, 4, 32, 20),
+                 (ca.P2R, 32, 32, 5, 32, 24), (ca.P2R, 32, 32, 6, 32, 20),
+                 (ca.P2R, 32, 32, 7, 32, 20), (ca.SP2R, 32, 32, 7, 32, 32),
+                 (ca.P2R, 32, 24, 7, 32, 1), (ca.P2R, 32, 32, 7, 32, 2),
+                 (ca.P2R, 32, 32, 7, 32, 7), (ca.P2R, 32, 32, 7, 32, 8),
+                 (ca.P2R, 30, 32, 6, 28, 19), (ca.P2R, 32, 8, 4, 24, 12),
+                 (ca.P2R, 32, 32, 7, 32, 44)]:
         cfg, ocfg = both(*args)
         rj = cfg.with_flags(ca.FLAG_NO_LJ)
         rng = np.random.RandomState(18)
@@ -349,8 +359,19 @@ def test_left_justified_kernel_equals_right_justified_kernel():
         a = gpu_p2r(cfg, x, y, ph)
         b = gpu_p2r(rj, x, y, ph)
         c = O.rotate(ocfg, x, y, ph)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), args
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), args
+        lim = 1 << (cfg.iw - 1)
+        for x0, y0 in ((lim - 1, 0), (-lim, -lim), (12345 % lim, -(777 % lim))):
+            for flags in (0, ca.FLAG_NO_SEED):
+                plan = ca.Plan(cfg.with_flags(flags))
+                a = gpu_plan_p2r(plan, x0, y0, ph)
+                c = O.rotate(ocfg, x0, y0, ph)
+                assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), args
+                a = gpu_plan_nco(plan, 30001, 0x1234, 0x01234567, 1 << 33, x0, y0)
+                c = O.nco(ocfg, 30001, 0x1234, 0x01234567, 1 << 33, x0, y0)
+                assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), args
+                plan.close()
 
 
 def test_generic_kernel_equals_unrolled_kernel():
