@@ -332,6 +332,31 @@ def measure_pmc(args):
 _probe_lib = None
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL
+# prints a five-line version banner when its first communicator comes up), so
+# main() points file descriptor 1 at stderr for the life of the process and
+# emit() writes the line to the original stdout.
+_STDOUT_FD = None
+
+
+def claim_stdout():
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _STDOUT_FD is None:
+        print(line)
+        return
+    data = (line + "\n").encode()
+    while data:
+        data = data[os.write(_STDOUT_FD, data):]
+
+
 class PowerSampler(threading.Thread):
     """Socket power and shader clock of one GPU while it works, read by a host
     thread from the amdgpu hwmon files of THAT device (matched by PCI bus id):
@@ -501,7 +526,7 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         ok = bool(np.array_equal(out[ti].cpu().numpy(), exp))
         avg = float(np.mean(kern_ms)) / 1e3
         achieved = w["bytes"] * n / avg / 1e9
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "Msamples/sec (%s)" % args.workload,
             "value": float(world) * n * args.steps / elapsed / 1e6,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -973,7 +998,7 @@ def run_group(args, w, launch):
         if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
             torch.cuda.empty_cache()
             out["other_paths"] = other_paths(ca, dev)
-        print(json.dumps(out))
+        emit(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
@@ -1329,7 +1354,7 @@ def run_direct(args, w, launch):
             out["full_recurrence_kernel"] = full
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
+        emit(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
@@ -1393,6 +1418,7 @@ def main():
     launch = resolve_launch(args)
     if launch == "spawn":
         respawn(args)               # does not return
+    claim_stdout()
     w = WORKLOADS[args.workload]
     if w["kind"] in RW and not w.get("io16"):
         return run_group(args, w, launch)

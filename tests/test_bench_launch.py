@@ -93,8 +93,10 @@ def test_launch_decisions_and_respawn_command(monkeypatch):
 
 
 def _line(stdout):
-    rows = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(rows) == 1, stdout
+    """The contract: stdout carries ONE line, the JSON record -- nothing else
+    (RCCL's version banner and the like go to stderr)."""
+    rows = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(rows) == 1 and rows[0].startswith("{"), stdout
     return json.loads(rows[0])
 
 
