@@ -413,6 +413,7 @@ int rccl_forward(cordic_group *g, uint64_t n_total, int c)
 	for (Shard &s : g->shards) {
 		uint64_t start, cnt, a, len;
 		shard_span(n_total, s.index, g->total, &start, &cnt);
+		fine = fine && ok(hipSetDevice(s.device));	// the communicator's device
 		if (fine && piece_span(cnt, g->chunks, c, &a, &len)) {
 			fine = api.Send(static_cast<int32_t *>(s.buf[2]) + a, (size_t)len,
 					ncclInt32, g->rroot, s.comm, s.copy) == ncclSuccess
