@@ -459,12 +459,14 @@ def hbm_probe(in0, in1, out0, out1, nwords, r, w, mode, reps, stream=0):
 
 
 def copy_probe(ptrs, n, rw, reps=10):
-    """Both copy patterns over the arrays in `ptrs` = [in0, in1, out0, out1]:
+    """The copy patterns over the arrays in `ptrs` = [in0, in1, out0, out1]:
     `tiles` = the best streaming pattern found on this chip (one-shot 4 KiB
-    tiles), `queued` = the seeded kernel's own work distribution."""
+    tiles), `queued` = the seeded kernel's own work distribution; `_nt` = the
+    same with non-temporal loads and stores."""
     r, w = rw
     res = {}
-    for name, mode in (("tiles", 0), ("queued", 1)):
+    for name, mode in (("tiles", 0), ("queued", 1), ("tiles_nt", 2),
+                       ("queued_nt", 3)):
         ms = hbm_probe(ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, r, w, mode, reps)
         if ms is not None:
             res[name + "_ms"] = ms
@@ -930,14 +932,15 @@ def run_group(args, w, launch):
                         "launches each before and after the timed region "
                         "(tools/hbm_probe_lib.hip)" % RW[kind],
                 "before": probes[0], "after": probes[-1]}
-            if "tiles_ms" in best:
-                cf = w["bytes"] * n / (best["tiles_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            tiles = [best[k] for k in ("tiles_ms", "tiles_nt_ms") if k in best]
+            if tiles:       # the faster of the plain and the non-temporal copy
+                cf = w["bytes"] * n / (min(tiles) * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roof["copy_frac"] = cf
                 roof["frac_over_copy"] = roof["frac"] / cf
-            if "queued_ms" in best:
+            queued = [best[k] for k in ("queued_ms", "queued_nt_ms") if k in best]
+            if queued:
                 roof["copy_frac_same_distribution"] = (
-                    w["bytes"] * n / (best["queued_ms"] * 1e-3) / 1e9
-                    / HBM_PEAK_GBS)
+                    w["bytes"] * n / (min(queued) * 1e-3) / 1e9 / HBM_PEAK_GBS)
         out = {
             "metric": "Msamples/sec (sin+cos pairs) at 16-stage/32-bit"
                       if args.workload == "cfg2" else

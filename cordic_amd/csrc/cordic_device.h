@@ -1171,7 +1171,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			const u32x4 tph = IO::widen(in);
 			if constexpr (FEED != Feed::Nco_ConstXY) {
 				if (nxt != kEnd && lane < live(nxt))
-					pre = CORDIC_LOAD_IN(&(phin + (size_t)nxt * kSeedBlock)[lane]);
+					pre = __builtin_nontemporal_load(
+						&(phin + (size_t)nxt * kSeedBlock)[lane]);
 			}
 			// the ticket for the tile after next: drawn now (behind the
 			// prefetch, so that nothing waits for it here), looked at after
@@ -1183,8 +1184,13 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				const size_t base = (size_t)cur * kSeedBlock;
 				i32x4 rx, ry;
 				pass(base + lane, tph, rx, ry);
-				CORDIC_STORE_OUT(false, &(ox + base)[lane], IO::narrow(rx));
-				CORDIC_STORE_OUT(false, &(oy + base)[lane], IO::narrow(ry));
+				// non-temporal loads AND stores: with the address-ordered
+				// queue they are worth +3 % on cfg2 together (0.80 -> 0.82 of
+				// the HBM peak, either one alone +1 %; same-box A/B,
+				// profiles/r02/ab_nontemporal.txt) -- under the round-1 chunk
+				// walk plain stores had been the faster ones
+				CORDIC_STORE_OUT(true, &(ox + base)[lane], IO::narrow(rx));
+				CORDIC_STORE_OUT(true, &(oy + base)[lane], IO::narrow(ry));
 			}
 			if (threadIdx.x == 0)
 				slot[(ring + 2) % 3] = resolve(ahead);
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		typename IO::uvec pa{};
 		if constexpr (FEED != Feed::Nco_ConstXY) {
 			if (cur != kEnd && lane < live(cur))
-				pa = CORDIC_LOAD_IN(&(phin + (size_t)cur * kSeedBlock)[lane]);
+				pa = __builtin_nontemporal_load(&(phin + (size_t)cur * kSeedBlock)[lane]);
 		}
 		// (Alternating two register sets, so that the compiler needs no
 		// copies between passes, doubles the loop body: -8 % on the 24-stage

@@ -202,12 +202,12 @@ __global__ __launch_bounds__(1024) void table_lookup(
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
 	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = pv[g];
+		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = table_sample<QUARTER>(tbl, p[v], pw, ow);
-		ov[g] = o;
+		__builtin_nontemporal_store(o, &ov[g]);
 	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
@@ -253,12 +253,12 @@ __global__ __launch_bounds__(1024) void table_lookup_lds(
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
 	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = pv[g];
+		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = sample(p[v]);
-		ov[g] = o;
+		__builtin_nontemporal_store(o, &ov[g]);
 	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
@@ -328,12 +328,12 @@ __global__ __launch_bounds__(1024) void quad_lookup(
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
 	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = pv[g];
+		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
 			o[v] = quad_sample(t[(p[v] >> ish) & imask], p[v], qp);
-		ov[g] = o;
+		__builtin_nontemporal_store(o, &ov[g]);
 	});
 	if (blockIdx.x == 0)
 		for (size_t i = nvec * kVec + threadIdx.x; i < n; i += 1024)
@@ -832,11 +832,12 @@ __global__ __launch_bounds__(256) void stream_probe(const dev::u32x4 *__restrict
 	const size_t g = t * 256 + threadIdx.x;
 	if (g >= nvec)
 		return;
+	// non-temporal, like the kernels whose traffic this stands in for
 	dev::u32x4 v = dev::u32x4{(uint32_t)g, 1, 2, 3};
-	if (R >= 1) v = a[g];
-	if (R >= 2) v += b[g];
-	if (W >= 1) c[g] = v;
-	if (W >= 2) d[g] = v + 1;
+	if (R >= 1) v = __builtin_nontemporal_load(&a[g]);
+	if (R >= 2) v += __builtin_nontemporal_load(&b[g]);
+	if (W >= 1) __builtin_nontemporal_store(v, &c[g]);
+	if (W >= 2) __builtin_nontemporal_store(v + 1, &d[g]);
 }
 
 int launch_stream_probe(int reads, int writes, const void *r0, const void *r1,

@@ -10,6 +10,8 @@
 //   mode 1  persistent 1024-thread blocks pulling 1024-vector tiles from
 //           per-XCD counters in address order: the seeded kernel's own
 //           work distribution (cordic_device.h: rotator_seeded)
+//   mode 2, 3  = mode 0, 1 with non-temporal loads and stores (what the seeded
+//           kernel uses since the end of round 2)
 //
 // R input arrays are read, W output arrays written, 16 bytes per lane.
 #include <hip/hip_runtime.h>
@@ -17,7 +19,18 @@
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int W>
+template <bool NT> __device__ __forceinline__ u32x4 ld(const u32x4 *p)
+{
+	if constexpr (NT) return __builtin_nontemporal_load(p);
+	else return *p;
+}
+template <bool NT> __device__ __forceinline__ void st(u32x4 *p, u32x4 v)
+{
+	if constexpr (NT) __builtin_nontemporal_store(v, p);
+	else *p = v;
+}
+
+template <int R, int W, bool NT>
 __global__ __launch_bounds__(256) void tiles(const u32x4 *__restrict__ a,
 		const u32x4 *__restrict__ b, u32x4 *__restrict__ c,
 		u32x4 *__restrict__ d, size_t nvec, int xcd)
@@ -29,17 +42,17 @@ __global__ __launch_bounds__(256) void tiles(const u32x4 *__restrict__ a,
 	if (g >= nvec)
 		return;
 	u32x4 v = u32x4{(uint32_t)g, 1, 2, 3};
-	if (R >= 1) v = a[g];
-	if (R >= 2) v += b[g];
-	if (W >= 1) c[g] = v;
-	if (W >= 2) d[g] = v + 1;
+	if (R >= 1) v = ld<NT>(&a[g]);
+	if (R >= 2) v += ld<NT>(&b[g]);
+	if (W >= 1) st<NT>(&c[g], v);
+	if (W >= 2) st<NT>(&d[g], v + 1);
 	// read-only sweeps: keep the loads alive (the condition never holds for
 	// the zero / ramp contents the probes run on)
 	if (W == 0 && (v.x ^ v.y ^ v.z ^ v.w) == 0x5bd1e995u && c)
 		c[0] = v;
 }
 
-template <int R, int W>
+template <int R, int W, bool NT>
 __global__ __launch_bounds__(1024) void queued(const u32x4 *__restrict__ a,
 		const u32x4 *__restrict__ b, u32x4 *__restrict__ c,
 		u32x4 *__restrict__ d, size_t nvec, unsigned *ctr)
@@ -76,10 +89,10 @@ __global__ __launch_bounds__(1024) void queued(const u32x4 *__restrict__ a,
 		const size_t g = (size_t)cur * 1024 + threadIdx.x;
 		if (g < nvec) {
 			u32x4 v = u32x4{(uint32_t)g, 1, 2, 3};
-			if (R >= 1) v = a[g];
-			if (R >= 2) v += b[g];
-			if (W >= 1) c[g] = v;
-			if (W >= 2) d[g] = v + 1;
+			if (R >= 1) v = ld<NT>(&a[g]);
+			if (R >= 2) v += ld<NT>(&b[g]);
+			if (W >= 1) st<NT>(&c[g], v);
+			if (W >= 2) st<NT>(&d[g], v + 1);
 		}
 		__syncthreads();
 		cur = nxt;
@@ -104,20 +117,24 @@ static float run(const void *in0, const void *in1, void *out0, void *out1,
 		return -1.f;
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
 		return -1.f;
+	const bool nt = mode >= 2;
+	mode &= 1;
 	if (mode == 1 && (hipMalloc((void **)&ctr, 2048) != hipSuccess
 			|| hipMemset(ctr, 0, 2048) != hipSuccess))
 		return -1.f;
 	const size_t blocks = (nvec + 255) / 256;
 	auto launch = [&]() {
-		if (mode == 0) {
-			hipLaunchKernelGGL((tiles<R, W>), dim3((unsigned)blocks), dim3(256), 0, st,
-				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
-				nvec, (blocks % 8 == 0) ? 1 : 0);
-		} else {
-			hipLaunchKernelGGL((queued<R, W>), dim3(2 * cus), dim3(1024), 0, st,
-				(const u32x4 *)in0, (const u32x4 *)in1, (u32x4 *)out0, (u32x4 *)out1,
-				nvec, ctr);
-		}
+		const u32x4 *a = (const u32x4 *)in0, *b = (const u32x4 *)in1;
+		u32x4 *c = (u32x4 *)out0, *d = (u32x4 *)out1;
+		const int xcd = (blocks % 8 == 0) ? 1 : 0;
+		if (mode == 0 && !nt)
+			hipLaunchKernelGGL((tiles<R, W, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, d, nvec, xcd);
+		else if (mode == 0)
+			hipLaunchKernelGGL((tiles<R, W, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, d, nvec, xcd);
+		else if (!nt)
+			hipLaunchKernelGGL((queued<R, W, false>), dim3(2 * cus), dim3(1024), 0, st, a, b, c, d, nvec, ctr);
+		else
+			hipLaunchKernelGGL((queued<R, W, true>), dim3(2 * cus), dim3(1024), 0, st, a, b, c, d, nvec, ctr);
 	};
 	launch();
 	float ms = -1.f;
@@ -147,7 +164,7 @@ extern "C" float hbm_probe(const void *in0, const void *in1, void *out0, void *o
 {
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const size_t nvec = nwords / 4;
-	if (reps < 1 || nvec == 0 || (mode != 0 && mode != 1))
+	if (reps < 1 || nvec == 0 || mode < 0 || mode > 3)
 		return -1.f;
 	if (R == 1 && W == 2) return run<1, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
 	if (R == 2 && W == 2) return run<2, 2>(in0, in1, out0, out1, nvec, mode, reps, st);
