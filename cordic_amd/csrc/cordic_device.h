@@ -559,9 +559,11 @@ struct Io16 {
 
 // Output stores.  Outputs are written once and never re-read by the engine.
 // Measured on MI355X: the non-temporal form is as good or better for the
-// VALU-bound kernels (full recurrence), while the table-seeded kernel, which
-// runs close to HBM speed, is faster with plain stores (cfg2: 439 vs 406
-// Gsample/s) -- so the choice is per kernel.
+// VALU-bound kernels (full recurrence).  The table-seeded kernel, which runs
+// close to HBM speed, was faster with plain stores while its blocks walked
+// contiguous chunks (round 1: 439 vs 406 Gsample/s on cfg2) and is faster with
+// non-temporal loads and stores now that they pull tiles in address order
+// (profiles/r02/ab_nontemporal.txt) -- so the choice is per kernel and path.
 #if defined(CORDIC_FORCE_NT_STORES)
 #define CORDIC_STORE_OUT(NT, ptr, val) __builtin_nontemporal_store((val), (ptr))
 #elif defined(CORDIC_FORCE_PLAIN_STORES)
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 // table lookup (see cordic_plan.cpp for the argument and the table layout).
 // Per block: the bucket table is copied to LDS and the (x_M, y_M) seeds of
 // every (octant, leaf) are computed with the exact recurrence -- nothing is
-// cached between launches.  Per sample: one bucket read, two compares, one
+// cached between launches.  Per sample: one bucket read, one compare, one
 // seed read, then stages M .. NLIVE-1 as in rotator_unrolled.
 struct SeedArgs {
 	const uint32_t *table;	// device copy of build_seed_table()'s words
