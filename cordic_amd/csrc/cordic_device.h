@@ -548,13 +548,15 @@ struct Io16 {
 	}
 };
 
-// Input loads: streamed once, never re-read (-DCORDIC_NT_LOADS: non-temporal).
-// Macros, not function templates: template deduction would strip the element
-// alignment off the pointer's vector typedef (Io32 / Io16).
-#ifdef CORDIC_NT_LOADS
-#define CORDIC_LOAD_IN(ptr) __builtin_nontemporal_load(ptr)
-#else
+// Input loads: streamed once, never re-read, hence non-temporal (same-box A/B
+// at the end of round 2: +2 % on the 20-byte-per-sample p2r, +0.4 % on r2p,
+// nothing on the constant-vector full recurrence; -DCORDIC_PLAIN_LOADS turns
+// it off).  Macros, not function templates: template deduction would strip
+// the element alignment off the pointer's vector typedef (Io32 / Io16).
+#ifdef CORDIC_PLAIN_LOADS
 #define CORDIC_LOAD_IN(ptr) (*(ptr))
+#else
+#define CORDIC_LOAD_IN(ptr) __builtin_nontemporal_load(ptr)
 #endif
 
 // Output stores.  Outputs are written once and never re-read by the engine.
@@ -672,10 +674,10 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 	typename IO::ivec nx{}, ny{};
 	if (g < nvec) {
 		if constexpr (FEED != Feed::Nco_ConstXY)
-			nph = phin[g];
+			nph = CORDIC_LOAD_IN(&phin[g]);
 		if constexpr (!kConstXY) {
-			nx = xin[g];
-			ny = yin[g];
+			nx = CORDIC_LOAD_IN(&xin[g]);
+			ny = CORDIC_LOAD_IN(&yin[g]);
 		}
 	}
 	for (; g < nvec; g += stride) {
@@ -684,10 +686,10 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		const size_t gn = g + stride;
 		if (gn < nvec) {
 			if constexpr (FEED != Feed::Nco_ConstXY)
-				nph = phin[gn];
+				nph = CORDIC_LOAD_IN(&phin[gn]);
 			if constexpr (!kConstXY) {
-				nx = xin[gn];
-				ny = yin[gn];
+				nx = CORDIC_LOAD_IN(&xin[gn]);
+				ny = CORDIC_LOAD_IN(&yin[gn]);
 			}
 		}
 
@@ -1286,15 +1288,15 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 	// software prefetch (see rotator_unrolled)
 	typename IO::ivec nx{}, ny{};
 	if (g < nvec) {
-		nx = xin[g];
-		ny = yin[g];
+		nx = CORDIC_LOAD_IN(&xin[g]);
+		ny = CORDIC_LOAD_IN(&yin[g]);
 	}
 	for (; g < nvec; g += stride) {
 		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
-			nx = xin[gn];
-			ny = yin[gn];
+			nx = CORDIC_LOAD_IN(&xin[gn]);
+			ny = CORDIC_LOAD_IN(&yin[gn]);
 		}
 		int64_t x[kVec], y[kVec], p[kVec];
 #pragma unroll
@@ -1441,15 +1443,15 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	typename IO::ivec nx{}, ny{};		// software prefetch
 	if (g < nvec) {
-		nx = xin[g];
-		ny = yin[g];
+		nx = CORDIC_LOAD_IN(&xin[g]);
+		ny = CORDIC_LOAD_IN(&yin[g]);
 	}
 	for (; g < nvec; g += stride) {
 		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
-			nx = xin[gn];
-			ny = yin[gn];
+			nx = CORDIC_LOAD_IN(&xin[gn]);
+			ny = CORDIC_LOAD_IN(&yin[gn]);
 		}
 		int64_t x[kVec], y[kVec], p[kVec];
 #pragma unroll
@@ -1611,15 +1613,15 @@ __global__ __launch_bounds__(kBlock) void topolar_ljw(CoreParams kp,
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	typename IO::ivec nx{}, ny{};		// software prefetch
 	if (g < nvec) {
-		nx = xin[g];
-		ny = yin[g];
+		nx = CORDIC_LOAD_IN(&xin[g]);
+		ny = CORDIC_LOAD_IN(&yin[g]);
 	}
 	for (; g < nvec; g += stride) {
 		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
-			nx = xin[gn];
-			ny = yin[gn];
+			nx = CORDIC_LOAD_IN(&xin[gn]);
+			ny = CORDIC_LOAD_IN(&yin[gn]);
 		}
 		int64_t x[kVec], y[kVec], p[kVec];
 #pragma unroll
