@@ -176,13 +176,13 @@ struct PlaceStats {
 // Average milliseconds of the `reads`R `writes`W probe over the given arrays
 // on `st` (one warm-up launch, two timed), or a negative value.
 float probe_ms(hipStream_t st, int reads, int writes, const void *r0, const void *r1,
-		void *w0, void *w1, uint64_t words)
+		void *w0, void *w1, uint64_t words, uint32_t *queue)
 {
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	float ms = -1.f;
 	auto go = [&]() {
-		return launch_stream_probe(reads, writes, r0, r1, w0, w1, (size_t)words, st)
-			== CORDIC_OK;
+		return launch_stream_probe(reads, writes, r0, r1, w0, w1, (size_t)words, st,
+			queue) == CORDIC_OK;
 	};
 	if (ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1)) && go()
 	    && ok(hipEventRecord(e0, st)) && go() && go()
@@ -222,11 +222,24 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		pool.push_back(p);
 	}
 	PlaceStats ps;
+	// tile counters for the probes (they run in the seeded kernel's work
+	// distribution); without them the probes fall back to one-shot tiles
+	uint32_t *queue = nullptr;
+	if (tune && (!ok(hipMalloc((void **)&queue, CORDIC_QUEUE_BYTES))
+			|| !ok(hipMemsetAsync(queue, 0, CORDIC_QUEUE_BYTES, st)))) {
+		(void)hipGetLastError();
+		if (queue) (void)hipFree(queue);
+		queue = nullptr;
+	}
 	auto take = [&](void **slot, size_t k) {
 		*slot = pool[k];
 		pool.erase(pool.begin() + (long)k);
 	};
 	auto finish = [&](bool in_order) {
+		if (queue) {
+			(void)hipStreamSynchronize(st);
+			(void)hipFree(queue);
+		}
 		if (in_order) {
 			for (int i = 0; i < nwrite; i++) if (!writes[i]) take(&writes[i], 0);
 			for (int i = 0; i < nread; i++) if (!reads[i]) take(&reads[i], 0);
@@ -245,7 +258,7 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 	size_t bi = 0, bj = 1;
 	if (nwrite == 2) {
 		auto try_pair = [&](size_t i, size_t j) {
-			const float ms = probe_ms(st, 0, 2, nullptr, nullptr, pool[i], pool[j], words);
+			const float ms = probe_ms(st, 0, 2, nullptr, nullptr, pool[i], pool[j], words, queue);
 			if (ms < 0.f) { failed = true; return; }
 			ps.probes++;
 			if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }
@@ -294,7 +307,7 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 						&& !failed; j++) {
 					if (j == w) continue;
 					const float ms = probe_ms(st, nread, 1, pool[i],
-						nread == 2 ? pool[j] : nullptr, pool[w], nullptr, words);
+						nread == 2 ? pool[j] : nullptr, pool[w], nullptr, words, queue);
 					if (ms < 0.f) { failed = true; break; }
 					ps.probes++;
 					if (best < 0.f || ms < best) { best = ms; bw = w; bi = i; bj = j; }
@@ -315,7 +328,7 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 				pool.erase(pool.begin() + (long)k);
 	} else if (nread == 1) {
 		for (size_t i = 0; i < pool.size() && !failed; i++) {
-			const float ms = probe_ms(st, 1, 2, pool[i], nullptr, writes[0], writes[1], words);
+			const float ms = probe_ms(st, 1, 2, pool[i], nullptr, writes[0], writes[1], words, queue);
 			if (ms < 0.f) { failed = true; break; }
 			ps.probes++;
 			if (best < 0.f || ms < best) { best = ms; bi = i; }
@@ -326,7 +339,7 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 	} else {
 		for (size_t i = 0; i < pool.size() && !failed; i++)
 			for (size_t j = i + 1; j < pool.size() && !failed; j++) {
-				const float ms = probe_ms(st, 2, 2, pool[i], pool[j], writes[0], writes[1], words);
+				const float ms = probe_ms(st, 2, 2, pool[i], pool[j], writes[0], writes[1], words, queue);
 				if (ms < 0.f) { failed = true; break; }
 				ps.probes++;
 				if (best < 0.f || ms < best) { best = ms; bi = i; bj = j; }

@@ -160,9 +160,12 @@ int	launch_quad_lookup(const cordic_quad_config &q, const int32_t *d_tables,
 int	launch_digest_u32(const uint32_t *w, size_t n, uint64_t index0,
 		uint64_t *digest, void *stream);
 // arithmetic-free `reads`R `writes`W stream over nwords 32-bit words per array
-// (0R2W, 1R2W, 2R2W, 1R1W, 2R1W); the written arrays are overwritten
+// (0R2W, 1R2W, 2R2W, 1R1W, 2R1W); the written arrays are overwritten.  With
+// `queue` (CORDIC_QUEUE_BYTES of zeroed device memory) the stream runs in the
+// seeded kernel's work distribution, else as one-shot 4 KiB tiles.
 int	launch_stream_probe(int reads, int writes, const void *r0, const void *r1,
-		void *w0, void *w1, size_t nwords, void *stream);
+		void *w0, void *w1, size_t nwords, void *stream,
+		uint32_t *queue = nullptr);
 
 } // namespace cordic_amd
 #endif

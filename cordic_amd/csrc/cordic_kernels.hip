@@ -840,13 +840,52 @@ __global__ __launch_bounds__(256) void stream_probe(const dev::u32x4 *__restrict
 	if (W >= 2) __builtin_nontemporal_store(v + 1, &d[g]);
 }
 
+// The same traffic in the seeded kernel's own work distribution: persistent
+// 1024-thread blocks, one per CU, pulling 1024-vector tiles from the per-XCD
+// counters in address order.  Which arrays suit a stream best depends on the
+// distribution too (one-shot tiles and the queue disagree on some
+// combinations), so placement probes with the one the job will use.
+template <int R, int W>
+__global__ __launch_bounds__(1024) void stream_probe_queued(
+		const dev::u32x4 *__restrict__ a, const dev::u32x4 *__restrict__ b,
+		dev::u32x4 *__restrict__ c, dev::u32x4 *__restrict__ d, size_t nvec,
+		uint32_t *queue)
+{
+	__shared__ uint32_t slot[3];
+	sweep_tiles(queue, slot, nvec, [&](size_t g) {
+		dev::u32x4 v = dev::u32x4{(uint32_t)g, 1, 2, 3};
+		if (R >= 1) v = __builtin_nontemporal_load(&a[g]);
+		if (R >= 2) v += __builtin_nontemporal_load(&b[g]);
+		if (W >= 1) __builtin_nontemporal_store(v, &c[g]);
+		if (W >= 2) __builtin_nontemporal_store(v + 1, &d[g]);
+	});
+}
+
 int launch_stream_probe(int reads, int writes, const void *r0, const void *r1,
-		void *w0, void *w1, size_t nwords, void *stream)
+		void *w0, void *w1, size_t nwords, void *stream, uint32_t *queue)
 {
 	clear_stale_error();
 	const size_t nvec = nwords / 4;
 	if (nvec == 0)
 		return CORDIC_OK;
+	if (queue) {
+		const int grid = grid_for((size_t)1024 * kVec, nwords, 1);
+		if (grid < 0)
+			return CORDIC_ERR_DEVICE;
+		auto goq = [&](auto kern) {
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0,
+				static_cast<hipStream_t>(stream),
+				static_cast<const dev::u32x4 *>(r0), static_cast<const dev::u32x4 *>(r1),
+				static_cast<dev::u32x4 *>(w0), static_cast<dev::u32x4 *>(w1), nvec, queue);
+		};
+		if (reads == 0 && writes == 2) goq(stream_probe_queued<0, 2>);
+		else if (reads == 1 && writes == 2) goq(stream_probe_queued<1, 2>);
+		else if (reads == 2 && writes == 2) goq(stream_probe_queued<2, 2>);
+		else if (reads == 1 && writes == 1) goq(stream_probe_queued<1, 1>);
+		else if (reads == 2 && writes == 1) goq(stream_probe_queued<2, 1>);
+		else return CORDIC_ERR_ARGS;
+		return check_launch();
+	}
 	const size_t blocks = (nvec + 255) / 256;
 	if (blocks > 0x7fffffffu)
 		return CORDIC_ERR_ARGS;
