@@ -207,6 +207,25 @@ ABI = {
                                       C.c_int, C.c_void_p]),
     "cordic_digest_u32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64,
                                     C.c_void_p, C.c_void_p]),
+    "cordic_quality_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
+    "cordic_quality_destroy": (None, [C.c_void_p]),
+    "cordic_quality_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_quality_p2r": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "cordic_quality_nco": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32,
+                                     C.c_uint32, C.c_uint64, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "cordic_quality_r2p": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "cordic_quality_p2r_result": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_quality_r2p_result": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_fill_circle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
 }
 
 
@@ -783,6 +802,105 @@ class Seq:
             self.close()
         except Exception:
             pass
+
+
+class _CP2RQuality(C.Structure):
+    _fields_ = ([("n", C.c_uint64)]
+                + [(k, C.c_double) for k in (
+                    "avg_err", "max_err", "mag", "input_mag", "alpha",
+                    "cnr_db", "expected_err", "avg_limit", "max_limit")]
+                + [("max_err_index", C.c_uint64)]
+                + [(k, C.c_int32) for k in (
+                    "pass_avg", "pass_max", "pass_alpha", "pass")]
+                + [(k, C.c_double) for k in (
+                    "sum_err2", "sum_xy", "sum_sq", "sum_d", "sum_in2")])
+
+
+class _CR2PQuality(C.Structure):
+    _fields_ = ([("n", C.c_uint64)]
+                + [(k, C.c_double) for k in (
+                    "max_phase_err", "max_mag_err", "avg_phase_err",
+                    "avg_mag_err", "mean_phase_err",
+                    "expected_avg_phase_err", "phase_limit", "mag_limit")]
+                + [("max_phase_err_index", C.c_uint64),
+                   ("max_mag_err_index", C.c_uint64)]
+                + [(k, C.c_int32) for k in (
+                    "pass_phase", "pass_mag", "pass")])
+
+
+def _as_dict(st):
+    return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+class Quality:
+    """cordic_quality: the reference benches' statistics and thresholds
+    (bench/cpp/cordic_tb.cpp:223-337, topolar_tb.cpp:222-315), reduced on the
+    device; calls accumulate until reset()."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _check(lib().cordic_quality_create(cfg.ref, C.byref(self._h)),
+               "cordic_quality_create")
+
+    def reset(self, stream=None):
+        _check(lib().cordic_quality_reset(self._h, _stream(stream)),
+               "cordic_quality_reset")
+
+    def p2r(self, x, y, phase, ox, oy, n=None, stream=None):
+        """x, y: ints (the constant vector) or int32 tensors"""
+        n = phase.numel() if n is None else n
+        if isinstance(x, int):
+            a = (None, None, x, y)
+        else:
+            a = (_ptr(x), _ptr(y), 0, 0)
+        _check(lib().cordic_quality_p2r(self._h, n, a[0], a[1], a[2], a[3],
+                                        _ptr(phase), _ptr(ox), _ptr(oy),
+                                        _stream(stream)),
+               "cordic_quality_p2r")
+
+    def nco(self, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
+        _check(lib().cordic_quality_nco(self._h, n, phase0 & 0xffffffff,
+                                        fcw & 0xffffffff, index0, x0, y0,
+                                        _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_quality_nco")
+
+    def r2p(self, x, y, imag, omag, ophase, n=None, stream=None):
+        n = x.numel() if n is None else n
+        _check(lib().cordic_quality_r2p(self._h, n, _ptr(x), _ptr(y), imag,
+                                        _ptr(omag), _ptr(ophase),
+                                        _stream(stream)),
+               "cordic_quality_r2p")
+
+    def p2r_result(self):
+        r = _CP2RQuality()
+        _check(lib().cordic_quality_p2r_result(self._h, C.byref(r)),
+               "cordic_quality_p2r_result")
+        return _as_dict(r)
+
+    def r2p_result(self):
+        r = _CR2PQuality()
+        _check(lib().cordic_quality_r2p_result(self._h, C.byref(r)),
+               "cordic_quality_r2p_result")
+        return _as_dict(r)
+
+    def close(self):
+        if self._h:
+            lib().cordic_quality_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fill_circle(x, y, index0, lgnsamples, iw, pw, n=None, stream=None):
+    n = x.numel() if n is None else n
+    _check(lib().cordic_fill_circle(_ptr(x), _ptr(y), n, index0, lgnsamples,
+                                    iw, pw, _stream(stream)),
+           "cordic_fill_circle")
 
 
 def seed_table(cfg):

@@ -598,6 +598,89 @@ int	cordic_group_read(cordic_group *grp, int local_shard, int array,
 int	cordic_group_write(cordic_group *grp, int local_shard, int array,
 		uint64_t offset, uint64_t count, const void *src);
 
+/* --------------------------------- the reference benches' pass criteria
+ *
+ * bench/cpp/cordic_tb.cpp:223-337 and bench/cpp/topolar_tb.cpp:222-315 are the
+ * reference's whole acceptance test: every output is compared with a double
+ * precision sin/cos (atan2) of its input, reduced to a few sums and maxima,
+ * and held against thresholds built from the generated header's
+ * QUANTIZATION_VARIANCE / PHASE_VARIANCE_RAD / GAIN.  A cordic_quality does
+ * that reduction ON THE DEVICE, over arrays that are already there, so the
+ * criteria can be evaluated over all 2^32 phases of a 32-bit core in about a
+ * second (the Verilated bench keeps 2^PW ints on the host; at PW = 32 its
+ * `const int NSAMPLES = 1ul << PW` is 0).  Calls ACCUMULATE -- a sweep may be
+ * fed in pieces -- until cordic_quality_reset; the *_result calls synchronise
+ * the device, add the per-block partial sums up on the host (fixed grid, no
+ * atomics: reproducible bit for bit) and apply the reference's thresholds.
+ * A handle belongs to the device that was current at creation and to one
+ * caller at a time; it accumulates either p2r or r2p statistics.
+ */
+typedef struct cordic_quality cordic_quality;
+
+typedef struct cordic_p2r_quality {	/* cordic_tb.cpp:285-337            */
+	uint64_t n;			/* samples accumulated               */
+	double	avg_err;		/* "AVG Err" : sqrt(sum err^2 / n)   */
+	double	max_err;		/* "MAX Err"                         */
+	double	mag;			/* "Mag"     : RMS output magnitude  */
+	double	input_mag;		/* RMS input magnitude (`scale`)     */
+	double	alpha;			/* "(alpha)" : sumxy / sumsq         */
+	double	cnr_db;			/* "CNR"                             */
+	double	expected_err;		/* sqrt(QUANTIZATION_VARIANCE +
+					   PHASE_VARIANCE_RAD (scale GAIN)^2) */
+	double	avg_limit;		/* 1.5 expected_err                  */
+	double	max_limit;		/* 5.2 expected_err                  */
+	uint64_t max_err_index;		/* sample (in feeding order) of max  */
+	int32_t	pass_avg, pass_max, pass_alpha, pass;
+	double	sum_err2, sum_xy, sum_sq, sum_d, sum_in2;	/* raw sums  */
+} cordic_p2r_quality;
+
+typedef struct cordic_r2p_quality {	/* topolar_tb.cpp:222-256,303-330   */
+	uint64_t n;
+	double	max_phase_err;		/* "Max phase error", phase units    */
+	double	max_mag_err;		/* "Max magnitude error"             */
+	double	avg_phase_err;		/* "Avg phase err"                   */
+	double	avg_mag_err;		/* RMS magnitude error (not in the
+					   reference report)                 */
+	double	mean_phase_err;		/* bias of the phase (likewise)      */
+	double	expected_avg_phase_err;	/* sqrt(PHASE_VARIANCE_RAD) RAD_TO_PHASE */
+	double	phase_limit;		/* 3.4 max(1, that)                  */
+	double	mag_limit;		/* 2 sqrt(QUANTIZATION_VARIANCE)     */
+	uint64_t max_phase_err_index, max_mag_err_index;
+	int32_t	pass_phase, pass_mag, pass;
+} cordic_r2p_quality;
+
+int	cordic_quality_create(const cordic_config *cfg, cordic_quality **q);
+void	cordic_quality_destroy(cordic_quality *q);
+int	cordic_quality_reset(cordic_quality *q, void *stream);
+/* p2r / sp2r cores.  d_xval / d_yval NULL: the constant vector (xval, yval),
+ * as the bench holds it (cordic_tb.cpp:68-69).  Inputs are taken modulo their
+ * port width exactly as the core takes them. */
+int	cordic_quality_p2r(cordic_quality *q, size_t n, const int32_t *d_xval,
+		const int32_t *d_yval, int32_t xval, int32_t yval,
+		const uint32_t *d_phase, const int32_t *d_oxval,
+		const int32_t *d_oyval, void *stream);
+/* the same for outputs of cordic_nco: the phases are the closed form */
+int	cordic_quality_nco(cordic_quality *q, size_t n, uint32_t phase0,
+		uint32_t fcw, uint64_t index0, int32_t xval, int32_t yval,
+		const int32_t *d_oxval, const int32_t *d_oyval, void *stream);
+/* r2p / sr2p cores.  imag >= 0: the magnitude every sample is expected to
+ * have before scaling, as the bench uses its circle's nominal radius
+ * (topolar_tb.cpp:238-246: imag[i] = (int)mg); imag < 0: each sample's own
+ * sqrt(x^2 + y^2). */
+int	cordic_quality_r2p(cordic_quality *q, size_t n, const int32_t *d_xval,
+		const int32_t *d_yval, int32_t imag, const int32_t *d_omag,
+		const uint32_t *d_ophase, void *stream);
+int	cordic_quality_p2r_result(cordic_quality *q, cordic_p2r_quality *out);
+int	cordic_quality_r2p_result(cordic_quality *q, cordic_r2p_quality *out);
+/* The r2p bench's input (topolar_tb.cpp:127-141): samples index0 .. index0+n-1
+ * of 2^lgnsamples points on TWO turns of a circle of radius 2^(IW-1)-1,
+ * components truncated toward zero by (int); the reference uses lgnsamples =
+ * PW.  cos / sin are the device's fp64 sincospi, which may differ from the
+ * host libm in the last place (the statistics refer to the integers actually
+ * fed, topolar_tb.cpp:142, so they are self-consistent either way). */
+int	cordic_fill_circle(int32_t *d_x, int32_t *d_y, size_t n, uint64_t index0,
+		int lgnsamples, int iw, int pw, void *stream);
+
 /* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,
