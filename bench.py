@@ -38,7 +38,63 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+# VALU side of the roofline ("report roofline.achieved (HBM) AND
+# valu_fraction").  1024 SIMDs x 64 lanes; in the mixed integer stream of a
+# micro-rotation a SIMD with 8 resident waves issues one VALU wave-instruction
+# every 3.65 cycles whatever the opcode (tools/stage_microbench.hip,
+# profiles/r02/stage_microbench.txt), at the shader clock the kernel actually
+# held (the hot kernels sit at the 1400 W socket limit below 2.4 GHz).
+N_SIMD, WAVE_LANES = 1024, 64
+VALU_ISSUE_CYCLES = 3.65
+SCLK_MAX_GHZ = 2.4
+
+
+def valu_block(samples_per_s, instr_per_sample, sclk_ghz, instr_source,
+               sclk_source):
+    """valu_fraction = lane-instructions/s the kernel retired / what the
+    SIMDs can issue for this instruction mix at the clock it ran at."""
+    if not instr_per_sample:
+        return None
+    clk = sclk_ghz or SCLK_MAX_GHZ
+    peak = N_SIMD * WAVE_LANES * clk * 1e9 / VALU_ISSUE_CYCLES
+    ach = samples_per_s * instr_per_sample
+    return {"instr_per_sample": instr_per_sample,
+            "instr_source": instr_source,
+            "sclk_ghz": clk, "sclk_source": sclk_source if sclk_ghz else
+            "nominal maximum (no hwmon samples)",
+            "issue_cycles_per_wave_instr": VALU_ISSUE_CYCLES,
+            "achieved_Tinstr_per_s": ach / 1e12,
+            "peak_Tinstr_per_s": peak / 1e12,
+            "frac": ach / peak,
+            "frac_at_2.4GHz": ach / (peak * SCLK_MAX_GHZ / clk)}
+
+
+def add_valu(roof, samples_per_s, pm, power, prof):
+    """roofline.valu / valu_fraction / bound from this run's SQ_INSTS_VALU
+    pass (or, without one, the committed profile) and this run's clock."""
+    instr = src = None
+    if pm and pm.get("valu_instr_per_sample"):
+        instr, src = pm["valu_instr_per_sample"], (
+            "SQ_INSTS_VALU x 64 / samples, rocprofv3 --pmc pass of this run")
+    elif prof and prof.get("valu_instr_per_sample"):
+        instr, src = prof["valu_instr_per_sample"], (
+            "committed profile (%s), not re-measured" % prof.get("source"))
+    sclk = ssrc = None
+    for key in ("sustained", "timed_region"):
+        if power and power.get(key) and power[key].get("sclk_mhz_median"):
+            sclk = power[key]["sclk_mhz_median"] / 1e3
+            ssrc = "hwmon freq1_input median, %s window of this run" % key
+            break
+    vb = valu_block(samples_per_s, instr, sclk, src, ssrc)
+    if vb:
+        roof["valu"] = vb
+        roof["valu_fraction"] = vb["frac"]
+        # whichever ceiling the kernel sits nearer to
+        roof["bound"] = "hbm" if roof["frac"] >= vb["frac"] else "valu"
+        roof["bound_note"] = ("hbm frac %.3f vs valu_fraction %.3f; the VALU "
+                              "ceiling is at the clock the 1400 W socket limit "
+                              "allowed" % (roof["frac"], vb["frac"]))
+    return roof
 
 # name -> (gencordic-style parameters, bytes/sample, VALU ops/sample counted
 # in the ISA of the kernel that runs it, description)
@@ -157,81 +213,60 @@ def _cpu_model():
     return "unknown"
 
 
-def other_paths(ca, dev, log2n=29, steps=8):
-    """Rates of the other entry points of the engine on this GPU (single-GPU
-    default run only; informational, not `value`): 2^log2n samples, HIP events
-    over `steps` launches after four warm-up launches, results spot-checked against the
-    oracle.  Keys are bench.py workload names."""
-    import oracle_lib as O
-    n = 1 << log2n
+# BASELINE.json's other GPU configurations at THEIR sizes (configs[2..4]) plus
+# the per-sample-vector rotator: (workload, log2 samples per launch)
+OTHER_PATHS = (("cfg3", 30), ("cfg4", 30), ("cfg5", 32), ("p2rxy", 30))
+
+
+def other_paths(args, steps=24, warmup=4):
+    """Driver-timed lines of the other configurations (single-GPU default run
+    only; informational, never `value`): each one is this script run on that
+    workload -- same timing discipline, HIP events around every launch, oracle
+    spot checks and digest, hwmon clock, one SQ_INSTS_VALU pass -- as a child
+    process once the main measurement is finished, condensed to its rate,
+    roofline (HBM fraction AND valu_fraction, bound) and checks."""
+    import subprocess
     res = {}
-
-    def timed(fn):
-        for _ in range(4):      # the GPU idled during cpu_baseline: re-clock
-            fn()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / steps
-
-    idx = torch.arange(0, n, 65521, device=dev)
-
-    def i32(k=1):
-        return [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(k)]
-
-    # cfg3: r2p 20 stages on I/Q ramps
-    cfg = ca.Config.from_cli(1, 24, 24, 2, -1, 20)
-    xin, yin, a, b = i32(4)
-    ca.fill_iq_ramp(xin, yin, 0, 0x9E3779B1, 0x85EBCA77, 24)
-    ms = timed(lambda: ca.r2p(cfg, xin, yin, a, b))
-    rm, rp = O.topolar(O.config_cli(1, 24, 24, 2, -1, 20),
-                       xin[idx].cpu().numpy(), yin[idx].cpu().numpy())
-    ok = bool(np.array_equal(a[idx].cpu().numpy(), rm) and np.array_equal(
-        b[idx].cpu().numpy().view(np.uint32), rp))
-    res["cfg3"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 16,
-                   "bit_exact_vs_oracle": ok}
-    # p2rxy: per-sample x, y and phase
-    cfg = ca.Config.from_cli(0, 32, 32, 2, 32, 16)
-    ocfg = O.config_cli(0, 32, 32, 2, 32, 16)
-    ph = i32()[0]
-    ca.fill_phase_ramp(ph, 0, 2)
-    ca.fill_iq_ramp(xin, yin, 0, 0x9E3779B1, 0x85EBCA77, 32)
-    ms = timed(lambda: ca.p2r(cfg, xin, yin, ph, a, b))
-    rx, ry = O.rotate(ocfg, xin[idx].cpu().numpy(), yin[idx].cpu().numpy(),
-                      ph[idx].cpu().numpy().view(np.uint32))
-    ok = bool(np.array_equal(a[idx].cpu().numpy(), rx)
-              and np.array_equal(b[idx].cpu().numpy(), ry))
-    res["p2rxy"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 20,
-                    "bit_exact_vs_oracle": ok}
-    # cfg5: fused NCO, store only
-    plan = ca.Plan(cfg)
-    ms = timed(lambda: plan.nco(n, 0, 0x01234567, 0, 2**31 - 1, 0, a, b))
-    pn = ((idx.cpu().numpy().astype(np.uint64) * np.uint64(0x01234567))
-          & np.uint64(0xffffffff)).astype(np.uint32)
-    rx, ry = O.rotate(ocfg, 2**31 - 1, 0, pn)
-    ok = bool(np.array_equal(a[idx].cpu().numpy(), rx)
-              and np.array_equal(b[idx].cpu().numpy(), ry))
-    res["cfg5"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 8,
-                   "bit_exact_vs_oracle": ok}
-    # quadtbl: the checked-in quadratic-interpolation core
-    quad = ca.Quad(-1, 13, 2, 18)
-    ms = timed(lambda: quad.lookup(ph, a))
-    oq = O.quad_cli(-1, 13, 2, 18)
-    ok = bool(np.array_equal(a[idx].cpu().numpy(), O.quad_lookup(
-        oq, O.quad_tables(oq), ph[idx].cpu().numpy().view(np.uint32))))
-    res["quadtbl"] = {"Msamples_per_s": n / ms / 1e3, "bytes_per_sample": 8,
-                      "bit_exact_vs_oracle": ok}
-    for key, e in res.items():
-        gbs = e["Msamples_per_s"] * 1e6 * e["bytes_per_sample"] / 1e9
-        e["roofline"] = {"bound": "hbm", "achieved": gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS}
-        e["from_profile"] = from_profile(key)
+    for wl, log2n in OTHER_PATHS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl,
+               "--steps", str(steps), "--warmup", str(warmup),
+               "--log2-samples", str(log2n), "--input", args.input,
+               "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
+               "--pmc-counters", "SQ_INSTS_VALU"]
+        if args.no_pmc:
+            cmd.append("--no-pmc")
+        if args.no_power:
+            cmd.append("--no-power")
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1])
+        except Exception as e:                # never lose the main line
+            res[wl] = {"error": repr(e)}
+            continue
+        roof = d["roofline"]
+        e = {"Msamples_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+             "steps": d["steps"], "samples_per_launch": 1 << log2n,
+             "bytes_per_sample": roof["bytes_per_sample"],
+             "kernel": d["config"]["kernel"],
+             "bit_exact_vs_oracle": d["bit_exact_vs_oracle"],
+             "digest": d["digest"],
+             "roofline": {k: roof[k] for k in (
+                 "bound", "achieved", "peak", "unit", "frac", "valu_fraction",
+                 "valu", "kernel_ms_avg", "kernel_ms_min") if k in roof},
+             "wall_s": time.perf_counter() - t0}
+        pw = (roof.get("power") or {}).get("sustained")
+        if pw:
+            e["sustained"] = {k: pw[k] for k in (
+                "socket_w_median", "sclk_mhz_median") if k in pw}
+        if "full_recurrence_kernel" in d:
+            f = d["full_recurrence_kernel"]
+            e["full_recurrence_kernel"] = {
+                "Msamples_per_s": f["value_per_gpu"], "hbm_frac": f["hbm_frac"],
+                "outputs_identical_to_seeded_kernel":
+                    f["outputs_identical_to_seeded_kernel"]}
+        res[wl] = e
     return res
 
 
@@ -279,10 +314,10 @@ KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
 
 
 def measure_pmc(args):
-    """`--pmc`: HBM bytes per launch of the workload's kernel, MEASURED now:
-    two separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- they do not fit
-    one pass, and PMC is never combined with tracing) over a 3-step run of
-    this same script, corrected as MI355X_MICROARCH.md prescribes for gfx950
+    """HBM bytes per launch and VALU instructions per sample of the workload's
+    kernel, MEASURED now: separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE,
+    SQ_INSTS_VALU -- the first two do not fit one pass, and PMC is never
+    combined with tracing) over a 3-step run of this same script, corrected as MI355X_MICROARCH.md prescribes for gfx950
     (FETCH_SIZE counts half of a wide coalesced read; both are in KiB)."""
     import csv
     import glob
@@ -304,7 +339,8 @@ def measure_pmc(args):
             base.append(flag)
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp")
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    counters = [c for c in args.pmc_counters.split(",") if c]
+    for ctr in counters:
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format",
                                 "csv", "-d", td, "--"] + base, cwd="/tmp",
@@ -321,12 +357,20 @@ def measure_pmc(args):
                 return {"error": "no %s rows for %s (rocprofv3 rc %d)"
                         % (ctr, kern, r.returncode)}
             vals[ctr] = (sum(rows) / len(rows), len(rows))
-    fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
-    return {"kernel": kern, "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+    out = {"kernel": kern, "passes": counters}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+        out.update({
+            "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
             "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
             "launches_averaged": vals["FETCH_SIZE"][1],
             "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM), "
-                          "WRITE_SIZE as reported, KiB -> B"}
+                          "WRITE_SIZE as reported, KiB -> B"})
+    if "SQ_INSTS_VALU" in vals:
+        out["SQ_INSTS_VALU_per_launch"] = vals["SQ_INSTS_VALU"][0]
+        out["valu_instr_per_sample"] = (vals["SQ_INSTS_VALU"][0] * 64.0
+                                        / float(1 << args.log2_samples))
+    return out
 
 
 _probe_lib = None
@@ -435,6 +479,42 @@ class PowerSampler(threading.Thread):
             return None
 
 
+def start_power(device, enabled):
+    if not enabled:
+        return None
+    sp = PowerSampler(device)
+    if sp.dir is None:
+        return None
+    sp.start()
+    return sp
+
+
+def finish_power(sampler, step, sync, t0, elapsed, steps, samples_per_step):
+    """The timed region is short (the governor is still settling): keep the
+    same kernel going for two more seconds and sample that as well."""
+    if sampler is None:
+        return None
+    t1 = time.perf_counter()
+    ms_step = elapsed / steps
+    more = max(1, min(4000, int(2.0 / max(ms_step, 1e-6))))
+    for _ in range(more):
+        step()
+    sync()
+    t2 = time.perf_counter()
+    sampler.stop()
+    power = {"source": "amdgpu hwmon of the device (power1_input, "
+                       "freq1_input), host thread, every 2 ms",
+             "limit_w": sampler.limit_w(),
+             "timed_region": sampler.window(t0, t1),
+             "sustained": sampler.window(t1 + (t2 - t1) / 2, t2)}
+    if power["sustained"]:
+        # for information only: `value` is the K timed steps
+        power["sustained"]["steps"] = more
+        power["sustained"]["msamples_per_s_local_shards"] = (
+            samples_per_step * more / (t2 - t1) / 1e6)
+    return power
+
+
 def hbm_probe(in0, in1, out0, out1, nwords, r, w, mode, reps, stream=0):
     """tools/libhbmprobe.so: average ms per launch of an arithmetic-free
     kernel reading r and writing w arrays of nwords 32-bit words -- the same
@@ -509,6 +589,8 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         ev[k + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    power = finish_power(sampler, step, torch.cuda.synchronize, t0, elapsed,
+                         args.steps, float(n))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -667,9 +749,10 @@ def run_group(args, w, launch):
     kind = w["kind"]
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
-    seeded = False
+    seeded, seed_stages = False, 0
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
-        seeded = ca.Plan(cfg).seed_info["stages"] > 0
+        seed_stages = ca.Plan(cfg).seed_info["stages"]
+        seeded = seed_stages > 0
 
     def fill(g):
         if kind == "p2r":
@@ -717,13 +800,7 @@ def run_group(args, w, launch):
         with torch.cuda.device(devices[0]):
             probes.append(copy_probe(ptrs, n, RW[kind]))
 
-    sampler = None
-    if rank == 0 and not args.no_power:
-        sampler = PowerSampler(devices[0])
-        if sampler.dir is None:
-            sampler = None
-        else:
-            sampler.start()
+    sampler = start_power(devices[0], rank == 0 and not args.no_power)
 
     for _ in range(args.warmup):
         step(grp)
@@ -742,28 +819,8 @@ def run_group(args, w, launch):
             marks.append(k + 1)
     barrier()
     elapsed = time.perf_counter() - t0
-    power = None
-    if sampler is not None:
-        # the timed region is short (the governor is still settling); keep
-        # the same kernel going for two more seconds and sample that as well
-        t1 = time.perf_counter()
-        ms_step = elapsed / args.steps
-        more = max(1, min(4000, int(2.0 / max(ms_step, 1e-6))))
-        for _ in range(more):
-            step(grp)
-        grp.sync()
-        t2 = time.perf_counter()
-        sampler.stop()
-        power = {"source": "amdgpu hwmon of the device (power1_input, "
-                           "freq1_input), host thread, every 2 ms",
-                 "limit_w": sampler.limit_w(),
-                 "timed_region": sampler.window(t0, t1),
-                 "sustained": sampler.window(t1 + (t2 - t1) / 2, t2)}
-        if power["sustained"]:
-            # for information only: `value` is the K timed steps above
-            power["sustained"]["steps"] = more
-            power["sustained"]["msamples_per_s_local_shards"] = (
-                float(nlocal) * n * more / (t2 - t1) / 1e6)
+    power = finish_power(sampler, lambda: step(grp), grp.sync, t0, elapsed,
+                         args.steps, float(nlocal) * n)
     per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -908,6 +965,7 @@ def run_group(args, w, launch):
             what="arrays allocated +2 spare, arithmetic-free probes of the "
                  "job's traffic over the role assignments, best kept "
                  "(--no-placement: as hipMalloc hands them out)")
+        pm = None
         if not args.no_pmc and total == 1:
             try:
                 pm = measure_pmc(args)
@@ -919,6 +977,8 @@ def run_group(args, w, launch):
                     n / float(1 << args.log2_samples))
                 roof["traffic_over_algorithmic"] = roof["traffic"] / (
                     w["bytes"] * n)
+        add_valu(roof, n / kern_avg_s, pm, power, from_profile(
+            args.workload + ("_noseed" if args.no_seed else "")))
         if probes and probes[0]:
             # the plain-copy ceiling of THIS run on THESE arrays: best of the
             # probes before and after the timed region
@@ -968,10 +1028,11 @@ def run_group(args, w, launch):
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
-                    "seeded(10)+unrolled, %s" % (
-                        "static chunks" if args.static_chunks
+                    "seeded(%d)+unrolled, %s" % (
+                        seed_stages, "static chunks" if args.static_chunks
                         else "address-ordered tile queue")
-                    if seeded else "unrolled"),
+                    if seeded else ("topolar_lj / topolar_unrolled"
+                                    if kind == "r2p" else "unrolled")),
                 "input": args.input,
                 "parallelism": "shard%d" % total,
             },
@@ -1006,7 +1067,7 @@ def run_group(args, w, launch):
             out["cpu_baseline"] = cpu_baseline(args.workload)
         if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
             torch.cuda.empty_cache()
-            out["other_paths"] = other_paths(ca, dev)
+            out["other_paths"] = other_paths(args)
         emit(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
@@ -1220,6 +1281,7 @@ def run_direct(args, w, launch):
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler = start_power(local, rank == 0 and not args.no_power)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -1234,6 +1296,8 @@ def run_direct(args, w, launch):
         ev[k + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    power = finish_power(sampler, step, torch.cuda.synchronize, t0, elapsed,
+                         args.steps, float(n))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1359,6 +1423,21 @@ def run_direct(args, w, launch):
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,
         }
+        roof = out["roofline"]
+        if power is not None:
+            roof["power"] = power
+        pm = None
+        if not args.no_pmc and world == 1:
+            try:
+                pm = measure_pmc(args)
+            except Exception as e:            # never lose the main line
+                pm = {"error": repr(e)}
+            roof["pmc"] = pm
+            if "hbm_bytes_per_launch" in pm:
+                roof["traffic"] = pm["hbm_bytes_per_launch"]
+                roof["traffic_over_algorithmic"] = roof["traffic"] / (
+                    w["bytes"] * n)
+        add_valu(roof, n / kern_avg_s, pm, power, out["from_profile"])
         if full is not None:
             out["full_recurrence_kernel"] = full
         if not args.no_cpu_baseline and world == 1:
@@ -1397,6 +1476,9 @@ def main():
     ap.add_argument("--no-power", action="store_true",
                     help="skip the hwmon power / clock samples and the two "
                          "seconds of sustained running behind the timed region")
+    ap.add_argument("--pmc-counters",
+                    default="FETCH_SIZE,WRITE_SIZE,SQ_INSTS_VALU",
+                    help="comma-separated rocprofv3 counters, one pass each")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip measuring roofline.traffic (two rocprofv3 --pmc "
                     "passes, FETCH_SIZE and WRITE_SIZE, over a 3-step run of "

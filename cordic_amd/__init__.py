@@ -17,7 +17,7 @@ from ._native import (  # noqa: F401
     FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_STATIC_CHUNKS,
     FLAG_UNIT_GAIN,
     ERR_ARGS, ERR_DEVICE, ERR_CONTAINER,
-    Config, CordicError, Plan, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, Quality, fill_circle,
+    Config, CordicError, Plan, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED,
     lib, lib_path,
     p2r, p2r_const, nco, r2p,
     p2r_host, r2p_host,
@@ -26,7 +26,7 @@ from ._native import (  # noqa: F401
 
 __all__ = [
     "P2R", "R2P", "SP2R", "SR2P", "Config", "CordicError", "Plan",
-    "seed_table", "Quality", "fill_circle", "Table", "TBL", "QTR", "Quad", "Stream", "Seq", "lib", "lib_path",
+    "seed_table", "Quality", "fill_circle", "last_kernel", "KERNEL_GENERIC", "KERNEL_UNROLLED", "KERNEL_SEEDED", "KERNEL_LEFT_JUSTIFIED", "Table", "TBL", "QTR", "Quad", "Stream", "Seq", "lib", "lib_path",
     "p2r", "p2r_const", "nco", "r2p", "p2r_host", "r2p_host",
     "fill_phase_ramp", "fill_iq_ramp", "digest_u32",
 ]

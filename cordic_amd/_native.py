@@ -207,6 +207,7 @@ ABI = {
                                       C.c_int, C.c_void_p]),
     "cordic_digest_u32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64,
                                     C.c_void_p, C.c_void_p]),
+    "cordic_last_kernel": (C.c_int, []),
     "cordic_quality_create": (C.c_int, [_cfgp, C.POINTER(C.c_void_p)]),
     "cordic_quality_destroy": (None, [C.c_void_p]),
     "cordic_quality_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -901,6 +902,14 @@ def fill_circle(x, y, index0, lgnsamples, iw, pw, n=None, stream=None):
     _check(lib().cordic_fill_circle(_ptr(x), _ptr(y), n, index0, lgnsamples,
                                     iw, pw, _stream(stream)),
            "cordic_fill_circle")
+
+
+KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED = 1, 2, 3, 4
+
+
+def last_kernel():
+    """enum cordic_kernel_family of this thread's most recent launch"""
+    return lib().cordic_last_kernel()
 
 
 def seed_table(cfg):

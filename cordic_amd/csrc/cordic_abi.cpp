@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -14,15 +15,31 @@
 using namespace cordic_amd;
 
 // ------------------------------------------------------------------- plans
-// Tile queues of the seeded kernel: every launch takes the next slot of a ring
-// (zeroed once here, left zeroed by every kernel that used it), so launches of
-// one plan that overlap (other streams, other threads) never share counters --
-// short of kQueueSlots of them being in flight at once.
+// Tile queues of the seeded kernel (CORDIC_QUEUE_BYTES of device counters,
+// zeroed once here and left zeroed by every kernel that used them).  Two
+// launches must never share a block of counters while either is running, so a
+// slot is handed out again only once the launch that used it has COMPLETED:
+//   - eager launches draw from slots [0, kEagerSlots): each slot carries an
+//     event recorded right behind its kernel; a slot whose event has not
+//     completed is skipped, and when every slot is busy the launch gets no
+//     queue at all and runs the static chunk-per-block sweep (same results);
+//   - a launch issued while its stream is being CAPTURED keeps its slot baked
+//     into the graph node and may be replayed at any later time, so it takes a
+//     slot from [kEagerSlots, kQueueSlots) that is never handed out again
+//     (at most kQueueSlots - kEagerSlots captured launches per handle; further
+//     ones run the static sweep).  A graph exec never runs concurrently with
+//     itself, so one slot per captured node is enough.
 constexpr unsigned kQueueSlots = 64;
+constexpr unsigned kEagerSlots = 48;
 
 struct QueueRing {
+	enum State : unsigned char { FREE, CLAIMED, RECORDED, RETIRED };
 	uint32_t *d = nullptr;		// kQueueSlots x CORDIC_QUEUE_BYTES
-	mutable std::atomic<unsigned> next{0};
+	mutable std::mutex mu;
+	mutable hipEvent_t ev[kEagerSlots] = {};
+	mutable State state[kQueueSlots] = {};
+	mutable unsigned next = 0, next_captured = kEagerSlots;
+
 	bool alloc()
 	{
 		const size_t bytes = (size_t)kQueueSlots * CORDIC_QUEUE_BYTES;
@@ -32,16 +49,70 @@ struct QueueRing {
 			release();
 			return false;
 		}
+		for (unsigned k = 0; k < kEagerSlots; k++)
+			if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
+				release();
+				return false;
+			}
 		return true;
 	}
-	void release() { if (d) (void)hipFree(d); d = nullptr; }
-	uint32_t *take() const
+	void release()
+	{
+		for (unsigned k = 0; k < kEagerSlots; k++)
+			if (ev[k]) {
+				(void)hipEventDestroy(ev[k]);
+				ev[k] = nullptr;
+			}
+		if (d) (void)hipFree(d);
+		d = nullptr;
+	}
+	uint32_t *ptr(int slot) const
+	{
+		return slot < 0 ? nullptr : d + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
+	}
+	// a slot no launch in flight uses, or -1 (the caller then launches
+	// without a queue)
+	int claim(void *stream) const
 	{
 		if (!d)
-			return nullptr;
-		const unsigned slot = next.fetch_add(1, std::memory_order_relaxed)
-				% kQueueSlots;
-		return d + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
+			return -1;
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) != hipSuccess) {
+			(void)hipGetLastError();
+			cs = hipStreamCaptureStatusNone;
+		}
+		std::lock_guard<std::mutex> lock(mu);
+		if (cs != hipStreamCaptureStatusNone) {
+			if (next_captured >= kQueueSlots)
+				return -1;
+			state[next_captured] = RETIRED;
+			return (int)next_captured++;
+		}
+		for (unsigned i = 0; i < kEagerSlots; i++) {
+			const unsigned k = (next + i) % kEagerSlots;
+			if (state[k] == RECORDED && hipEventQuery(ev[k]) == hipSuccess)
+				state[k] = FREE;
+			if (state[k] == FREE) {
+				state[k] = CLAIMED;
+				next = (k + 1) % kEagerSlots;
+				return (int)k;
+			}
+		}
+		(void)hipGetLastError();	// hipErrorNotReady of the queries
+		return -1;
+	}
+	// after the launch that uses `slot` has been enqueued (rc = its status)
+	void launched(int slot, void *stream, int rc) const
+	{
+		if (slot < 0 || slot >= (int)kEagerSlots)
+			return;
+		std::lock_guard<std::mutex> lock(mu);
+		if (rc != CORDIC_OK)
+			state[slot] = FREE;	// nothing ran on it
+		else if (hipEventRecord(ev[slot], static_cast<hipStream_t>(stream)) == hipSuccess)
+			state[slot] = RECORDED;
+		else
+			state[slot] = RETIRED;	// cannot tell when it is free again
 	}
 };
 
@@ -51,6 +122,8 @@ struct cordic_plan {
 	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
 	QueueRing queues;
 };
+
+int cordic_last_kernel(void) { return g_last_kernel; }
 
 int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 {
@@ -118,7 +191,15 @@ static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 	j.seed_S = plan->S;
 	j.seed_nbuckets = plan->nbuckets;
 	j.seed_nleaves = plan->nleaves;
-	j.queue = plan->queues.take();
+}
+
+// launch with a tile queue no other launch in flight is using
+template <typename F> static int with_queue(const QueueRing &ring, void *stream, F launch)
+{
+	const int slot = ring.claim(stream);
+	const int rc = launch(ring.ptr(slot));
+	ring.launched(slot, stream, rc);
+	return rc;
 }
 
 int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,
@@ -131,7 +212,10 @@ int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,
 	j.x0 = xval; j.y0 = yval; j.phase = d_phase;
 	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
 	attach_seed(plan, j);
-	return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+	return with_queue(plan->queues, stream, [&](uint32_t *q) {
+		j.queue = q;
+		return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+	});
 }
 
 int cordic_plan_nco(const cordic_plan *plan, size_t n, uint32_t phase0,
@@ -144,7 +228,10 @@ int cordic_plan_nco(const cordic_plan *plan, size_t n, uint32_t phase0,
 	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
 	j.index0 = index0; j.ox = d_oxval; j.oy = d_oyval; j.n = n;
 	attach_seed(plan, j);
-	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+	return with_queue(plan->queues, stream, [&](uint32_t *q) {
+		j.queue = q;
+		return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+	});
 }
 
 // 16-bit containers: the job carries the int16 / uint16 arrays behind its
@@ -240,7 +327,10 @@ int cordic_plan_p2r16_const(const cordic_plan *plan, size_t n, int32_t xval,
 	RotatorJob j = job16(nullptr, nullptr, d_phase, d_oxval, d_oyval, n);
 	j.x0 = xval; j.y0 = yval;
 	attach_seed(plan, j);
-	return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+	return with_queue(plan->queues, stream, [&](uint32_t *q) {
+		j.queue = q;
+		return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+	});
 }
 
 int cordic_plan_nco16(const cordic_plan *plan, size_t n, uint32_t phase0,
@@ -255,7 +345,10 @@ int cordic_plan_nco16(const cordic_plan *plan, size_t n, uint32_t phase0,
 	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
 	j.index0 = index0;
 	attach_seed(plan, j);
-	return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+	return with_queue(plan->queues, stream, [&](uint32_t *q) {
+		j.queue = q;
+		return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);
+	});
 }
 
 // ------------------------------------------------------------- table cores
@@ -376,9 +469,10 @@ int cordic_table_lookup(const cordic_table *tbl, size_t n,
 {
 	if (!tbl)
 		return CORDIC_ERR_ARGS;
-	return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val, stream,
-			tbl->d_lds16, tbl->lds_mode, tbl->lds_entries,
-			tbl->queues.take());
+	return with_queue(tbl->queues, stream, [&](uint32_t *q) {
+		return launch_table_lookup(tbl->cfg, tbl->d_tbl, n, d_phase, d_val,
+				stream, tbl->d_lds16, tbl->lds_mode, tbl->lds_entries, q);
+	});
 }
 
 // ------------------------------------------------- quadratic sine core
@@ -461,8 +555,10 @@ int cordic_quad_lookup(const cordic_quad *core, size_t n, const uint32_t *d_phas
 {
 	if (!core)
 		return CORDIC_ERR_ARGS;
-	return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin, stream,
-			core->queues.take());
+	return with_queue(core->queues, stream, [&](uint32_t *q) {
+		return launch_quad_lookup(core->cfg, core->d_tab, n, d_phase, d_sin,
+				stream, q);
+	});
 }
 
 // Scratch of the clocked views.  cordic_*_reserve sizes it up front; a *_ticks

@@ -59,6 +59,10 @@ struct Shard {
 	uint64_t *d_digest = nullptr;
 	hipEvent_t marks[kMaxMarks] = {};
 	hipEvent_t piece[kMaxChunks] = {};
+	// recorded on `copy` behind the last forwarded piece of a job: the next
+	// job's kernels overwrite out0 / out1 and must not overtake those reads
+	hipEvent_t copied = nullptr;
+	bool	copy_pending = false;
 	ncclComm_t comm = nullptr;	// rank = index of total (cordic_group_rccl_init)
 	// what the last placement of this shard's arrays saw
 	int	place_candidates = 0, place_probes = 0;
@@ -137,7 +141,12 @@ struct cordic_group {
 	int	chunks = 1;
 	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
 	bool	placement = true;
+	// the job size the shards' input arrays were last filled for (0: not
+	// filled, kCallerFilled: cordic_group_write supplied them)
+	uint64_t filled_total = 0;
+	int	filled_inputs = 0;
 };
+constexpr uint64_t kCallerFilled = ~(uint64_t)0;
 
 namespace {
 
@@ -162,6 +171,7 @@ void release(Shard &s)
 	if (s.plan) cordic_plan_destroy(s.plan);
 	for (hipEvent_t &e : s.marks) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t &e : s.piece) if (e) (void)hipEventDestroy(e);
+	if (s.copied) (void)hipEventDestroy(s.copied);
 	if (s.compute) (void)hipStreamDestroy(s.compute);
 	if (s.copy) (void)hipStreamDestroy(s.copy);
 	s = Shard{};
@@ -210,8 +220,20 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 	const size_t bytes = (size_t)(words ? words : 1) * 4;
 	std::vector<void *> pool;
 	const size_t want = need + (tune ? (size_t)kPlaceSpare : 0);
+	// a spare candidate is taken only while as much again stays free (other
+	// shards or processes may share the device)
+	auto room_for_spare = [&] {
+		size_t fr = 0, tot = 0;
+		if (!ok(hipMemGetInfo(&fr, &tot))) {
+			(void)hipGetLastError();
+			return false;
+		}
+		return fr >= 2 * bytes;
+	};
 	for (size_t k = 0; k < want; k++) {
 		void *p = nullptr;
+		if (k >= need && !room_for_spare())
+			break;
 		if (!ok(hipMalloc(&p, bytes))) {
 			(void)hipGetLastError();
 			if (k >= need)
@@ -270,6 +292,8 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
 		while (!failed && best > good && pool.size() < need + (size_t)kPlaceSpareMax) {
 			void *p = nullptr;
+			if (!room_for_spare())
+				break;
 			if (!ok(hipMalloc(&p, bytes))) {
 				(void)hipGetLastError();
 				break;		// no room: make do with what there is
@@ -368,11 +392,18 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			return CORDIC_ERR_DEVICE;
 		const uint64_t cap = cnt > s.cap ? cnt : s.cap;
 		const int nin = inputs > s.inputs ? inputs : s.inputs;
-		if (cap > s.cap)
+		if (cap > s.cap) {
 			for (void *&p : s.buf) {
 				if (p) (void)hipFree(p);
 				p = nullptr;
 			}
+			// nothing is allocated until the calls below succeed, and
+			// whatever the inputs held is gone
+			s.cap = 0;
+			s.inputs = 0;
+			g->filled_total = 0;
+			g->filled_inputs = 0;
+		}
 		s.place_candidates = s.place_probes = 0;
 		s.place_best_ms = s.place_worst_ms = 0.f;
 		s.place_wbest_ms = s.place_wworst_ms = 0.f;
@@ -459,8 +490,22 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 	DeviceScope scope;
 	if (int rc = ensure(g, n_total, inputs))
 		return rc;
+	// jobs that read input arrays need them filled for THIS job size
+	if (inputs > 0 && g->filled_total != kCallerFilled &&
+	    (g->filled_total != n_total || g->filled_inputs < inputs))
+		return CORDIC_ERR_ARGS;
 	const bool forward = g->root >= 0 || g->rroot >= 0;
 	const int chunks = forward ? g->chunks : 1;
+	for (Shard &s : g->shards) {
+		if (!s.copy_pending)
+			continue;
+		// the previous job's pieces are still being read by the copy
+		// engines / RCCL: this job's kernels write the same arrays
+		if (!ok(hipSetDevice(s.device)) ||
+		    !ok(hipStreamWaitEvent(s.compute, s.copied, 0)))
+			return CORDIC_ERR_DEVICE;
+		s.copy_pending = false;
+	}
 	// piece-major, so that every device has work queued before the first
 	// copy is issued
 	for (int c = 0; c < chunks; c++) {
@@ -496,6 +541,17 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 			if (int rc = rccl_forward(g, n_total, c))
 				return rc;
 	}
+	if (forward)
+		for (Shard &s : g->shards) {
+			if (!ok(hipSetDevice(s.device)))
+				return CORDIC_ERR_DEVICE;
+			if (!s.copied && !ok(hipEventCreateWithFlags(&s.copied,
+					hipEventDisableTiming)))
+				return CORDIC_ERR_DEVICE;
+			if (!ok(hipEventRecord(s.copied, s.copy)))
+				return CORDIC_ERR_DEVICE;
+			s.copy_pending = true;
+		}
 	return CORDIC_OK;
 }
 
@@ -673,6 +729,8 @@ int cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift)
 				(size_t)cnt, start, shift, s.compute))
 			return rc;
 	}
+	grp->filled_total = n_total;
+	grp->filled_inputs = 1;
 	return CORDIC_OK;
 }
 
@@ -694,6 +752,8 @@ int cordic_group_fill_iq_ramp(cordic_group *grp, uint64_t n_total, uint32_t mulx
 				mulx, muly, bits, s.compute))
 			return rc;
 	}
+	grp->filled_total = n_total;
+	grp->filled_inputs = 2;
 	return CORDIC_OK;
 }
 
@@ -981,9 +1041,12 @@ int cordic_group_write(cordic_group *grp, int local_shard, int array,
 	DeviceScope scope;
 	if (!ok(hipSetDevice(s.device)) ||
 	    !ok(hipStreamSynchronize(s.compute)) ||
+	    !ok(hipStreamSynchronize(s.copy)) ||
 	    !ok(hipMemcpy(static_cast<uint32_t *>(s.buf[array]) + offset, src,
 			(size_t)count * 4, hipMemcpyDefault)))
 		return CORDIC_ERR_DEVICE;
+	if (array < 2)
+		grp->filled_total = kCallerFilled;	// the caller's own inputs
 	return CORDIC_OK;
 }
 

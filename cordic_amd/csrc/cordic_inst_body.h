@@ -82,28 +82,45 @@ namespace {
 // trapping on the device.  Also raises the dynamic-LDS limit.
 inline bool seeded_kernel_usable(const void *kern, size_t lds_bytes)
 {
-	// verified kernels of this thread (the attribute is sticky per function
-	// and always raised to the whole 160 KiB, so one check per kernel does)
-	constexpr int kCache = 16;
-	thread_local const void *ok[kCache] = {};
+	// function attributes and LDS limits are per DEVICE: the cache of
+	// verified kernels is keyed on (device, kernel), and the table has to
+	// fit what this device offers per block (160 KiB on gfx950; a part with
+	// less simply runs the full-recurrence kernel)
+	int dev = 0, lds_max = 0;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	constexpr int kCache = 64;
+	struct Seen { const void *kern; int dev; int lds_max; };
+	thread_local Seen ok[kCache] = {};
 	for (int i = 0; i < kCache; i++)
-		if (ok[i] == kern)
-			return lds_bytes <= 160 * 1024;
+		if (ok[i].kern == kern && ok[i].dev == dev)
+			return lds_bytes <= (size_t)ok[i].lds_max;
 	hipFuncAttributes attr;
-	if (hipFuncGetAttributes(&attr, kern) != hipSuccess
+	int optin = 0;
+	if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin,
+				dev) != hipSuccess) {
+		(void)hipGetLastError();
+		optin = 0;
+	}
+	if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock,
+				dev) != hipSuccess
+			|| lds_bytes > (size_t)(lds_max = lds_max > optin ? lds_max : optin)
+			|| hipFuncGetAttributes(&attr, kern) != hipSuccess
 			|| attr.sharedSizeBytes != 0
 			|| hipFuncSetAttribute(kern,
-				hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+				hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)
 				!= hipSuccess) {
 		(void)hipGetLastError();
 		return false;
 	}
 	for (int i = 0; i < kCache; i++)
-		if (!ok[i]) {
-			ok[i] = kern;
+		if (!ok[i].kern) {
+			ok[i] = Seen{kern, dev, lds_max};
 			break;
 		}
-	return lds_bytes <= 160 * 1024;
+	return true;
 }
 
 template <Feed FEED>

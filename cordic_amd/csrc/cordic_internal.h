@@ -68,6 +68,7 @@ bool	seed_eligible(const cordic_config &c, int m);
 size_t	build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap);
 
 // ---- device launchers: cordic_kernels.hip
+extern thread_local int g_last_kernel;	// enum cordic_kernel_family
 // Where the rotator's phase / vector inputs come from.
 enum class Feed : int {
 	PhaseArray_ConstXY = 0,	// d_phase[], scalar x/y      (cordic_p2r_const)

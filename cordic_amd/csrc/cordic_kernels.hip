@@ -14,6 +14,10 @@
 #include "cordic_launch.h"
 
 namespace cordic_amd {
+// cordic_last_kernel(): which kernel family served this thread's most recent
+// rotator / converter launch (diagnostic; lets a test assert that the fast
+// path really ran instead of a quietly slower one)
+thread_local int g_last_kernel = CORDIC_KERNEL_NONE;
 namespace {
 using namespace dev;
 
@@ -567,7 +571,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 							sa, j, lds);
 			}
 		}
+		if (done)
+			g_last_kernel = CORDIC_KERNEL_SEEDED;
 		if (!done && j.n >= (size_t)kVec) {
+			g_last_kernel = CORDIC_KERNEL_UNROLLED;
 			const int ngen = general_stages_for(cfg.ww);
 			if (j.io16) {
 				done = launch_rot_narrow16(FEED, cfg.nlive, grid, st, kp, j);
@@ -621,6 +628,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 	const int grid = grid_for(kBlock, j.n);
 	if (grid < 0)
 		return CORDIC_ERR_DEVICE;
+	g_last_kernel = CORDIC_KERNEL_GENERIC;
 	launch_rot_generic<FEED>(grid, st, kp, j);
 	return check_launch();
 }
@@ -692,6 +700,8 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 			else if (lj_ok && cfg.ww <= 40)
 				done = launch_pol_ljw(cfg.nlive, grid, st, kp, x, y, mag,
 						phase, n);
+			g_last_kernel = done ? CORDIC_KERNEL_LEFT_JUSTIFIED
+					     : CORDIC_KERNEL_UNROLLED;
 			if (done)
 				;
 			else if (io16)
@@ -719,6 +729,7 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 	const int grid = grid_for(kBlock, n);
 	if (grid < 0)
 		return CORDIC_ERR_DEVICE;
+	g_last_kernel = CORDIC_KERNEL_GENERIC;
 	launch_pol_generic(grid, st, kp, x, y, mag, phase, n, io16);
 	return check_launch();
 }

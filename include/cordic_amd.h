@@ -211,6 +211,19 @@ int	cordic_r2p(const cordic_config *cfg, size_t n,
 		const int32_t *d_xval, const int32_t *d_yval,
 		int32_t *d_omag, uint32_t *d_ophase, void *stream);
 
+/* Diagnostic: the kernel family that served the calling thread's most recent
+ * p2r / nco / r2p launch.  Every family computes the same bits; they differ in
+ * speed (seeded > left-justified / unrolled > generic), and a caller -- or a
+ * test -- that expects the fast path can check that it got it. */
+enum cordic_kernel_family {
+	CORDIC_KERNEL_NONE		= 0,
+	CORDIC_KERNEL_GENERIC		= 1,	/* run-time stage loop            */
+	CORDIC_KERNEL_UNROLLED		= 2,	/* unrolled, one lane = 4 samples */
+	CORDIC_KERNEL_SEEDED		= 3,	/* plan: seed table + unrolled    */
+	CORDIC_KERNEL_LEFT_JUSTIFIED	= 4	/* r2p: topolar_lj / topolar_ljw  */
+};
+int	cordic_last_kernel(void);
+
 /*
  * Plans: a generated core bound to the current HIP device.
  *
@@ -404,7 +417,9 @@ int	cordic_quad_lookup(const cordic_quad *core, size_t n,
  * allocates it up front (synchronising the device), otherwise a call that
  * needs more grows it in stream order on its own stream (hipMallocAsync: no
  * device-wide stall, but not legal inside a stream capture -- reserve first,
- * then capture).  Once reserved a call only enqueues kernels, and
+ * then capture).  cordic_stream_reserve / cordic_seq_reserve themselves
+ * hipDeviceSynchronize and hipFree when they grow the scratch: call them at
+ * set-up time, not between launches that should overlap.  Once reserved a call only enqueues kernels, and
  * the pipeline state sits in one set of device buffers that the kernels update
  * in place, so a HIP graph captured around it can be replayed block after
  * block (the same holds for cordic_seq_ticks).
@@ -502,6 +517,14 @@ int	cordic_group_range(const cordic_group *grp, uint64_t n_total, int shard,
 /* (re)allocate the shards' buffers for jobs of n_total samples with `inputs`
  * (0, 1 or 2) input arrays; job calls do this implicitly on first use */
 int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
+/* A job that READS input arrays (p2r_const: in0; r2p: in0, in1) requires them
+ * to have been filled for the same n_total -- by cordic_group_fill_* or by
+ * cordic_group_write -- since the shards' arrays were last (re)allocated:
+ * growing the capacity discards what the inputs held, and such a job then
+ * returns CORDIC_ERR_ARGS instead of computing on uninitialised memory.
+ * Back-to-back jobs need no cordic_group_sync between them, also with
+ * forwarding set: a job's kernels wait (in stream order, on the device) until
+ * the previous job's pieces have left out0 / out1. */
 /* Placement of the shards' arrays.  What HBM delivers to a job's streams
  * depends on which allocations they run over (a property of the combination of
  * arrays, stable for their lifetime, not visible in the addresses: 0.75-0.82 of

@@ -863,3 +863,103 @@ def test_seeded_plan_in_a_hip_graph_and_on_two_streams():
     for a, b in outs:
         assert np.array_equal(to_np(a), rx) and np.array_equal(to_np(b), ry)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_more_launches_in_flight_than_the_plan_has_tile_queues():
+    """A tile queue is handed out again only when the launch that used it has
+    completed; when every one is busy a launch runs the static sweep.  160
+    launches of ONE plan over four streams (far more than the 48 queues),
+    every output array pre-filled with a sentinel: no sample may be missing,
+    none may come from another launch."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    n = (1 << 22) + 4096 * 5
+    x0 = (1 << 31) - 1
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+    rng = np.random.RandomState(11)
+    phases, want, outs = [], [], []
+    for k in range(4):
+        ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        phases.append(dev_i32(ph))
+        want.append(O.rotate(ocfg, x0, 0, ph))
+        outs.append([[torch.empty(n, dtype=torch.int32, device=DEV)
+                      for _ in range(2)] for _ in range(2)])
+    torch.cuda.synchronize()
+    for rep in range(40):
+        for k, st in enumerate(streams):
+            a, b = outs[k][rep & 1]
+            with torch.cuda.stream(st):
+                a.fill_(0x5a5a5a5a); b.fill_(0x5a5a5a5a)
+            plan.p2r_const(x0, 0, phases[k], a, b, n=n, stream=st)
+            assert ca.last_kernel() == ca.KERNEL_SEEDED
+    torch.cuda.synchronize()
+    for k in range(4):
+        for a, b in outs[k]:
+            assert np.array_equal(to_np(a), want[k][0])
+            assert np.array_equal(to_np(b), want[k][1])
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_graph_replays_overlap_eager_launches_of_the_same_plan():
+    """A captured launch keeps its tile queue for good (replayable at any
+    time); eager launches on another stream never get that one."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    n = 1 << 22
+    x0 = (1 << 31) - 1
+    rng = np.random.RandomState(12)
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    rx, ry = O.rotate(ocfg, x0, 0, ph)
+    dph = dev_i32(ph)
+    gx = torch.zeros(n, dtype=torch.int32, device=DEV)
+    gy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ex = [torch.zeros(n, dtype=torch.int32, device=DEV) for _ in range(2)]
+    side = torch.cuda.Stream(device=DEV)
+    plan.p2r_const(x0, 0, dph, gx, gy)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.p2r_const(x0, 0, dph, gx, gy)
+    for rep in range(60):           # more eager launches than queues
+        if rep % 3 == 0:
+            gx.fill_(-1); gy.fill_(-1)
+            g.replay()
+        with torch.cuda.stream(side):
+            ex[0].fill_(-1); ex[1].fill_(-1)
+        plan.p2r_const(x0, 0, dph, ex[0], ex[1], stream=side)
+        if rep % 3 == 2:
+            torch.cuda.synchronize()
+            assert np.array_equal(to_np(gx), rx) and np.array_equal(to_np(gy), ry)
+            assert np.array_equal(to_np(ex[0]), rx)
+            assert np.array_equal(to_np(ex[1]), ry)
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_the_fast_paths_are_the_ones_that_run():
+    """cordic_last_kernel: BASELINE's cores land on the kernels the bench
+    reports (a silently slower fallback would still be bit-exact)."""
+    n = 1 << 16
+    ph = torch.zeros(n, dtype=torch.int32, device=DEV)
+    a = torch.zeros_like(ph); b = torch.zeros_like(ph)
+    for args in ((ca.P2R, 32, 32, 2, 32, 16), (ca.P2R, 32, 32, 2, 32, 24),
+                 (ca.SP2R, 32, 32, 2, 32, 16)):
+        cfg = ca.Config.from_cli(*args)
+        plan = ca.Plan(cfg)
+        plan.p2r_const(1, 0, ph, a, b)
+        assert ca.last_kernel() == ca.KERNEL_SEEDED
+        plan.nco(n, 0, 1, 0, 1, 0, a, b)
+        assert ca.last_kernel() == ca.KERNEL_SEEDED
+        ca.p2r_const(cfg, 1, 0, ph, a, b)
+        assert ca.last_kernel() == ca.KERNEL_UNROLLED
+        ca.p2r(cfg, a, b, ph, a, b)
+        assert ca.last_kernel() == ca.KERNEL_UNROLLED
+        plan.close()
+    cfg = ca.Config.from_cli(ca.R2P, 24, 24, 2, -1, 20)
+    ca.r2p(cfg, a, b, a, b)
+    assert ca.last_kernel() == ca.KERNEL_LEFT_JUSTIFIED
+    ca.r2p(cfg.with_flags(ca.FLAG_FORCE_GENERIC), a, b, a, b)
+    assert ca.last_kernel() == ca.KERNEL_GENERIC
+    torch.cuda.synchronize()

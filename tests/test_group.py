@@ -275,3 +275,61 @@ def test_placed_arrays_for_stateless_callers():
         ca.Arrays(4 * n, 3, 2)
     with pytest.raises(ca.CordicError):
         ca.Arrays(4 * n, 1, 0)
+
+
+def test_back_to_back_jobs_with_forwarding_do_not_mix():
+    """No cordic_group_sync between two DIFFERENT jobs: the second job's
+    kernels overwrite out0 / out1, which the first job's copies may still be
+    reading.  The group orders them on the device (an event behind the last
+    forwarded piece); each consumer array must hold its own job."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n_total = (1 << 24) + 4101           # long enough for copies to lag
+    g = ca.Group(cfg, devices=[0, 0])
+    dst = [ca.Group(cfg, devices=[0]) for _ in range(3)]
+    ptrs = []
+    for d in dst:
+        d.reserve(n_total, 0)
+        ptrs.append(d.buffers(0)[1])
+    phase0 = [0x1000, 0x9abcdef0, 0x55555555]
+    for k in range(3):
+        g.set_gather(0, ptrs[k][2], ptrs[k][3], 4)
+        g.nco(n_total, phase0[k], 0x01234567, AMP, 0)    # no sync in between
+    g.sync()
+    idx = np.arange(0, n_total, 997, dtype=np.uint64)
+    for k in range(3):
+        ph = ((np.uint64(phase0[k]) + idx * np.uint64(0x01234567))
+              & np.uint64(0xffffffff)).astype(np.uint32)
+        rx, ry = O.rotate(ocfg, AMP, 0, ph)
+        got0 = dst[k].read(0, dst[k].OUT0, 0, n_total)[::997]
+        got1 = dst[k].read(0, dst[k].OUT1, 0, n_total)[::997]
+        assert np.array_equal(got0, rx) and np.array_equal(got1, ry), k
+    g.close()
+    for d in dst:
+        d.close()
+
+
+def test_a_job_needs_inputs_filled_for_its_own_size():
+    """Growing the capacity discards the inputs: a job that reads them must
+    refuse (CORDIC_ERR_ARGS) rather than compute on uninitialised memory."""
+    cfg, ocfg = both(*CFG4)
+    g = ca.Group(cfg, devices=[0, 0])
+    g.fill_phase_ramp(1 << 16, 0)
+    g.p2r_const(1 << 16, AMP, 0)                      # fine
+    with pytest.raises(ca.CordicError) as e:
+        g.p2r_const(1 << 18, AMP, 0)                  # larger, never filled
+    assert e.value.status == ca.ERR_ARGS
+    with pytest.raises(ca.CordicError):
+        g.p2r_const(1 << 15, AMP, 0)                  # other size: other ramp
+    g.fill_phase_ramp(1 << 18, 0)
+    g.p2r_const(1 << 18, AMP, 0)
+    rx, _ = oracle_p2r(ocfg, 0, 1 << 18)
+    got = np.concatenate([g.read(s, g.OUT0, 0, g.range(1 << 18, s)[1])
+                          for s in range(2)])
+    assert np.array_equal(got, rx)
+    # inputs the caller wrote himself are taken as they are
+    g2 = ca.Group(cfg, devices=[0])
+    g2.reserve(4096, 1)
+    g2.write(0, g2.IN0, 0, np.arange(4096, dtype=np.uint32))
+    g2.p2r_const(4096, AMP, 0)
+    assert np.array_equal(g2.read(0, g2.OUT0, 0, 4096), rx[:4096])
+    g.close(); g2.close()
