@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -19,10 +20,12 @@ using namespace cordic_amd;
 // zeroed once here and left zeroed by every kernel that used them).  Two
 // launches must never share a block of counters while either is running, so a
 // slot is handed out again only once the launch that used it has COMPLETED:
-//   - eager launches draw from slots [0, kEagerSlots): each slot carries an
-//     event recorded right behind its kernel; a slot whose event has not
-//     completed is skipped, and when every slot is busy the launch gets no
-//     queue at all and runs the static chunk-per-block sweep (same results);
+//   - eager launches draw from slots [0, kEagerSlots) round robin: each slot
+//     carries an event recorded right behind its kernel; a launch that gets a
+//     slot whose previous user may still be running is ordered behind it on
+//     the device (same stream: nothing to do; other stream: the stream waits
+//     for the event) -- the host never waits and may run ahead of the GPU by
+//     any number of launches;
 //   - a launch issued while its stream is being CAPTURED keeps its slot baked
 //     into the graph node and may be replayed at any later time, so it takes a
 //     slot from [kEagerSlots, kQueueSlots) that is never handed out again
@@ -38,6 +41,7 @@ struct QueueRing {
 	mutable std::mutex mu;
 	mutable hipEvent_t ev[kEagerSlots] = {};
 	mutable State state[kQueueSlots] = {};
+	mutable void *last_stream[kEagerSlots] = {};
 	mutable unsigned next = 0, next_captured = kEagerSlots;
 
 	bool alloc()
@@ -68,7 +72,8 @@ struct QueueRing {
 	}
 	uint32_t *ptr(int slot) const
 	{
-		return slot < 0 ? nullptr : d + (size_t)slot * (CORDIC_QUEUE_BYTES / 4);
+		return slot < 0 ? nullptr
+			: d + (size_t)(slot % (int)kQueueSlots) * (CORDIC_QUEUE_BYTES / 4);
 	}
 	// a slot no launch in flight uses, or -1 (the caller then launches
 	// without a queue)
@@ -76,6 +81,18 @@ struct QueueRing {
 	{
 		if (!d)
 			return -1;
+		// A/B switch (measurement only): the round-2 behaviour, slots handed
+		// out round-robin without looking at what is still in flight
+		static const bool unchecked = [] {
+			const char *e = std::getenv("CORDIC_QUEUE_UNCHECKED");
+			return e && e[0] == '1';
+		}();
+		if (unchecked) {
+			std::lock_guard<std::mutex> lock(mu);
+			const unsigned k = next;
+			next = (next + 1) % kQueueSlots;
+			return (int)k + (int)kQueueSlots;	// launched() ignores it
+		}
 		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
 		if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) != hipSuccess) {
 			(void)hipGetLastError();
@@ -88,17 +105,29 @@ struct QueueRing {
 			state[next_captured] = RETIRED;
 			return (int)next_captured++;
 		}
+		// round robin; a slot whose last launch may still be running is
+		// made safe ON THE DEVICE: same stream -> stream order already
+		// serialises the two kernels; another stream -> this stream waits
+		// for that launch's event (no host wait, and the host may run any
+		// number of launches ahead of the GPU without losing the queue)
 		for (unsigned i = 0; i < kEagerSlots; i++) {
 			const unsigned k = (next + i) % kEagerSlots;
-			if (state[k] == RECORDED && hipEventQuery(ev[k]) == hipSuccess)
-				state[k] = FREE;
-			if (state[k] == FREE) {
-				state[k] = CLAIMED;
-				next = (k + 1) % kEagerSlots;
-				return (int)k;
+			if (state[k] == CLAIMED || state[k] == RETIRED)
+				continue;	// another thread is launching on it
+			if (state[k] == RECORDED && last_stream[k] != stream
+					&& hipEventQuery(ev[k]) != hipSuccess) {
+				(void)hipGetLastError();	// hipErrorNotReady
+				if (hipStreamWaitEvent(static_cast<hipStream_t>(stream),
+						ev[k], 0) != hipSuccess) {
+					(void)hipGetLastError();
+					continue;
+				}
 			}
+			state[k] = CLAIMED;
+			last_stream[k] = stream;
+			next = (k + 1) % kEagerSlots;
+			return (int)k;
 		}
-		(void)hipGetLastError();	// hipErrorNotReady of the queries
 		return -1;
 	}
 	// after the launch that uses `slot` has been enqueued (rc = its status)

@@ -15,9 +15,11 @@
  *   gcc -std=c99 -D_GNU_SOURCE -I include examples/multi_proc.c -L cordic_amd \
  *       -lcordic_amd -Wl,-rpath,$PWD/cordic_amd -o tools/multi_proc
  *   tools/multi_proc [-r WORKERS] [-l LOG2_SAMPLES_PER_GPU] [-n NSTAGES]
- *                    [-k STEPS] [-c CHUNKS] [-d DEV,DEV,...]
+ *                    [-k STEPS] [-c CHUNKS] [-d DEV,DEV,...] [-R ROOT] [-t TOTAL]
  *     -r  workers = GPUs used (default 1; there is no HIP call in the launcher
- *         to count them with); -d the device of each worker (default 0,1,2...)
+ *         to count them with); -d the device of each worker (default 0,1,2...);
+ *     -R  the worker whose GPU collects the results (default 0); -t the job
+ *         size in samples when it is not WORKERS * 2^L (ragged shards)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,12 +63,12 @@ static int write_all(int fd, const void *buf, size_t n)
 	return 0;
 }
 
-static int worker(int rank, int workers, int device, int lg, int ns, int steps,
-		int chunks, int id_in, const int *id_out, int report_fd)
+static int worker(int rank, int workers, int device, uint64_t n_total, int ns,
+		int steps, int chunks, int root_rank, int id_in, const int *id_out,
+		int report_fd)
 {
 	cordic_config cfg;
 	CHECK(cordic_config_init(&cfg, CORDIC_P2R, 32, 32, 2, 32, ns));
-	const uint64_t n_total = ((uint64_t)1 << lg) * (uint64_t)workers;
 	const int32_t amp = 0x7fffffff;
 
 	cordic_group *grp;
@@ -97,15 +99,15 @@ static int worker(int rank, int workers, int device, int lg, int ns, int steps,
 	rep.compute_ms /= (float)steps;
 	CHECK(cordic_group_digest(grp, n_total, &rep.shard_digest));
 
-	/* the consumer's arrays: on worker 0's device, the whole job */
+	/* the consumer's arrays: on the root worker's device, the whole job */
 	cordic_group *root = NULL;
 	void *g0 = NULL, *g1 = NULL;
-	if (rank == 0) {
+	if (rank == root_rank) {
 		CHECK(cordic_group_create(&cfg, 1, &device, 0, 1, &root));
 		CHECK(cordic_group_reserve(root, n_total, 0));
 		CHECK(cordic_group_buffers(root, 0, NULL, NULL, NULL, &g0, &g1, NULL));
 	}
-	CHECK(cordic_group_set_gather_rccl(grp, 0, (int32_t *)g0, (int32_t *)g1, chunks));
+	CHECK(cordic_group_set_gather_rccl(grp, root_rank, (int32_t *)g0, (int32_t *)g1, chunks));
 	CHECK(cordic_group_p2r_const(grp, n_total, amp, 0));	/* warm-up */
 	CHECK(cordic_group_sync(grp));
 	CHECK(cordic_group_mark(grp, 2));
@@ -116,7 +118,7 @@ static int worker(int rank, int workers, int device, int lg, int ns, int steps,
 	CHECK(cordic_group_elapsed(grp, 2, 3, &rep.gather_ms, NULL));
 	rep.gather_ms /= (float)steps;
 	CHECK(cordic_group_set_gather_rccl(grp, -1, NULL, NULL, 1));
-	if (rank == 0) {
+	if (rank == root_rank) {
 		CHECK(cordic_group_digest(root, n_total, &rep.gathered_digest));
 		cordic_group_destroy(root);
 	}
@@ -126,7 +128,8 @@ static int worker(int rank, int workers, int device, int lg, int ns, int steps,
 
 int main(int argc, char **argv)
 {
-	int workers = 1, lg = 28, ns = 24, steps = 10, chunks = 8;
+	int workers = 1, lg = 28, ns = 24, steps = 10, chunks = 8, root = 0;
+	unsigned long long total = 0;
 	int devices[MAXW], listed = 0;
 	for (int k = 1; k < argc; k++) {
 		if (k + 1 >= argc) { fprintf(stderr, "missing value for %s\n", argv[k]); return 2; }
@@ -135,6 +138,8 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[k], "-n")) ns = atoi(argv[++k]);
 		else if (!strcmp(argv[k], "-k")) steps = atoi(argv[++k]);
 		else if (!strcmp(argv[k], "-c")) chunks = atoi(argv[++k]);
+		else if (!strcmp(argv[k], "-R")) root = atoi(argv[++k]);
+		else if (!strcmp(argv[k], "-t")) total = strtoull(argv[++k], NULL, 0);
 		else if (!strcmp(argv[k], "-d")) {
 			char *tok = strtok(argv[++k], ",");
 			while (tok && listed < MAXW) {
@@ -145,10 +150,12 @@ int main(int argc, char **argv)
 	}
 	if (listed && workers == 1) workers = listed;
 	if (workers < 1 || workers > MAXW || (listed && listed != workers) || steps < 1
-			|| lg < 0 || lg > 32) {
-		fprintf(stderr, "bad -r / -d / -k / -l\n");
+			|| lg < 0 || lg > 32 || root < 0 || root >= workers) {
+		fprintf(stderr, "bad -r / -d / -k / -l / -R\n");
 		return 2;
 	}
+	const uint64_t n_job = total ? (uint64_t)total
+				     : ((uint64_t)1 << lg) * (uint64_t)workers;
 	if (!listed)
 		for (int r = 0; r < workers; r++) devices[r] = r;
 
@@ -168,8 +175,8 @@ int main(int argc, char **argv)
 				if (q != r) { close(rp[q][1]); close(idp[q][0]); }
 				if (r != 0) close(idp[q][1]);
 			}
-			_exit(worker(r, workers, devices[r], lg, ns, steps, chunks,
-				idp[r][0], id_out, rp[r][1]));
+			_exit(worker(r, workers, devices[r], n_job, ns, steps, chunks,
+				root, idp[r][0], id_out, rp[r][1]));
 		}
 	}
 	for (int r = 0; r < workers; r++) {
@@ -187,7 +194,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "a worker failed\n");
 		return 1;
 	}
-	const double n_total = (double)((uint64_t)1 << lg) * workers;
+	const double n_total = (double)n_job;
 	uint64_t sum = 0;
 	float cms = 0.f, gms = 0.f;
 	for (int r = 0; r < workers; r++) {
@@ -197,14 +204,15 @@ int main(int argc, char **argv)
 		printf("  worker %d on device %d: %8.3f ms per step, with the gather %8.3f\n",
 			r, devices[r], rep[r].compute_ms, rep[r].gather_ms);
 	}
-	printf("%d process(es), 2^%d samples each, %d stages\n", workers, lg, ns);
+	printf("%d process(es), %llu samples in all, %d stages, results to worker %d\n",
+		workers, (unsigned long long)n_job, ns, root);
 	printf("compute only            : %8.3f ms per step, %9.1f Gsample/s\n", cms,
 		n_total / (cms * 1e-3) / 1e9);
 	printf("compute + RCCL gather   : %8.3f ms per step, %9.1f Gsample/s (%d pieces)\n",
 		gms, n_total / (gms * 1e-3) / 1e9, chunks);
 	printf("sum of the shard digests: %016llx\n", (unsigned long long)sum);
 	printf("digest of the gathered  : %016llx  %s\n",
-		(unsigned long long)rep[0].gathered_digest,
-		rep[0].gathered_digest == sum ? "(equal)" : "(MISMATCH)");
-	return rep[0].gathered_digest == sum ? 0 : 1;
+		(unsigned long long)rep[root].gathered_digest,
+		rep[root].gathered_digest == sum ? "(equal)" : "(MISMATCH)");
+	return rep[root].gathered_digest == sum ? 0 : 1;
 }

@@ -260,20 +260,20 @@ def test_r2p_24_bit_core_with_the_generators_own_stage_count():
 
 @pytest.mark.gpu
 def test_one_lsb_off_fails_where_the_margin_is_tight():
-    """p2r 24 bit (gencordic's own PW 31 / 27 stages): all 2^31 phases pass
-    with AVG err 0.66 against a limit of 0.88; the same outputs with o_xval
-    one LSB high on every other sample do not."""
+    """p2r 20 bit (gencordic's own PW 27 / 23 stages): all 2^27 phases pass
+    with AVG err 0.62 against a limit of 0.85 and MAX err 2.62 against 2.96;
+    the same outputs with o_xval one LSB high on every other sample do not."""
     import torch
     import cordic_amd as ca
     from gpu_util import DEV
-    cfg = ca.Config.from_cli(ca.P2R, 24, 24, 2)
-    assert (cfg.pw, cfg.nstages) == (31, 27)
+    cfg = ca.Config.from_cli(ca.P2R, 20, 20, 2)
+    assert (cfg.pw, cfg.nstages) == (27, 23)
     n = 1 << cfg.pw
     ph = torch.empty(n, dtype=torch.int32, device=DEV)
     ox = torch.empty_like(ph)
     oy = torch.empty_like(ph)
     ca.fill_phase_ramp(ph, 0, 0)
-    x0 = 2 ** 23 - 1
+    x0 = 2 ** 19 - 1
     plan = ca.Plan(cfg)
     plan.p2r_const(x0, 0, ph, ox, oy)
     q = ca.Quality(cfg)
@@ -287,8 +287,8 @@ def test_one_lsb_off_fails_where_the_margin_is_tight():
     assert not bad["pass"] and not bad["pass_avg"]
     assert bad["sum_err2"] > good["sum_err2"] + 0.4 * (n // 2)
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "one_lsb_p2r24.txt"), "w") as f:
-        f.write("p2r -i 24 -o 24 (PW 31, 27 stages), all 2^31 phases\n"
+    with open(os.path.join(OUT, "one_lsb_p2r20.txt"), "w") as f:
+        f.write("p2r -i 20 -o 20 (PW 27, 23 stages), all 2^27 phases\n"
                 "as computed   : AVG err %.6f (limit %.6f) MAX err %.6f "
                 "(limit %.6f) alpha %.9f -> PASS\n"
                 "o_xval+1 on every other sample: AVG err %.6f MAX err %.6f "
@@ -297,3 +297,31 @@ def test_one_lsb_off_fails_where_the_margin_is_tight():
                               bad["avg_err"], bad["max_err"],
                               "PASS" if bad["pass"] else "FAIL"))
     q.close()
+
+
+@pytest.mark.gpu
+def test_p2r_24_bit_core_full_sweep_and_its_worst_sample():
+    """gencordic's own 24-bit rotator (PW 31, 27 stages) over ALL 2^31 phases:
+    AVG err 0.657 (limit 0.881) passes; MAX err 3.147 exceeds the 5.2-sigma
+    threshold 3.053 by 3 % at ONE phase of 2^31 -- a property of the
+    reference's arithmetic, which no Verilated bench could have met (its
+    sweeps stop at int-sized arrays): the engine's output at the worst phase
+    is the oracle's, bit for bit, and the error there is recomputed on the
+    host."""
+    import cordic_amd as ca
+    from gpu_util import gpu_p2r
+    r = _run_tb("nat24_p2r", ["-t", "p2r", "-i", "24", "-o", "24"])
+    m = _p2r_numbers(r.stdout)
+    assert m["n"] == 2 ** 31
+    assert m["avg"] < 1.5 * m["exp"]
+    assert 5.2 * m["exp"] < m["mx"] < 5.5 * m["exp"]
+    worst = int(re.search(r"MAX Err at phase 0x([0-9a-f]+)", r.stdout).group(1), 16)
+    c = O.config_cli(O.P2R, 24, 24, 2)
+    cfg = ca.Config.from_cli(ca.P2R, 24, 24, 2)
+    ph = np.full(8, worst, dtype=np.uint32)
+    x0 = 2 ** 23 - 1
+    rx, ry = O.rotate(c, x0, 0, ph)
+    gx, gy = gpu_p2r(cfg, x0, 0, ph)
+    assert np.array_equal(gx, rx) and np.array_equal(gy, ry)
+    q = Q.p2r_quality(c, ph, x0, 0, rx, ry)
+    assert q["mxerr"] == pytest.approx(m["mx"], rel=1e-6)

@@ -333,3 +333,127 @@ def test_a_job_needs_inputs_filled_for_its_own_size():
     g2.p2r_const(4096, AMP, 0)
     assert np.array_equal(g2.read(0, g2.OUT0, 0, 4096), rx[:4096])
     g.close(); g2.close()
+
+
+# ------------------------------------------------ two ranks, one GPU (shim)
+#
+# Real RCCL refuses two ranks on one device, so the rank > 0 branches of the
+# C++ gather (cordic_group.cpp: rccl_forward) and the piece geometry ACROSS
+# processes never ran on the one-GPU boxes.  tests/rccl_shim/ implements the
+# seven RCCL entry points the group uses over UNIX sockets + HIP IPC;
+# CORDIC_RCCL_LIB selects it, and examples/multi_proc.c (fork per rank, id
+# through pipes) then runs as several processes on device 0.
+
+def _multi_proc(args, timeout=300):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "multi_proc")
+    shim = os.path.join(root, "tests", "rccl_shim", "librccl_shim.so")
+    if not (os.path.exists(exe) and os.path.exists(shim)):
+        pytest.skip("tools/multi_proc or the RCCL shim not built")
+    env = dict(os.environ, CORDIC_RCCL_LIB=shim, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CORDIC_GROUP_PLACEMENT="0")
+    return subprocess.run([exe] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("ranks,root", [(2, 0), (2, 1), (3, 2)])
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+def test_two_processes_gather_through_the_cpp_rccl_path(ranks, root, chunks):
+    """Ragged job size, every piece count, root != 0: the gathered arrays'
+    digest equals the sum of the shards' digests AND the oracle's digest of
+    the whole job (24 stages, phase[n] = n)."""
+    import re
+    cfg, ocfg = both(*CFG4)
+    n_total = (1 << 20) + 4101
+    r = _multi_proc(["-d", ",".join(["0"] * ranks), "-t", str(n_total), "-n", "24",
+                     "-k", "2", "-c", str(chunks), "-R", str(root)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(equal)" in r.stdout
+    assert "results to worker %d" % root in r.stdout
+    got = int(re.search(r"digest of the gathered  : ([0-9a-f]{16})",
+                        r.stdout).group(1), 16)
+    rx, ry = oracle_p2r(ocfg, 0, n_total)
+    assert got == (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
+
+
+_RANK_SCRIPT = r"""
+import os, sys, time
+import numpy as np
+root, rank, idfile, n_total = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import cordic_amd as ca
+import oracle_lib as O
+AMP = 2**31 - 1
+P0 = (0x1000, 0x9abcdef0, 0x55555555)
+cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)
+if rank == 0:
+    uid = ca.rccl_unique_id()
+    open(idfile, "wb").write(bytes(uid))
+    os.rename(idfile, idfile + ".ready")
+else:
+    while not os.path.exists(idfile + ".ready"):
+        time.sleep(0.05)
+    uid = open(idfile + ".ready", "rb").read()
+g = ca.Group(cfg, devices=[0], first_shard=rank, total_shards=2)
+g.rccl_init(uid)
+ROOT_SHARD = 1                       # the consumer is NOT rank 0
+dst = []
+if rank == ROOT_SHARD:
+    dst = [ca.Group(cfg, devices=[0]) for _ in P0]
+    for d in dst:
+        d.reserve(n_total, 0)
+for k, p0 in enumerate(P0):          # different jobs, no sync in between
+    if rank == ROOT_SHARD:
+        ptrs = dst[k].buffers(0)[1]
+        g.set_gather_rccl(ROOT_SHARD, ptrs[2], ptrs[3], 3)
+    else:
+        g.set_gather_rccl(ROOT_SHARD, None, None, 3)
+    g.nco(n_total, p0, 0x01234567, AMP, 0)
+g.sync()
+if rank == ROOT_SHARD:
+    ocfg = O.config_cli(O.P2R, 32, 32, 2, 32, 16)
+    idx = np.arange(n_total, dtype=np.uint64)
+    for k, p0 in enumerate(P0):
+        ph = ((np.uint64(p0) + idx * np.uint64(0x01234567))
+              & np.uint64(0xffffffff)).astype(np.uint32)
+        rx, ry = O.rotate(ocfg, AMP, 0, ph)
+        assert np.array_equal(dst[k].read(0, dst[k].OUT0, 0, n_total), rx), k
+        assert np.array_equal(dst[k].read(0, dst[k].OUT1, 0, n_total), ry), k
+    print("gathered arrays equal the oracle for %d jobs" % len(P0))
+g.close()
+"""
+
+
+def test_group_over_the_shim_from_python_two_ranks(tmp_path):
+    """Two PROCESSES, one shard each, root shard 1, three DIFFERENT successive
+    jobs (NCO blocks with changing phase0) without a sync in between: the
+    arrays gathered on the root equal the oracle element by element."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "tests", "rccl_shim", "librccl_shim.so")
+    if not os.path.exists(shim):
+        pytest.skip("RCCL shim not built")
+    env = dict(os.environ, CORDIC_RCCL_LIB=shim, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    n_total = (1 << 18) + 77
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r),
+                               str(tmp_path / "id.bin"), str(n_total)],
+                              env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+    assert "gathered arrays equal the oracle for 3 jobs" in outs[1][0]
