@@ -116,6 +116,9 @@ WORKLOADS = {
     "qtrtbl": dict(kind="tbl", table=(5, -1, 24, 18), bytes=8, shift=0,
                    desc="quarterwav PW=18 OW=24 (rtl/quarterwav.v), phase "
                    "ramp n"),
+    "qtrtbl24": dict(kind="tbl", table=(5, -1, 24, 17), bytes=8, shift=0,
+                     desc="quarterwav PW=17 OW=24 (32-bit entries in LDS, "
+                     "128 KiB), phase ramp n"),
     "qtrtbl16": dict(kind="tbl", table=(5, -1, 16, 17), bytes=8, shift=0,
                      desc="quarterwav PW=17 OW=16 (int16 copy in LDS), phase "
                      "ramp n"),
@@ -310,7 +313,8 @@ KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
              "cfg1": "rotator_seeded", "cfg3": "topolar_lj",
              "p2rxy": "rotator_unrolled", "quadtbl": "quad_lookup",
              "quadtbl24": "quad_lookup", "sintbl": "table_lookup",
-             "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup"}
+             "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup",
+             "qtrtbl24": "table_lookup"}
 
 
 def measure_pmc(args):
@@ -578,6 +582,7 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    sampler = start_power(dev.index or 0, rank == 0 and not args.no_power)
     for _ in range(args.warmup):
         tab.lookup(phase, out)
     barrier()
@@ -589,8 +594,9 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         ev[k + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    power = finish_power(sampler, step, torch.cuda.synchronize, t0, elapsed,
-                         args.steps, float(n))
+    power = finish_power(sampler, lambda: tab.lookup(phase, out),
+                         torch.cuda.synchronize, t0, elapsed, args.steps,
+                         float(n))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -610,7 +616,7 @@ def bench_table(args, w, ca, dist, dev, world, rank):
         ok = bool(np.array_equal(out[ti].cpu().numpy(), exp))
         avg = float(np.mean(kern_ms)) / 1e3
         achieved = w["bytes"] * n / avg / 1e9
-        emit(json.dumps({
+        line = {
             "metric": "Msamples/sec (%s)" % args.workload,
             "value": float(world) * n * args.steps / elapsed / 1e6,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -620,7 +626,8 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             "config": {"workload": "%s: %s" % (args.workload, w["desc"]),
                        "samples_per_gpu": n, "pw": tab.pw, "ow": tab.ow,
                        "entries": tab.entries,
-                       "kernel": "quad_lookup" if quad else "table_lookup",
+                       "kernel": "quad_lookup" if quad else
+                       "table_lookup (lds mode %d)" % tab.lds_mode,
                        "input": args.input, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -629,7 +636,10 @@ def bench_table(args, w, ca, dist, dev, world, rank):
                          "bytes_per_sample": w["bytes"],
                          "kernel_ms_avg": avg * 1e3},
             "from_profile": from_profile(args.workload),
-            "bit_exact_vs_oracle": ok}))
+            "bit_exact_vs_oracle": ok}
+        if power is not None:
+            line["roofline"]["power"] = power
+        emit(json.dumps(line))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

@@ -399,16 +399,22 @@ namespace {
 bool pack_for_lds(const cordic_table_config &c, const std::vector<int32_t> &t,
 		std::vector<int16_t> *out, int *mode)
 {
-	if (c.ow > 16 || c.pw < 4)
+	if (c.pw < 4)
 		return false;
 	const int quarter = 1 << (c.pw - 2);
 	if (quarter > 32768)
 		return false;
+	// OW <= 16: a packed int16 copy (modes 1 / 2, two blocks per CU); wider
+	// outputs: the 32-bit entries themselves (modes 3 / 4, 128 KiB for 2^15
+	// entries, one block per CU), read from the table in HBM by the kernel
+	const bool wide = c.ow > 16;
 	if (c.kind == CORDIC_QTR) {
-		out->resize((size_t)quarter);
-		for (int k = 0; k < quarter; k++)
-			(*out)[(size_t)k] = (int16_t)t[(size_t)k];
-		*mode = 1;
+		if (!wide) {
+			out->resize((size_t)quarter);
+			for (int k = 0; k < quarter; k++)
+				(*out)[(size_t)k] = (int16_t)t[(size_t)k];
+		}
+		*mode = wide ? 3 : 1;
 		return true;
 	}
 	const int n = 1 << c.pw;
@@ -420,10 +426,12 @@ bool pack_for_lds(const cordic_table_config &c, const std::vector<int32_t> &t,
 		if (v != t[(size_t)i])
 			return false;
 	}
-	out->resize((size_t)quarter + 1);
-	for (int k = 0; k <= quarter; k++)
-		(*out)[(size_t)k] = (int16_t)t[(size_t)k];
-	*mode = 2;
+	if (!wide) {
+		out->resize((size_t)quarter + 1);
+		for (int k = 0; k <= quarter; k++)
+			(*out)[(size_t)k] = (int16_t)t[(size_t)k];
+	}
+	*mode = wide ? 4 : 2;
 	return true;
 }
 } // namespace
@@ -463,10 +471,15 @@ int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 	std::vector<int16_t> packed;
 	int mode = 0;
 	if (pack_for_lds(*cfg, host, &packed, &mode)) {
-		// optional: on failure the L2 gather kernel serves the table
-		if (hipMalloc((void **)&t->d_lds16, packed.size() * 2) == hipSuccess
+		const int quarter = 1 << (cfg->pw - 2);
+		if (mode >= 3) {
+			// the kernel fills its LDS copy from d_tbl itself
+			t->lds_mode = mode;
+			t->lds_entries = quarter + (mode == 4 ? 1 : 0);
+		} else if (hipMalloc((void **)&t->d_lds16, packed.size() * 2) == hipSuccess
 				&& hipMemcpy(t->d_lds16, packed.data(), packed.size() * 2,
 					hipMemcpyHostToDevice) == hipSuccess) {
+			// optional: on failure the L2 gather kernel serves the table
 			t->lds_mode = mode;
 			t->lds_entries = (int)packed.size();
 		} else {

@@ -21,11 +21,13 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			(const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, n / kVec);
 		return true;
 	}
-	switch (nlive) {
+	// the static instances are PLAIN: WW <= 32 and rounding at the 2^30 scale
+	const bool plain = (32 - kp.iw) - kp.in_shl >= 2 && kp.r >= 2 && kp.r <= 31;
+	switch (plain ? nlive : -1) {
 #define X(N) case N: \
-	hipLaunchKernelGGL((topolar_lj<N>), dim3(grid), dim3(kBlock), 0, st, kp, \
-		(const i32x4 *)x, (const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, \
-		n / kVec); \
+	hipLaunchKernelGGL((topolar_lj<N, false, Io32, false, true>), dim3(grid), \
+		dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y, \
+		(i32x4 *)mag, (u32x4 *)ph, n / kVec); \
 	return true;
 	CORDIC_POL_STAGES(X)
 #undef X

@@ -226,13 +226,17 @@ __global__ __launch_bounds__(1024) void table_lookup(
 // the entries are truncated, so it is a property to test, not to assume).
 //   mode 1: -t qtr table as is           (entries  = 2^(PW-2))
 //   mode 2: -t tbl folded to a quadrant  (entries  = 2^(PW-2) + 1)
-template <int MODE>
+//   E = int32_t: the same two layouts for outputs wider than 16 bits, the
+//   entries taken from the 32-bit table itself (lds modes 3 / 4; 2^15 entries
+//   = 128 KiB, one block per CU) -- round 2 gathered those from L2.
+template <int MODE, typename E>
 __global__ __launch_bounds__(1024) void table_lookup_lds(
-		const int16_t *__restrict__ packed, int entries,
+		const E *__restrict__ packed, int entries,
 		const uint32_t *__restrict__ phase, int32_t *__restrict__ val,
 		size_t n, int pw, int ow, uint32_t *queue)
 {
-	extern __shared__ __attribute__((aligned(16))) int16_t lds16[];
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	E *lds16 = reinterpret_cast<E *>(lds_raw);
 	__shared__ uint32_t slot[3];
 	for (int i = threadIdx.x; i < entries; i += 1024)
 		lds16[i] = packed[i];
@@ -770,25 +774,43 @@ int launch_table_lookup(const cordic_table_config &t, const int32_t *d_tbl,
 	if (n == 0) return CORDIC_OK;
 	if (!d_tbl || !phase || !val || !table_sane(t)) return CORDIC_ERR_ARGS;
 	if (!aligned4(phase) || !aligned4(val)) return CORDIC_ERR_ARGS;
-	if (d_lds16 && lds_mode) {
-		const size_t bytes = ((size_t)lds_entries * 2 + 15) & ~(size_t)15;
-		int per_cu = (int)((160 * 1024) / bytes);
+	if (lds_mode >= 3 || (d_lds16 && lds_mode)) {
+		const bool wide = lds_mode >= 3;
+		const size_t bytes = ((size_t)lds_entries * (wide ? 4 : 2) + 15) & ~(size_t)15;
+		int per_cu = (int)((160 * 1024) / (bytes + 64));
 		if (per_cu > 2) per_cu = 2;
-		const int grid = grid_for((size_t)1024 * kVec, n, per_cu);
+		const int grid = grid_for((size_t)1024 * kVec, n, per_cu < 1 ? 1 : per_cu);
 		if (grid < 0) return CORDIC_ERR_DEVICE;
 		hipStream_t st = static_cast<hipStream_t>(stream);
-		auto k1 = table_lookup_lds<1>;
-		auto k2 = table_lookup_lds<2>;
-		auto kern = (lds_mode == 1) ? k1 : k2;
-		bool lds_ok = true;
-		if (bytes + 64 > 64 * 1024)	// + the kernel's static tile-id slots
-			lds_ok = hipFuncSetAttribute((const void *)kern,
+		const void *kern;
+		switch (lds_mode) {
+		case 1: kern = (const void *)table_lookup_lds<1, int16_t>; break;
+		case 2: kern = (const void *)table_lookup_lds<2, int16_t>; break;
+		case 3: kern = (const void *)table_lookup_lds<1, int32_t>; break;
+		default: kern = (const void *)table_lookup_lds<2, int32_t>; break;
+		}
+		bool lds_ok = per_cu >= 1;
+		if (lds_ok && bytes + 64 > 64 * 1024)	// + the kernel's static tile-id slots
+			lds_ok = hipFuncSetAttribute(kern,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)bytes + 64) == hipSuccess;
 		if (lds_ok) {
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), bytes, st,
-					d_lds16, lds_entries, phase, val, n, t.pw, t.ow,
-					queue);
+			if (lds_mode == 1)
+				hipLaunchKernelGGL((table_lookup_lds<1, int16_t>), dim3(grid),
+					dim3(1024), bytes, st, d_lds16, lds_entries, phase,
+					val, n, t.pw, t.ow, queue);
+			else if (lds_mode == 2)
+				hipLaunchKernelGGL((table_lookup_lds<2, int16_t>), dim3(grid),
+					dim3(1024), bytes, st, d_lds16, lds_entries, phase,
+					val, n, t.pw, t.ow, queue);
+			else if (lds_mode == 3)
+				hipLaunchKernelGGL((table_lookup_lds<1, int32_t>), dim3(grid),
+					dim3(1024), bytes, st, d_tbl, lds_entries, phase,
+					val, n, t.pw, t.ow, queue);
+			else
+				hipLaunchKernelGGL((table_lookup_lds<2, int32_t>), dim3(grid),
+					dim3(1024), bytes, st, d_tbl, lds_entries, phase,
+					val, n, t.pw, t.ow, queue);
 			return check_launch();
 		}
 		clear_stale_error();	// the L2 gather kernel below serves the table

@@ -336,7 +336,10 @@ int	cordic_table_lookup(const cordic_table *tbl, size_t n,
 /* which kernel serves this table: 0 = gather from the table in L2, 1 = packed
  * int16 copy of a quarter-wave table in LDS, 2 = full-wave table folded to its
  * first quadrant in LDS (OW <= 16, PW <= 17, and -- for 2 -- the generated
- * table verified to have the symmetry) */
+ * table verified to have the symmetry); 3 / 4 = the same two layouts for
+ * OW > 16 with the 32-bit entries themselves in LDS (PW <= 17: 2^15 entries
+ * = 128 KiB, one block per CU).  A 2^16-entry quadrant (PW 18) does not fit
+ * the 160 KiB of a CU at 24 bits and stays on the L2 gather. */
 int	cordic_table_lds_mode(const cordic_table *tbl);
 
 /* ---------------------------------- quadratically interpolated sine core

@@ -92,7 +92,11 @@ def test_emitted_table_rtl_executed_by_vsim_equals_oracle(args, tmp_path):
                                            (ca.QTR, -1, 16, 17),
                                            (ca.TBL, -1, 16, 16),
                                            (ca.TBL, -1, 12, 15),
-                                           (ca.QTR, -1, 9, 5)])
+                                           (ca.QTR, -1, 9, 5),
+                                           (ca.QTR, -1, 24, 17),
+                                           (ca.QTR, -1, 20, 14),
+                                           (ca.TBL, -1, 24, 17),
+                                           (ca.TBL, -1, 18, 10)])
 def test_gpu_table_lookup_equals_oracle(kind, iw, ow, pw):
     import torch
     from gpu_util import DEV, dev_i32, to_np
@@ -112,7 +116,12 @@ def test_gpu_table_lookup_equals_oracle(kind, iw, ow, pw):
         assert np.array_equal(to_np(out)[off:off + n], exp)
     # small 16-bit tables are served from LDS (a full-wave table only if the
     # generated entries really are symmetric); the rest gather from L2
-    small = t.ow <= 16 and (1 << (t.pw - 2)) <= 32768 and t.pw >= 4
+    # (wider outputs: the 32-bit entries in LDS, modes 3 / 4)
+    fits = (1 << (t.pw - 2)) <= 32768 and t.pw >= 4
+    small = t.ow <= 16 and fits
+    wide = t.ow > 16 and fits
     assert t.lds_mode in ((1,) if (small and kind == ca.QTR) else
-                          (0, 2) if small else (0,))
+                          (0, 2) if small else
+                          (3,) if (wide and kind == ca.QTR) else
+                          (0, 4) if wide else (0,))
     t.close()

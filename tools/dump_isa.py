@@ -36,7 +36,7 @@ KERNELS = [
      r"topolar_unrolled<cordic_amd::dev::Narrow32, 20, 0, false, cordic_amd::dev::Io32, false>",
      "cfg3 r2p, round-1 form (8 instructions per micro-rotation)"),
     ("topolar_lj_20", "cordic_inst_pol_lj.o",
-     r"topolar_lj<20, false, cordic_amd::dev::Io32, false>",
+     r"topolar_lj<20, false, cordic_amd::dev::Io32, false, true>",
      "cfg3 r2p, left-justified form (7 instructions per micro-rotation)"),
 ]
 
