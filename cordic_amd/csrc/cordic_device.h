@@ -42,6 +42,10 @@ constexpr int kBlock = 256;		// 4 waves: one per SIMD
 constexpr int kVec = 4;			// samples per lane per pass (16 B)
 constexpr int kTile = kBlock * kVec;	// samples per block per pass
 constexpr int kSeedBlock = CORDIC_SEED_BLOCK;	// waves of a block share one table
+#ifndef CORDIC_SEED_SUBTILES
+#define CORDIC_SEED_SUBTILES 2
+#endif
+constexpr int kSeedSub = CORDIC_SEED_SUBTILES;	// rows of a tile (rotator_seeded)
 constexpr int kSeedStages = CORDIC_SEED_STAGES;	// M: stages replaced by the table
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1098,7 +1102,13 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// streams advancing at once -- where one-shot tiles reach 0.72-0.76
 		// and this queue 0.72.  One counter per XCD: XCD j sweeps the j-th
 		// eighth of the batch, and helps the others once its own is done.
-		const uint32_t ntiles = (uint32_t)((nvec + kSeedBlock - 1) / kSeedBlock);
+		// A tile is kSeedSub rows of kSeedBlock vectors (row s = vectors
+		// tile * kTileVecs + s * kSeedBlock + lane: every row is one
+		// contiguous 16 KiB stretch per array): with two rows a lane rotates
+		// 8 samples per rendezvous, which halves the barriers, the tickets and
+		// the per-pass scalar work per sample.
+		constexpr uint32_t kTileVecs = (uint32_t)kSeedBlock * kSeedSub;
+		const uint32_t ntiles = (uint32_t)((nvec + kTileVecs - 1) / kTileVecs);
 		const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
 		// three tile-id slots behind the seeds, addressed like them by byte
 		// offset (ds_read / ds_write: a generic `volatile` pointer would
@@ -1160,9 +1170,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		int ring = 0;
 		const uint32_t lane = threadIdx.x;
 		// vectors of the tile that exist (only the batch's last tile is partial)
-		const uint32_t last_live = (uint32_t)(nvec - (size_t)(ntiles - 1) * kSeedBlock);
+		const uint32_t last_live = (uint32_t)(nvec - (size_t)(ntiles - 1) * kTileVecs);
 		auto live = [&](uint32_t tile) -> uint32_t {
-			return tile == ntiles - 1 ? last_live : (uint32_t)kSeedBlock;
+			return tile == ntiles - 1 ? last_live : kTileVecs;
 		};
 		// One pass over tile `cur` with its phases in `in`; the phases of the
 		// next tile are prefetched into `pre` (which may be `in` itself: the
@@ -1170,13 +1180,20 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// (Storing the results one pass late, so that the compiler's
 		// vmcnt(0) wait for the prefetch never meets a young store, measured
 		// no gain: same-box A/B in profiles/r02/ab_delayed_stores.txt.)
-		auto tile_pass = [&](const typename IO::uvec &in, typename IO::uvec &pre) {
+		auto tile_pass = [&](const typename IO::uvec (&in)[kSeedSub],
+				typename IO::uvec (&pre)[kSeedSub]) {
 			const uint32_t nxt = __builtin_amdgcn_readfirstlane(slot[(ring + 1) % 3]);
-			const u32x4 tph = IO::widen(in);
+			u32x4 tph[kSeedSub];
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++)
+				tph[s] = IO::widen(in[s]);
 			if constexpr (FEED != Feed::Nco_ConstXY) {
-				if (nxt != kEnd && lane < live(nxt))
-					pre = __builtin_nontemporal_load(
-						&(phin + (size_t)nxt * kSeedBlock)[lane]);
+#pragma unroll
+				for (int s = 0; s < kSeedSub; s++)
+					if (nxt != kEnd && lane + (uint32_t)s * kSeedBlock < live(nxt))
+						pre[s] = __builtin_nontemporal_load(
+							&(phin + (size_t)nxt * kTileVecs
+								+ (size_t)s * kSeedBlock)[lane]);
 			}
 			// the ticket for the tile after next: drawn now (behind the
 			// prefetch, so that nothing waits for it here), looked at after
@@ -1184,17 +1201,21 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			uint32_t ahead = 0;
 			if (threadIdx.x == 0)
 				ahead = draw();
-			if (lane < live(cur)) {
-				const size_t base = (size_t)cur * kSeedBlock;
-				i32x4 rx, ry;
-				pass(base + lane, tph, rx, ry);
-				// non-temporal loads AND stores: with the address-ordered
-				// queue they are worth +3 % on cfg2 together (0.80 -> 0.82 of
-				// the HBM peak, either one alone +1 %; same-box A/B,
-				// profiles/r02/ab_nontemporal.txt) -- under the round-1 chunk
-				// walk plain stores had been the faster ones
-				CORDIC_STORE_OUT(true, &(ox + base)[lane], IO::narrow(rx));
-				CORDIC_STORE_OUT(true, &(oy + base)[lane], IO::narrow(ry));
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++) {
+				if (lane + (uint32_t)s * kSeedBlock < live(cur)) {
+					const size_t base = (size_t)cur * kTileVecs
+							+ (size_t)s * kSeedBlock;
+					i32x4 rx, ry;
+					pass(base + lane, tph[s], rx, ry);
+					// non-temporal loads AND stores: with the address-
+					// ordered queue they are worth +3 % on cfg2 together
+					// (0.80 -> 0.82 of the HBM peak, either one alone +1 %;
+					// same-box A/B, profiles/r02/ab_nontemporal.txt) -- under
+					// the round-1 chunk walk plain stores had been the faster
+					CORDIC_STORE_OUT(true, &(ox + base)[lane], IO::narrow(rx));
+					CORDIC_STORE_OUT(true, &(oy + base)[lane], IO::narrow(ry));
+				}
 			}
 			if (threadIdx.x == 0)
 				slot[(ring + 2) % 3] = resolve(ahead);
@@ -1202,10 +1223,14 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			cur = nxt;
 			ring = (ring + 1) % 3;
 		};
-		typename IO::uvec pa{};
+		typename IO::uvec pa[kSeedSub] = {};
 		if constexpr (FEED != Feed::Nco_ConstXY) {
-			if (cur != kEnd && lane < live(cur))
-				pa = __builtin_nontemporal_load(&(phin + (size_t)cur * kSeedBlock)[lane]);
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++)
+				if (cur != kEnd && lane + (uint32_t)s * kSeedBlock < live(cur))
+					pa[s] = __builtin_nontemporal_load(
+						&(phin + (size_t)cur * kTileVecs
+							+ (size_t)s * kSeedBlock)[lane]);
 		}
 		// (Alternating two register sets, so that the compiler needs no
 		// copies between passes, doubles the loop body: -8 % on the 24-stage

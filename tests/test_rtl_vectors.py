@@ -205,3 +205,58 @@ def test_gpu_reproduces_every_rtl_vector(vectors):
             gm, gp = gpu_r2p(cfg, x, y)
             assert gm.tolist() == e["o_mag"], name
             assert gp.tolist() == e["o_phase"], name
+
+
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref not built")
+def test_worst_case_samples_of_the_acceptance_sweeps(tmp_path):
+    """The full sweeps of tools/cordic_tb on the GPU (tests/test_acceptance.py,
+    profiles/r03/acceptance/) put the 24-bit cores gencordic derives for
+    itself just OUTSIDE two of the reference's own thresholds:
+      p2r -i 24 -o 24 (PW 31, 27 stages): MAX err 3.1467 > 5.2 sigma = 3.0529
+          at phase 0x5ffbf244 -- one phase of 2^31;
+      r2p -i 24 -o 24 (PW 32, 29 stages): max phase error 12.36 > 9.31 at
+          sample 643630894 of topolar_tb's circle.
+    Is that the engine / oracle, or the reference's arithmetic?  The emitted
+    RTL of exactly those cores, executed by vsim on exactly those samples
+    (and their neighbours), gives the oracle's outputs bit for bit, and the
+    error recomputed from the RTL's own outputs is the figure the sweep
+    reported."""
+    import quality as Q
+
+    def emit(args):
+        vf = tmp_path / "core.v"
+        subprocess.run([GEN, "-a"] + args.split() + ["-f", str(vf)], check=True,
+                       capture_output=True)
+        return vsim.Module(vf.read_text())
+
+    # ---- p2r, 24 bits
+    m = emit("-t p2r -i 24 -o 24")
+    c = O.config_cli(O.P2R, 24, 24, 2)
+    assert (m.params["PW"], m.params["WW"]) == (c.pw, c.ww) == (31, 27)
+    worst = 0x5ffbf244
+    ph = np.array([worst - 2, worst - 1, worst, worst + 1, worst + 2], dtype=np.uint32)
+    x0 = 2 ** 23 - 1
+    res = drive(m, [x0] * ph.size, [0] * ph.size, ph)
+    ox, oy = O.rotate(c, x0, 0, ph)
+    assert [r["o_xval"] for r in res] == ox.tolist()
+    assert [r["o_yval"] for r in res] == oy.tolist()
+    q = Q.p2r_quality(c, ph[2:3], x0, 0, ox[2:3], oy[2:3])
+    assert q["mxerr"] == pytest.approx(3.146680, abs=2e-6)
+    assert q["mxerr"] > 5.2 * q["sigma"]            # the reference's threshold
+
+    # ---- r2p, 24 bits: sample i of topolar_tb.cpp:127-141 (LGNSAMPLES = PW)
+    m = emit("-t r2p -i 24 -o 24")
+    c = O.config_cli(O.R2P, 24, 24, 2)
+    assert (m.params["PW"], m.params["WW"], c.nstages) == (32, 32, 29)
+    i = np.arange(643630894 - 2, 643630894 + 3, dtype=np.int64)
+    ip = (i << 1).astype(np.int32).astype(np.float64)      # ipdata = (int)lv
+    mg = float(2 ** 23 - 1)
+    x = np.trunc(mg * np.cos(ip * np.pi / 2 ** 31)).astype(np.int32)
+    y = np.trunc(mg * np.sin(ip * np.pi / 2 ** 31)).astype(np.int32)
+    res = drive(m, x, y, None)
+    mag, p = O.topolar(c, x, y)
+    assert [r["o_mag"] for r in res] == mag.tolist()
+    assert [r["o_phase"] & 0xffffffff for r in res] == p.tolist()
+    q = Q.r2p_quality(c, x[2:3], y[2:3], int(mg), mag[2:3], p[2:3])
+    assert q["mxperr"] == pytest.approx(12.36, abs=0.01)
+    assert q["mxperr"] > q["phase_limit"]
