@@ -995,15 +995,23 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 
 	// One tile pass: 4 samples per lane of vector g, phases in tph; results in
 	// rx / ry (the caller stores them).
-	auto pass = [&](size_t g, const u32x4 tph, i32x4 &rx, i32x4 &ry) {
-		// pb = folded phase + 45 deg: bits 31..30 the quadrant q, bits 29..0
-		// r = p0 + 2^29.  Nothing below needs r on its own -- the bucket
-		// index is a bit field of pb, the compare and the residual work
-		// modulo 2^30 resp. 2^29 -- which saves the masking.
-		uint32_t pb[kVec];
+	// pb = folded phase + 45 deg: bits 31..30 the quadrant q, bits 29..0
+	// r = p0 + 2^29.  Nothing below needs r on its own -- the bucket index is
+	// a bit field of pb, the compare and the residual work modulo 2^30 resp.
+	// 2^29 -- which saves the masking.  Kept apart from the rotation so that
+	// the tile loop can consume a row's phases BEFORE it prefetches the next
+	// tile's into the same registers (no copies between passes).
+	// NCO feed: the phase of vector g = g0 + lane is  phase0 + fcw * (index0 +
+	// 4 g0)  [block-uniform when g0 is: scalar arithmetic]  + (4 fcw) * lane
+	// [a per-lane constant]: one vector add per row instead of a 64-bit index,
+	// a v_mul_lo_u32 and two more adds.
+	const uint32_t lane4f = (FEED == Feed::Nco_ConstXY)
+			? threadIdx.x * (uint32_t)kVec * kp.fcw : 0u;
+	auto fold_pb = [&](size_t g0, uint32_t lane_part, const u32x4 tph,
+			uint32_t (&pb)[kVec]) {
 		if constexpr (FEED == Feed::Nco_ConstXY) {
-			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
-			pb[0] = (kp.phase0 + 0x20000000u) + s0 * kp.fcw;
+			const uint32_t s0 = (uint32_t)(kp.index0 + g0 * kVec);
+			pb[0] = ((kp.phase0 + 0x20000000u) + s0 * kp.fcw) + lane_part;
 #pragma unroll
 			for (int v = 1; v < kVec; v++)
 				pb[v] = pb[v - 1] + kp.fcw;
@@ -1013,7 +1021,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(pb[v])
 					: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
 		}
-
+	};
+	// One row: 4 samples per lane with their folded phases in pb; results in
+	// rx / ry (the caller stores them).
+	auto pass_pb = [&](const uint32_t (&pb)[kVec], i32x4 &rx, i32x4 &ry) {
 		// three passes so that the four bucket reads, then the four seed
 		// reads, are in flight together (one s_waitcnt each, not eight).
 		// Per sample: lshl_add, lshr, lshr, and | sub, bfe, lshl_add,
@@ -1180,20 +1191,32 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// (Storing the results one pass late, so that the compiler's
 		// vmcnt(0) wait for the prefetch never meets a young store, measured
 		// no gain: same-box A/B in profiles/r02/ab_delayed_stores.txt.)
-		auto tile_pass = [&](const typename IO::uvec (&in)[kSeedSub],
-				typename IO::uvec (&pre)[kSeedSub]) {
+		// a lane's vector in row s of a tile, clamped into the tile's live
+		// part (only the batch's last tile is partial): the loads need no
+		// predicate, so nothing has to be preserved around them
+		auto row_vec = [&](uint32_t tile, int s) -> size_t {
+			uint32_t l = lane + (uint32_t)s * kSeedBlock;
+			const uint32_t top = live(tile) - 1u;	// block-uniform
+			// (spelled out: left to itself the compiler selects with
+			// v_cndmask_b32, ~23 cycles per wave-instruction here, §4.1)
+			asm("v_min_u32 %0, %1, %2" : "=v"(l) : "v"(l), "s"(top));
+			return (size_t)tile * kTileVecs + l;
+		};
+		auto tile_pass = [&](typename IO::uvec (&ph)[kSeedSub]) {
 			const uint32_t nxt = __builtin_amdgcn_readfirstlane(slot[(ring + 1) % 3]);
-			u32x4 tph[kSeedSub];
+			// the phases of this tile are consumed first ...
+			uint32_t pb[kSeedSub][kVec];
 #pragma unroll
 			for (int s = 0; s < kSeedSub; s++)
-				tph[s] = IO::widen(in[s]);
+				fold_pb((size_t)cur * kTileVecs + (size_t)s * kSeedBlock, lane4f,
+					IO::widen(ph[s]), pb[s]);
+			// ... then the next tile's are prefetched into the same registers
 			if constexpr (FEED != Feed::Nco_ConstXY) {
+				if (nxt != kEnd) {
 #pragma unroll
-				for (int s = 0; s < kSeedSub; s++)
-					if (nxt != kEnd && lane + (uint32_t)s * kSeedBlock < live(nxt))
-						pre[s] = __builtin_nontemporal_load(
-							&(phin + (size_t)nxt * kTileVecs
-								+ (size_t)s * kSeedBlock)[lane]);
+					for (int s = 0; s < kSeedSub; s++)
+						ph[s] = __builtin_nontemporal_load(&phin[row_vec(nxt, s)]);
+				}
 			}
 			// the ticket for the tile after next: drawn now (behind the
 			// prefetch, so that nothing waits for it here), looked at after
@@ -1207,7 +1230,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					const size_t base = (size_t)cur * kTileVecs
 							+ (size_t)s * kSeedBlock;
 					i32x4 rx, ry;
-					pass(base + lane, tph[s], rx, ry);
+					pass_pb(pb[s], rx, ry);
 					// non-temporal loads AND stores: with the address-
 					// ordered queue they are worth +3 % on cfg2 together
 					// (0.80 -> 0.82 of the HBM peak, either one alone +1 %;
@@ -1225,18 +1248,18 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		};
 		typename IO::uvec pa[kSeedSub] = {};
 		if constexpr (FEED != Feed::Nco_ConstXY) {
+			if (cur != kEnd) {
 #pragma unroll
-			for (int s = 0; s < kSeedSub; s++)
-				if (cur != kEnd && lane + (uint32_t)s * kSeedBlock < live(cur))
-					pa[s] = __builtin_nontemporal_load(
-						&(phin + (size_t)cur * kTileVecs
-							+ (size_t)s * kSeedBlock)[lane]);
+				for (int s = 0; s < kSeedSub; s++)
+					pa[s] = __builtin_nontemporal_load(&phin[row_vec(cur, s)]);
+			}
 		}
 		// (Alternating two register sets, so that the compiler needs no
 		// copies between passes, doubles the loop body: -8 % on the 24-stage
-		// core, nothing elsewhere -- profiles/r02/ab_pingpong.txt.)
+		// core, nothing elsewhere -- profiles/r02/ab_pingpong.txt.  Consuming
+		// the phases before the prefetch needs no copies and no second set.)
 		while (cur != kEnd)
-			tile_pass(pa, pa);
+			tile_pass(pa);
 		if (threadIdx.x == 0)
 			queue_leave(sa.queue);
 		return;
@@ -1269,7 +1292,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				nph = CORDIC_LOAD_IN(&phin[gn]);
 		}
 		i32x4 rx, ry;
-		pass(g, tph, rx, ry);
+		uint32_t pb[kVec];
+		fold_pb(g, 0u, tph, pb);
+		pass_pb(pb, rx, ry);
 		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
 		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	}
@@ -1478,6 +1503,9 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 		ny = CORDIC_LOAD_IN(&yin[g]);
 	}
 	for (; g < nvec; g += stride) {
+		// (Consuming the ports before the prefetch, as the seeded kernel's
+		// tile loop does, changes nothing here: hipcc sinks the prefetch to
+		// the loop latch and keeps 8 v_mov_b64 per pass around it.)
 		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {

@@ -26,6 +26,9 @@ KERNELS = [
     ("rotator_seeded_lj29_16", "cordic_inst_seed_lj29.o",
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false>",
      "cfg2 headline: seeded p2r, WW 35, 16 stages (5 after the seed)"),
+    ("rotator_seeded_lj29_16_nco", "cordic_inst_seed_lj29.o",
+     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)2, false, cordic_amd::dev::Io32, false>",
+     "cfg5: fused NCO + seeded p2r, store only"),
     ("rotator_unrolled_lj29_16", "cordic_inst_rot_lj29.o",
      r"rotator_unrolled<cordic_amd::dev::WideLJ<29>, 16, 2, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false>",
      "cfg2 full recurrence, constant vector"),

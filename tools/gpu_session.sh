@@ -31,7 +31,7 @@ for task in "$@"; do
 		  nproc; grep -m1 'model name' /proc/cpuinfo; cat /sys/fs/cgroup/cpu.max 2>/dev/null
 		  rocm-smi --showclocks --showpower --showtemp --showperflevel 2>&1 | grep -v '^$'
 		  rocminfo 2>/dev/null | grep -E 'Marketing|Compute Unit|Max Clock|gfx' | head -12; } >> $log 2>&1 ;;
-	tests)	timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS} >> $log 2>&1; echo "rc=$?" >> $log ;;
+	tests)	timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS} 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" >> $log; echo "rc=${PIPESTATUS[0]}" >> $log ;;
 	smoke)	timeout 600 python -c "import __graft_entry__ as g; g.smoke()" >> $log 2>&1; echo "rc=$?" >> $log ;;
 	bench)	timeout 900 python bench.py ${BENCH_ARGS} >> $log 2>&1; echo "rc=$?" >> $log ;;
 	hbm)	snap >> $log; timeout 600 ./tools/hbm_probe2 ${HBM_ARGS} >> $log 2>&1; snap >> $log ;;
@@ -68,7 +68,7 @@ d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['ro
 		done; done ;;
 	sweep)	# one bench.py line per workload x {ramp, random}
 		mkdir -p gpurun_out/bench_sweep
-		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 quadtbl quadtbl24; do
+		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 qtrtbl24 quadtbl quadtbl24; do
 			for inp in ramp random; do
 				python bench.py --workload $w --input $inp --no-cpu-baseline --no-other-paths --no-pmc \
 					> gpurun_out/bench_sweep/${w}_${inp}.json 2>> $log
