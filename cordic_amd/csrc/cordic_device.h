@@ -1504,8 +1504,14 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	}
 	for (; g < nvec; g += stride) {
 		// (Consuming the ports before the prefetch, as the seeded kernel's
-		// tile loop does, changes nothing here: hipcc sinks the prefetch to
-		// the loop latch and keeps 8 v_mov_b64 per pass around it.)
+		// tile loop does, changes nothing here: hipcc sinks the predicated
+		// prefetch to the loop latch and keeps 8 v_mov_b64 per pass around
+		// it.  Making it unpredicated -- index clamped with one v_min_u32,
+		// loads in the loop's main block, copies gone -- measured SLOWER in
+		// every grid-stride kernel: cfg3 -4 %, p2rxy -1.5 %, full recurrence
+		// -2.7 %, profiles/r03/ab_unpredicated_prefetch.txt: with the loads
+		// at the top, the vmcnt(0) wait of the next pass falls on this pass's
+		// just-issued stores.)
 		const i32x4 tx = IO::widen(nx), ty = IO::widen(ny);
 		const size_t gn = g + stride;
 		if (gn < nvec) {
