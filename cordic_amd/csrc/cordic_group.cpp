@@ -32,6 +32,7 @@
 #include <rccl/rccl.h>		// types only: the entry points come from dlopen
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -267,6 +268,20 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 			for (int i = 0; i < nread; i++) if (!reads[i]) take(&reads[i], 0);
 		}
 		for (void *q : pool) (void)hipFree(q);
+		// CORDIC_PLACEMENT_DEBUG=1: what the probes saw, and the chosen
+		// assignment probed once more after the rest has been freed (freeing
+		// the neighbours changes nothing: profiles/r03/state_probe.txt)
+		static const bool debug = [] {
+			const char *e = std::getenv("CORDIC_PLACEMENT_DEBUG");
+			return e && e[0] == '1';
+		}();
+		if (debug && tune && nwrite == 2) {
+			const float after = probe_ms(st, nread, 2, reads[0], reads[1], writes[0],
+					writes[1], words, nullptr);
+			std::fprintf(stderr, "[cordic placement] candidates %d probes %d best %.3f ms "
+				"worst %.3f ms; chosen assignment after the spares were freed: "
+				"%.3f ms\n", ps.candidates, ps.probes, ps.best, ps.worst, after);
+		}
 		if (stats) *stats = ps;
 		return CORDIC_OK;
 	};
