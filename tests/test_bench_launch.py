@@ -228,3 +228,34 @@ def test_power_sampler_host_logic(tmp_path, monkeypatch):
     import glob
     if not glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
         assert bench.PowerSampler(0).dir is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["cfg4", "cfg3", "p2rxy", "qtrtbl24"])
+def test_every_line_says_which_ceiling_binds(workload):
+    """roofline.achieved (HBM) AND valu_fraction, with the
+    evidence which bound is hit -- instruction count from this run's own
+    SQ_INSTS_VALU pass, clock from this run's hwmon samples."""
+    r = run(["--workload", workload, "--steps", "6", "--warmup", "2",
+             "--log2-samples", "24", "--no-cpu-baseline", "--no-other-paths",
+             "--no-copy-probe", "--pmc-counters", "SQ_INSTS_VALU"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    roof = d["roofline"]
+    assert d["bit_exact_vs_oracle"] is True
+    assert roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    if workload == "qtrtbl24":
+        assert roof["bound"] == "hbm" and "lds mode 3" in d["config"]["kernel"]
+        return
+    v = roof["valu"]
+    assert "rocprofv3 --pmc pass of this run" in v["instr_source"]
+    # (the seeded kernel builds its table in every block: at 2^24 samples that
+    # prologue adds ~15 % to cfg4's 111 instructions per sample)
+    want = {"cfg4": (105, 135), "cfg3": (150, 175), "p2rxy": (125, 150)}[workload]
+    assert want[0] < v["instr_per_sample"] < want[1], v
+    assert roof["valu_fraction"] == pytest.approx(
+        v["achieved_Tinstr_per_s"] / v["peak_Tinstr_per_s"])
+    assert roof["bound"] in ("hbm", "valu")
+    assert roof["bound"] == ("hbm" if roof["frac"] >= roof["valu_fraction"]
+                             else "valu")

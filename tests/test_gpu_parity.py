@@ -963,3 +963,46 @@ def test_the_fast_paths_are_the_ones_that_run():
     ca.r2p(cfg.with_flags(ca.FLAG_FORCE_GENERIC), a, b, a, b)
     assert ca.last_kernel() == ca.KERNEL_GENERIC
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_one_plan_launched_from_four_host_threads():
+    """Plan handles may be shared between threads (include/cordic_amd.h): four
+    host threads, one stream each, 30 launches each of ONE plan (ctypes drops
+    the GIL inside the calls, so the queue-slot bookkeeping really is entered
+    concurrently); every output complete and its own."""
+    import threading
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    n = (1 << 21) + 4096 + 12
+    x0 = (1 << 31) - 1
+    rng = np.random.RandomState(21)
+    jobs = []
+    for k in range(4):
+        ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        jobs.append(dict(ph=dev_i32(ph), want=O.rotate(ocfg, x0, 0, ph),
+                         st=torch.cuda.Stream(device=DEV),
+                         a=torch.empty(n, dtype=torch.int32, device=DEV),
+                         b=torch.empty(n, dtype=torch.int32, device=DEV)))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(j):
+        try:
+            for _ in range(30):
+                with torch.cuda.stream(j["st"]):
+                    j["a"].fill_(0x5a5a5a5a); j["b"].fill_(0x5a5a5a5a)
+                plan.p2r_const(x0, 0, j["ph"], j["a"], j["b"], n=n, stream=j["st"])
+        except Exception as e:      # surfaced in the main thread below
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for j in jobs:
+        assert np.array_equal(to_np(j["a"]), j["want"][0])
+        assert np.array_equal(to_np(j["b"]), j["want"][1])
+    plan.close()
