@@ -38,6 +38,28 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# TEST SWITCH (tests/test_bench_launch.py): BENCH_TEST_SHARE_GPU=1 lets N ranks
+# share device 0 so that the N > 1 code path of this script -- rank / world
+# bookkeeping, shard ranges, max-over-ranks timing, digest reduction, the
+# one-process block -- can execute on a one-GPU box.  RCCL refuses two ranks on
+# one device, so the process group is gloo and its tensors live on the host.
+# Never set by the driver; a line produced this way says so in `launch.mode`.
+SHARE_GPU = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
+
+
+def dist_init(dist, rank, world, local):
+    if SHARE_GPU:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+
+
+def coll_device(dev):
+    """where the tensors of the (tiny) collectives live"""
+    return torch.device("cpu") if SHARE_GPU else dev
+
 # VALU side of the roofline (SURVEY.md 8d: "report roofline.achieved (HBM) AND
 # valu_fraction").  1024 SIMDs x 64 lanes; in the mixed integer stream of a
 # micro-rotation a SIMD with 8 resident waves issues one VALU wave-instruction
@@ -598,7 +620,7 @@ def bench_table(args, w, ca, dist, dev, world, rank):
                          torch.cuda.synchronize, t0, elapsed, args.steps,
                          float(n))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
@@ -677,12 +699,12 @@ def resolve_launch(args):
                              "one rank per GPU (--nproc-per-node %d)"
                              % (need, world, need))
         have = visible_gpus()
-        if have < need:
+        if have < need and not SHARE_GPU:
             raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, "
                              "found %d" % (need, need, have))
         return "torchrun"
     have = visible_gpus()
-    if have < need:
+    if have < need and not SHARE_GPU:
         raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d"
                          % (need, need, have))
     if args.single_process:
@@ -742,15 +764,14 @@ def run_group(args, w, launch):
         import torch.distributed as dist
         rank = int(os.environ["RANK"])
         world = int(os.environ["WORLD_SIZE"])
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = 0 if SHARE_GPU else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist_init(dist, rank, world, local)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if launch == "single-process":
         total, nlocal, first = args.gpus, args.gpus, 0
-        devices = list(range(args.gpus))
+        devices = [0] * args.gpus if SHARE_GPU else list(range(args.gpus))
     else:
         total, nlocal, first, devices = world, 1, rank, [local]
 
@@ -833,7 +854,7 @@ def run_group(args, w, launch):
                          args.steps, float(nlocal) * n)
     per_rank = [elapsed]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(dev))
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [float(v.item()) for v in allt]
@@ -847,7 +868,7 @@ def run_group(args, w, launch):
     digest = grp.digest(n_total)
     if dist is not None:
         d = torch.tensor([digest - (1 << 64) if digest >= 1 << 63 else digest],
-                         dtype=torch.int64, device=dev)
+                         dtype=torch.int64, device=coll_device(dev))
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
         digest = int(d.item()) & 0xFFFFFFFFFFFFFFFF
 
@@ -912,7 +933,7 @@ def run_group(args, w, launch):
         d2 = grp2.digest(n_total)
         if dist is not None:
             d = torch.tensor([d2 - (1 << 64) if d2 >= 1 << 63 else d2],
-                             dtype=torch.int64, device=dev)
+                             dtype=torch.int64, device=coll_device(dev))
             dist.all_reduce(d, op=dist.ReduceOp.SUM)
             d2 = int(d.item()) & 0xFFFFFFFFFFFFFFFF
         full = {"ms_per_step": ms2, "steps": k2,
@@ -1047,7 +1068,9 @@ def run_group(args, w, launch):
                 "parallelism": "shard%d" % total,
             },
             "launch": {
-                "mode": {"torchrun": "one process per GPU (torch.distributed"
+                "mode": ("TEST: %d ranks sharing device 0, gloo process group; "
+                         % world if SHARE_GPU else "") +
+                        {"torchrun": "one process per GPU (torch.distributed"
                          ".run%s), RCCL only for the digest all-reduce" % (
                              ", self-spawned by bench.py" if os.environ.get(
                                  "BENCH_SELF_SPAWNED") else ""),
@@ -1208,13 +1231,14 @@ def run_direct(args, w, launch):
     world = int(os.environ.get("WORLD_SIZE", "1")) if launch == "torchrun" else 1
     rank = int(os.environ.get("RANK", "0")) if launch == "torchrun" else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) if launch == "torchrun" else 0
+    if SHARE_GPU:
+        local = 0
     dist = None
     if launch == "torchrun":
         # launched by torch.distributed.run: RCCL process group (also for a
         # single rank, so that the collective path can be exercised on 1 GPU)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist_init(dist, rank, world, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -1309,7 +1333,7 @@ def run_direct(args, w, launch):
     power = finish_power(sampler, step, torch.cuda.synchronize, t0, elapsed,
                          args.steps, float(n))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
@@ -1321,6 +1345,8 @@ def run_direct(args, w, launch):
     ca.digest_u32(b.view(torch.int32),
                   index0 // (2 if io16 else 1) + (1 << 40), d)
     if dist is not None:
+        torch.cuda.synchronize()
+        d = d.to(coll_device(dev))
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
     torch.cuda.synchronize()
     digest = int(d.cpu().numpy().view(np.uint64)[0])

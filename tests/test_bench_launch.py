@@ -259,3 +259,82 @@ def test_every_line_says_which_ceiling_binds(workload):
     assert roof["bound"] in ("hbm", "valu")
     assert roof["bound"] == ("hbm" if roof["frac"] >= roof["valu_fraction"]
                              else "valu")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,ranks", [("cfg2", 2), ("cfg4", 3), ("cfg3", 2),
+                                            ("cfg5", 2), ("p2rxy", 2)])
+def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
+    """The command the driver runs for N > 1 --
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    -- executed for real with N ranks SHARING device 0 (BENCH_TEST_SHARE_GPU:
+    gloo process group; RCCL refuses two ranks on one device).  Everything
+    rank-dependent in bench.py runs: RANK / WORLD_SIZE, shard s of N by global
+    index, max-over-ranks timing, whole-job `value`, the digest summed over
+    the ranks -- which must equal the ORACLE's digest of the whole job."""
+    import numpy as np
+    import oracle_lib as O
+    from gpu_util import cpu_digest
+    lg = 20
+    e = dict(os.environ, BENCH_TEST_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", str(ranks),
+           "--workload", workload, "--steps", "4", "--warmup", "1",
+           "--log2-samples", str(lg), "--no-cpu-baseline", "--no-other-paths",
+           "--no-pmc", "--no-power", "--no-copy-probe"]
+    r = subprocess.run(cmd, env=e, text=True, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == ranks and d["scaling"] == "weak"
+    if "launch" in d:       # the cordic_group workloads (p2rxy runs stateless)
+        assert d["launch"]["world_size"] == ranks
+        assert "TEST" in d["launch"]["mode"]
+        assert len(d["launch"]["per_rank_Msamples_per_s"]) == ranks
+    n = 1 << lg
+    assert d["value"] == pytest.approx(
+        ranks * n * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6)
+    assert d["bit_exact_vs_oracle"] is True
+    # the whole job on the CPU: n_total samples by GLOBAL index
+    n_total = ranks * n
+    idx = np.arange(n_total, dtype=np.uint64)
+    amp = 2 ** 31 - 1
+    if workload in ("cfg2", "cfg4"):
+        sh, ns = (2, 16) if workload == "cfg2" else (0, 24)
+        c = O.config_cli(O.P2R, 32, 32, 2, 32, ns)
+        ph = ((idx << np.uint64(sh)) & np.uint64(0xffffffff)).astype(np.uint32)
+        a, b = O.rotate(c, amp, 0, ph)
+    elif workload == "cfg5":
+        c = O.config_cli(O.P2R, 32, 32, 2, 32, 16)
+        ph = ((idx * np.uint64(0x01234567)) & np.uint64(0xffffffff)).astype(np.uint32)
+        a, b = O.rotate(c, amp, 0, ph)
+    else:
+        i32 = idx.astype(np.uint32)
+
+        def ramp(mul, bits):
+            v = ((i32 * np.uint32(mul)) >> np.uint32(8)).astype(np.int64)
+            v &= (1 << bits) - 1
+            return ((v ^ (1 << (bits - 1))) - (1 << (bits - 1))).astype(np.int32)
+        if workload == "cfg3":
+            c = O.config_cli(O.R2P, 24, 24, 2, -1, 20)
+            a, b = O.topolar(c, ramp(0x9E3779B1, 24), ramp(0x85EBCA77, 24))
+        else:
+            c = O.config_cli(O.P2R, 32, 32, 2, 32, 16)
+            ph = ((idx << np.uint64(2)) & np.uint64(0xffffffff)).astype(np.uint32)
+            a, b = O.rotate(c, ramp(0x9E3779B1, 32), ramp(0x85EBCA77, 32), ph)
+    want = (cpu_digest(a, 0) + cpu_digest(b, 1 << 40)) % 2 ** 64
+    assert int(d["digest"], 16) == want, (d["digest"], "%016x" % want)
+    if "single_process_cordic_group" in d:
+        sp = d["single_process_cordic_group"]
+        assert "error" not in sp, sp
