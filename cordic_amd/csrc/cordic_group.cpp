@@ -77,6 +77,10 @@ constexpr int kPlaceSpareMax = 6;	// ... and at most, while no good pair shows
 // a pair of written arrays is good enough at 0.88 of the 8 TB/s peak (single
 // arrays sweep at 0.88-0.89, good pairs reach 0.90)
 constexpr double kPlaceGoodBytesPerMs = 0.88 * 8e9;
+// the 1R2W pattern of a constant-vector rotator: 0.845 is what a well placed
+// triple reaches (0.85-0.86 at best)
+constexpr double kPlaceGoodMixBytesPerMs = 0.845 * 8e9;
+constexpr int kPlaceReadExtra = 6;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
 struct Rccl {
@@ -375,6 +379,38 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		}
 		if (failed) { (void)hipGetLastError(); return finish(true); }
 		take(&reads[0], bi);
+		// Which array is READ matters most in a mixed stream (profiles/r03/
+		// hbm_vmm_probe.txt: rotating the roles over one triple gives 0.72 /
+		// 0.86 / 0.86).  While the job's full pattern stays under 0.845 of the
+		// peak, try up to kPlaceReadExtra fresh allocations in the read role,
+		// one at a time (a 4 GiB hipMalloc + three launches each), keeping
+		// only a better one.
+		const float good_mix = (float)((double)words * 12.0 / kPlaceGoodMixBytesPerMs);
+		for (int extra = 0; extra < kPlaceReadExtra && best > good_mix
+				&& room_for_spare(); extra++) {
+			void *cand = nullptr;
+			if (!ok(hipMalloc(&cand, bytes))) {
+				(void)hipGetLastError();
+				break;
+			}
+			ps.candidates++;
+			const float ms = probe_ms(st, 1, 2, cand, nullptr, writes[0], writes[1],
+					words, queue);
+			if (ms < 0.f) {
+				(void)hipGetLastError();
+				(void)hipFree(cand);
+				break;
+			}
+			ps.probes++;
+			if (ms > worst) worst = ms;
+			if (ms < best) {
+				best = ms;
+				pool.push_back(reads[0]);	// the old one is freed with the rest
+				reads[0] = cand;
+			} else {
+				(void)hipFree(cand);
+			}
+		}
 	} else {
 		for (size_t i = 0; i < pool.size() && !failed; i++)
 			for (size_t j = i + 1; j < pool.size() && !failed; j++) {

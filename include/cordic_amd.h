@@ -536,6 +536,10 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
  * therefore allocates two more than it needs, times an arithmetic-free twin of
  * the job's traffic over the candidate role assignments (tens of
  * milliseconds, once per allocation), keeps the fastest and frees the rest.
+ * While no pair of written arrays reaches 0.88 of the peak it tries up to four
+ * more candidates, and while a 1R2W job's full pattern stays under 0.845 up to
+ * six more in the READ role (the array that is read decides most), one at a
+ * time; spares are taken only while as much memory again stays free.
  * On by default; cordic_group_set_placement(grp, 0) before the first
  * reserve / job call, or CORDIC_GROUP_PLACEMENT=0 in the environment, takes
  * the arrays as hipMalloc hands them out.  cordic_group_placement reports
