@@ -1211,7 +1211,7 @@ def time_gather(args, grp, step, launch, dist, dev, devices, n, n_total, rank,
     grp.set_gather_rccl(-1)
     d = grp.digest(n_total)
     t = torch.tensor([d - (1 << 64) if d >= 1 << 63 else d],
-                     dtype=torch.int64, device=dev)
+                     dtype=torch.int64, device=coll_device(dev))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     ok = None
     if rank == 0:

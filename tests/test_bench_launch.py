@@ -338,3 +338,34 @@ def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
     if "single_process_cordic_group" in d:
         sp = d["single_process_cordic_group"]
         assert "error" not in sp, sp
+
+
+@pytest.mark.gpu
+def test_bench_gather_over_the_cpp_rccl_path_with_two_ranks():
+    """`bench.py --gpus 2 --gather` as TWO processes sharing the GPU: the
+    group's own RCCL forwarding (cordic_group_rccl_init / _set_gather_rccl,
+    id broadcast through the process group) runs over tests/rccl_shim, rank 1
+    really sends, rank 0 really receives, and what arrives has the digest of
+    the whole job."""
+    shim = os.path.join(ROOT, "tests", "rccl_shim", "librccl_shim.so")
+    if not os.path.exists(shim):
+        pytest.skip("RCCL shim not built")
+    e = dict(os.environ, BENCH_TEST_SHARE_GPU="1", CORDIC_RCCL_LIB=shim,
+             HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "2",
+           "--workload", "cfg4", "--gather", "--steps", "4", "--warmup", "1",
+           "--log2-samples", "20", "--no-cpu-baseline", "--no-other-paths",
+           "--no-pmc", "--no-power", "--no-copy-probe",
+           "--no-single-process-check"]
+    r = subprocess.run(cmd, env=e, text=True, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    g = d["gather"]
+    assert "set_gather_rccl" in g["mode"]
+    assert g["outputs_identical"] is True and g["ms_compute_and_gather"] > 0
+    assert d["n_gpus"] == 2 and d["bit_exact_vs_oracle"] is True
