@@ -360,7 +360,8 @@ def measure_pmc(args):
             str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
             "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
-                     ("--static-chunks", args.static_chunks)):
+                     ("--static-chunks", args.static_chunks),
+                     ("--no-tails", args.no_tails)):
         if on:
             base.append(flag)
     vals = {}
@@ -757,6 +758,8 @@ def run_group(args, w, launch):
         cfg = cfg.with_flags(ca.FLAG_NO_SEED)
     if args.static_chunks:
         cfg = cfg.with_flags(ca.FLAG_STATIC_CHUNKS)
+    if args.no_tails:
+        cfg = cfg.with_flags(ca.FLAG_NO_TAILS)
 
     dist = None
     rank, world, local = 0, 1, 0
@@ -1534,6 +1537,9 @@ def main():
     ap.add_argument("--static-chunks", action="store_true",
                     help="seeded kernel: one contiguous chunk per persistent "
                     "block instead of the address-ordered tile queue (A/B)")
+    ap.add_argument("--no-tails", action="store_true",
+                    help="seeded kernel: phase recurrence behind the seeds "
+                    "instead of the direction-tail lookups (A/B)")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
     args = ap.parse_args()

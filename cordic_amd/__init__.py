@@ -14,7 +14,7 @@ Reference interfaces mirrored (see include/cordic_amd.h for file:line):
 """
 from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
-    FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_STATIC_CHUNKS,
+    FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_NO_TAILS, FLAG_STATIC_CHUNKS,
     FLAG_UNIT_GAIN,
     ERR_ARGS, ERR_DEVICE, ERR_CONTAINER,
     Config, CordicError, Plan, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED,

@@ -9,6 +9,7 @@ FLAG_NO_LJ = 0x4
 FLAG_NO_SEED = 0x8
 FLAG_STATIC_CHUNKS = 0x20
 FLAG_UNIT_GAIN = 0x10
+FLAG_NO_TAILS = 0x40
 # enum cordic_status (the codes tests assert on)
 ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9
 
@@ -915,7 +916,7 @@ def last_kernel():
 def seed_table(cfg):
     """Host-side seed table words of a core (numpy uint32) or None."""
     import numpy as np
-    cap = 4 + 4096 * 6
+    cap = 4 + 4096 * 6 + 4 + 4 * (6 + 2 * 4096 + 2 * 64)
     buf = np.zeros(cap, dtype=np.uint32)
     n = lib().cordic_seed_table(cfg.ref, buf.ctypes.data_as(_u32p), cap)
     return buf[:n].copy() if n else None

@@ -149,6 +149,7 @@ struct cordic_plan {
 	cordic_config cfg;
 	uint32_t *d_table = nullptr;	// device copy of the seed table
 	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
+	DtInfo dt;			// direction tails behind the seeds (dt.n == 0: none)
 	QueueRing queues;
 };
 
@@ -166,8 +167,10 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 	if (!p)
 		return CORDIC_ERR_NOMEM;
 	p->cfg = *cfg;
-	std::vector<uint32_t> words(4 + 4096 * 4 + 4096 * 2);
-	const size_t nw = build_seed_table(*cfg, CORDIC_SEED_STAGES, words.data(), words.size());
+	std::vector<uint32_t> words(4 + 4096 * 4 + 4096 * 2
+			+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 64));
+	const size_t nw = build_seed_table(*cfg, CORDIC_SEED_STAGES, words.data(),
+			words.size(), &p->dt);
 	if (nw) {
 		if (hipMalloc((void **)&p->d_table, nw * 4) != hipSuccess ||
 		    hipMemcpy(p->d_table, words.data(), nw * 4,
@@ -220,6 +223,7 @@ static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 	j.seed_S = plan->S;
 	j.seed_nbuckets = plan->nbuckets;
 	j.seed_nleaves = plan->nleaves;
+	j.dt = plan->dt;
 }
 
 // launch with a tile queue no other launch in flight is using
@@ -849,7 +853,8 @@ size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_wor
 	if (!cfg)
 		return 0;
 	if (!buf || cap_words == 0) {
-		std::vector<uint32_t> tmp(4 + 4096 * 4 + 4096 * 2);
+		std::vector<uint32_t> tmp(4 + 4096 * 4 + 4096 * 2
+				+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 64));
 		return build_seed_table(*cfg, CORDIC_SEED_STAGES, tmp.data(), tmp.size());
 	}
 	return build_seed_table(*cfg, CORDIC_SEED_STAGES, buf, cap_words);

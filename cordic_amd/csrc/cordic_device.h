@@ -352,6 +352,22 @@ __device__ __forceinline__ void rot_stage_lj(int64_t &x, int64_t &y, int64_t &p,
 	op_mad_s(p, a_scaled, ns);
 }
 
+// The same stage with its multipliers handed in (direction tails of the seeded
+// kernel: -s 2^LJ and s 2^LJ come out of a table indexed by the residual
+// phase, there is no phase to update): two shifts and two multiply-adds.
+template <int LJ, int K>
+__device__ __forceinline__ void rot_stage_lj_dir(int64_t &x, int64_t &y, int32_t ns,
+		int32_t s)
+{
+	static_assert(K >= LjConst<LJ>::first, "early stages carry low-word bits");
+	constexpr int sh = (K - LjConst<LJ>::first > 31) ? 31
+						: K - LjConst<LJ>::first;
+	const int32_t sy = (int32_t)((uint64_t)y >> 32) >> sh;
+	const int32_t sx = (int32_t)((uint64_t)x >> 32) >> sh;
+	op_mad(x, sy, ns);
+	op_mad(y, sx, s);
+}
+
 // The first 31-LJ stages (k < 32-LJ) on the same left-justified pairs:
 // (y >>> k) no longer fits the high word alone,
 //     y >>> k = hi(y~) * 2^D + r,   D = 32-LJ-k,   r = the top D bits of lo(y~),
@@ -813,7 +829,28 @@ struct SeedArgs {
 	// Tile queue: kQueueCounters zeroed counters, kQueueStride words apart
 	// (one cache line each), or NULL for the static chunk-per-block sweep.
 	uint32_t *queue;
+	// direction tails behind the seeds (cordic_internal.h: DtInfo; the words
+	// they refer to follow the seed table in `table`)
+	DtInfo	dt;
 };
+
+// LDS of the direction tails of a seeded kernel: per group its buckets
+// (8 bytes each, aligned to their total size so that the bucket address is
+// (index & mask) | base) and its 64-byte leaf entries.  `at` = first free byte
+// behind the seeds and the tile-id slots; returns the new end.
+__host__ __device__ inline uint32_t dt_lds_layout(const DtInfo &dt, uint32_t at,
+		uint32_t *bucket_base, uint32_t *leaf_base)
+{
+	for (int g = 0; g < dt.n; g++) {
+		const uint32_t bb = (uint32_t)dt.lv[g].nb * 8u;
+		at = (at + bb - 1u) & ~(bb - 1u);
+		if (bucket_base) bucket_base[g] = at;
+		at += bb;
+		if (leaf_base) leaf_base[g] = at;
+		at += (uint32_t)dt.lv[g].nl * (uint32_t)dt_entry_dwords(dt.lv[g].t) * 4u;
+	}
+	return at;
+}
 
 constexpr int kQueueCounters = 8;	// one per XCD
 constexpr int kQueueStride = 64;	// words between counters
@@ -895,7 +932,7 @@ __device__ __forceinline__ void for_each_queued_tile(uint32_t *queue,
 
 
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
-		typename IO = Io32, bool UG = false>
+		typename IO = Io32, bool UG = false, bool DT = false>
 __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		SeedArgs sa, const typename IO::uvec *__restrict__ phin,
 		typename IO::ivec *__restrict__ ox,
@@ -971,6 +1008,49 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			d[3] = 0;
 		}
 	}
+	// Direction tails (cordic_internal.h: dt_levels; cordic_plan.cpp): per
+	// group of stages behind the seeds a bucket table over the biased
+	// residual u and leaf entries {ns_0, s_0, ns_1, s_1, ... (the multipliers
+	// -/+ s_j 2^LJ of the group's stages), off'} with u_next = u - off'
+	// (cordic_internal.h: dt_pairs, dt_entry_dwords).
+	constexpr int kDtR = NLIVE - M;
+	constexpr int kDtN = DT ? dt_levels(kDtR) : 0;
+	uint32_t dt_bk[kDtMaxLevels] = {}, dt_lf[kDtMaxLevels] = {};
+	if constexpr (DT) {
+		static_assert(C::lj != 0 && !DYN && !UG, "direction tails: static LJ instances");
+		static_assert(kDtN >= 1 && kDtN <= kDtMaxLevels, "no group to look up");
+		dt_lds_layout(sa.dt, seed_base + 4u * (uint32_t)L * 16u + 16u, dt_bk, dt_lf);
+#pragma unroll
+		for (int g = 0; g < kDtN; g++) {
+			const DtLevel lv = sa.dt.lv[g];
+			const uint32_t *src = sa.table + lv.word;
+			uint32_t *bk = lds + dt_bk[g] / 4u;
+			for (int i = threadIdx.x; i < lv.nb * 2; i += kSeedBlock) {
+				const uint32_t w = src[i];
+				bk[i] = (i & 1) ? dt_lf[g] + w * (uint32_t)dt_entry_dwords(lv.t) * 4u : w;
+			}
+			const uint32_t *lsrc = src + (size_t)lv.nb * 2;
+			uint32_t *lf = lds + dt_lf[g] / 4u;
+			for (int e = threadIdx.x; e < lv.nl; e += kSeedBlock) {
+				const uint32_t pat = lsrc[2 * e];
+				uint32_t *d = lf + (size_t)e * dt_entry_dwords(lv.t);
+				const int np = dt_pairs(lv.t);
+				for (int jj = 0; jj < lv.t; jj++) {
+					// bit set: residual >= 0 at that stage, s = +1
+					const bool pos = (pat >> (lv.t - 1 - jj)) & 1u;
+					const uint32_t plus = LjConst<C::lj>::bit;
+					const uint32_t minus = LjConst<C::lj>::mask | plus;
+					if (jj < np) {
+						d[2 * jj + 0] = pos ? minus : plus;	// -s 2^LJ (x)
+						d[2 * jj + 1] = pos ? plus : minus;	//  s 2^LJ (y)
+					} else {
+						d[np + jj] = pos ? plus : minus;
+					}
+				}
+				d[lv.t + np] = lsrc[2 * e + 1];
+			}
+		}
+	}
 	__syncthreads();
 
 	LjRegs ljc{};
@@ -978,6 +1058,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		ljc.mask = vgpr_const(LjConst<C::lj>::mask);
 		ljc.bit = vgpr_const(LjConst<C::lj>::bit);
 		ljc.maskbit = vgpr_const(LjConst<C::lj>::mask | LjConst<C::lj>::bit);
+	}
+	uint32_t dt_maskv[kDtMaxLevels] = {};
+	if constexpr (DT) {
+#pragma unroll
+		for (int g = 0; g < kDtN; g++)
+			dt_maskv[g] = vgpr_const(((uint32_t)sa.dt.lv[g].nb - 1u) << 3);
 	}
 	const uint32_t k45 = vgpr_const(0x20000000u);	// 45 degrees (VOP3 has no literal)
 	const uint32_t bshift = (uint32_t)sa.S - 3;	// bucket -> byte offset
@@ -989,6 +1075,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	// VALU instruction per read).  Checked once per wave.
 	typedef const __attribute__((address_space(3))) u32x4 lds_entry;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+	typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 	typedef const __attribute__((address_space(3))) u32x2 lds_bucket;
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
 		__builtin_trap();
@@ -1022,9 +1109,27 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
 		}
 	};
+	// Direction tails trade VALU instructions for LDS reads (a bucket and up
+	// to 44 bytes of multipliers per group and sample).  Where the lanes of a
+	// wave read the SAME entries -- a phase ramp, an NCO with a small
+	// increment: what the benches feed -- those reads are broadcasts and
+	// nearly free; on unrelated phases they collide on the LDS banks and the
+	// lookup loses to the recurrence (-22 % on the pseudo-random NCO of cfg5,
+	// profiles/r03/ab_tails.txt).  So each wave decides per row: first and
+	// last phase of the row less than 2^16 apart -> tails, else the phase
+	// recurrence (two lane reads and a scalar compare; a row of unrelated
+	// phases passes by chance once in 2^15).
+	auto row_is_coherent = [](const uint32_t (&pb)[kVec]) -> bool {
+		const uint32_t pf = __builtin_amdgcn_readfirstlane(pb[0]);
+		const uint32_t pl = __builtin_amdgcn_readlane(pb[kVec - 1], 63);
+		return (pl - pf + 0x10000u) < 0x20000u;
+	};
 	// One row: 4 samples per lane with their folded phases in pb; results in
 	// rx / ry (the caller stores them).
-	auto pass_pb = [&](const uint32_t (&pb)[kVec], i32x4 &rx, i32x4 &ry) {
+	auto pass_pb = [&](auto TAILS_, const uint32_t (&pb)[kVec], i32x4 &rx, i32x4 &ry) {
+		// (two instantiations: with the direction tails or with the phase
+		// recurrence behind the seeds -- decided per row by the caller)
+		constexpr bool kTails = DT && decltype(TAILS_)::value;
 		// three passes so that the four bucket reads, then the four seed
 		// reads, are in flight together (one s_waitcnt each, not eight).
 		// Per sample: lshl_add, lshr, lshr, and | sub, bfe, lshl_add,
@@ -1052,6 +1157,117 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				: "v"(q[v]), "s"(qstride), "v"(a));
 			se[v] = *(lds_entry *)(uintptr_t)a;
 		}
+		if constexpr (kTails) {
+			// ---- the stages behind the seeds take their multipliers from
+			// tables indexed by the biased residual u = p_M + bias0 >= 0
+			constexpr int LJ = C::lj;
+			uint32_t u[kVec];
+#pragma unroll
+			for (int v = 0; v < kVec; v++) {
+				x[v] = (int64_t)(((uint64_t)se[v][1] << 32) | se[v][0]);
+				y[v] = (int64_t)(((uint64_t)se[v][3] << 32) | se[v][2]);
+				asm("v_bfe_u32 %0, %1, 0, 29" : "=v"(u[v])
+					: "v"(pb[v] - se[v][0] + sa.dt.bias0));
+			}
+			// one group: bucket read, compare, entry read, T stages of 4
+			// instructions; per sample lshr, and_or | sub, lshr, lshl_add
+			// (| sub for the next group's u) = 5-6 VALU instructions
+			auto group = [&](auto G_) {
+				constexpr int G = decltype(G_)::value;
+				constexpr int T = dt_size(kDtR, G);
+				constexpr int K0 = M + dt_first(kDtR, G);	// stages done
+				constexpr bool more = (G + 1 < kDtN) || dt_rest(kDtR) > 0;
+				const uint32_t sh3 = (uint32_t)sa.dt.lv[G].shift - 3u;
+				u32x2 b2[kVec];
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					uint32_t a;
+					asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a)
+						: "v"(u[v] >> sh3), "v"(dt_maskv[G]), "s"(dt_bk[G]));
+					b2[v] = *(lds_bucket *)(uintptr_t)a;
+				}
+				constexpr int P = dt_pairs(T);
+				constexpr int W = T + P + (more ? 1 : 0);	// dwords used
+				constexpr int kStride = dt_entry_dwords(T) * 4;
+				uint32_t ea[kVec];
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					const uint32_t c = (b2[v][0] - u[v]) >> 31;	// u >= bound
+					if constexpr ((kStride & (kStride - 1)) == 0)
+						asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(ea[v])
+							: "v"(c), "n"(__builtin_ctz(kStride)), "v"(b2[v][1]));
+					else
+						asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ea[v])
+							: "v"(c), "n"(kStride), "v"(b2[v][1]));
+				}
+				uint32_t en[kVec][16];
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+#pragma unroll
+					for (int at = 0; at < W; at += 4) {
+						// only the dwords that are used: the LDS returns
+						// 128 bytes a cycle to the CU whatever the lanes
+						// ask for
+						if (W - at >= 4) {
+							const u32x4 t4 = *(lds_entry *)(uintptr_t)(ea[v] + 4u * at);
+							en[v][at] = t4[0]; en[v][at + 1] = t4[1];
+							en[v][at + 2] = t4[2]; en[v][at + 3] = t4[3];
+						} else if (W - at == 3) {
+							const u32x3 t3 = *(const __attribute__((address_space(3)))
+								u32x3 *)(uintptr_t)(ea[v] + 4u * at);
+							en[v][at] = t3[0]; en[v][at + 1] = t3[1];
+							en[v][at + 2] = t3[2];
+						} else if (W - at == 2) {
+							const u32x2 t2 = *(lds_bucket *)(uintptr_t)(ea[v] + 4u * at);
+							en[v][at] = t2[0]; en[v][at + 1] = t2[1];
+						} else {
+							en[v][at] = *(const __attribute__((address_space(3)))
+								uint32_t *)(uintptr_t)(ea[v] + 4u * at);
+						}
+					}
+				}
+				auto stage = [&](auto J_) {
+					constexpr int J = decltype(J_)::value;
+					if constexpr (J < T) {
+#pragma unroll
+						for (int v = 0; v < kVec; v++) {
+							if constexpr (J < P)
+								rot_stage_lj_dir<LJ, K0 + J + 1>(x[v], y[v],
+									(int32_t)en[v][2 * J], (int32_t)en[v][2 * J + 1]);
+							else
+								rot_stage_lj_dir<LJ, K0 + J + 1>(x[v], y[v],
+									-(int32_t)en[v][P + J], (int32_t)en[v][P + J]);
+						}
+					}
+				};
+				stage(std::integral_constant<int, 0>{});
+				stage(std::integral_constant<int, 1>{});
+				stage(std::integral_constant<int, 2>{});
+				stage(std::integral_constant<int, 3>{});
+				stage(std::integral_constant<int, 4>{});
+				stage(std::integral_constant<int, 5>{});
+				if constexpr (more) {
+#pragma unroll
+					for (int v = 0; v < kVec; v++)
+						u[v] -= en[v][T + P];
+				}
+			};
+			if constexpr (kDtN > 0) group(std::integral_constant<int, 0>{});
+			if constexpr (kDtN > 1) group(std::integral_constant<int, 1>{});
+			if constexpr (kDtN > 2) group(std::integral_constant<int, 2>{});
+			if constexpr (kDtN > 3) group(std::integral_constant<int, 3>{});
+			constexpr int kRest = dt_rest(kDtR);
+			if constexpr (kRest > 0) {
+				// the last stages on the residual phase itself
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					const int32_t r = (int32_t)(u[v] - sa.dt.bias_last);
+					p[v] = (int64_t)(((uint64_t)(uint32_t)(r >> 1) << 32)
+							| ((uint32_t)r << 31));
+				}
+				RotChainLJ<LJ, NLIVE, NLIVE - kRest, false>::run(x, y, p, kp, ljc);
+			}
+		} else {
 #pragma unroll
 		for (int v = 0; v < kVec; v++) {
 			if constexpr (C::lj != 0) {
@@ -1072,6 +1288,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					(int32_t)(pb[v] - se[v][2]), 0, 30);
 			}
 		}
+		}
 
 		if constexpr (C::lj == 0) {
 			RotChain<C, NLIVE, 0, M, DYN>::run(x, y, p, kp);
@@ -1083,7 +1300,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		} else {
 			constexpr int LJ = C::lj;
 			static_assert(M >= C::ngen, "seed must cover the general stages");
-			RotChainLJ<LJ, NLIVE, M, DYN>::run(x, y, p, kp, ljc);
+			if constexpr (!kTails)
+				RotChainLJ<LJ, NLIVE, M, DYN>::run(x, y, p, kp, ljc);
 			if (kp.r_lj == 32) {
 #pragma unroll
 				for (int v = 0; v < kVec; v++) {
@@ -1230,7 +1448,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					const size_t base = (size_t)cur * kTileVecs
 							+ (size_t)s * kSeedBlock;
 					i32x4 rx, ry;
-					pass_pb(pb[s], rx, ry);
+					if (DT && row_is_coherent(pb[s]))
+						pass_pb(std::true_type{}, pb[s], rx, ry);
+					else
+						pass_pb(std::false_type{}, pb[s], rx, ry);
 					// non-temporal loads AND stores: with the address-
 					// ordered queue they are worth +3 % on cfg2 together
 					// (0.80 -> 0.82 of the HBM peak, either one alone +1 %;
@@ -1294,7 +1515,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		i32x4 rx, ry;
 		uint32_t pb[kVec];
 		fold_pb(g, 0u, tph, pb);
-		pass_pb(pb, rx, ry);
+		if (DT && row_is_coherent(pb))
+			pass_pb(std::true_type{}, pb, rx, ry);
+		else
+			pass_pb(std::false_type{}, pb, rx, ry);
 		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
 		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	}

@@ -140,9 +140,29 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			j.n / kVec);
 		return true;
 	}
+	// Direction tails pay where the lanes of a wave read the same table
+	// entries.  A phase ARRAY is judged by the kernel itself, wave by wave; an
+	// NCO's phases are known here: a row of 64 lanes x 4 samples spans
+	// 256 increments, which has to stay under the 2^16 the kernel's own test
+	// allows -- otherwise the plain instance runs, without that test.
+	bool tails_pay = true;
+	if (FEED == Feed::Nco_ConstXY) {
+		const int32_t f = (int32_t)kp.fcw;	// left-justified increment
+		tails_pay = (f < 0 ? -(int64_t)f : (int64_t)f) < 256;
+	}
 	switch (nlive) {
+	// static instances; where the plan carries direction tails for the
+	// stages behind the seeds (left-justified cores with 3 or more of them),
+	// the instance that looks their multipliers up
 #define X(N) case N: { \
 	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
+	if constexpr (CORDIC_INST_CONTAINER::lj != 0 \
+			&& dt_levels(N - kSeedStages) >= 1 \
+			&& dt_levels(N - kSeedStages) <= kDtMaxLevels) { \
+		if (sa.dt.n == dt_levels(N - kSeedStages) && tails_pay) \
+			kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, \
+					FEED, false, Io32, false, true>; \
+	} \
 	if (!seeded_kernel_usable((const void *)kern, lds_bytes)) \
 		return false; \
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp, sa, \

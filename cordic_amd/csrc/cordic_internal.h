@@ -63,9 +63,84 @@ int	quad_write_header(const cordic_quad_config *q, const char *name,
 #define CORDIC_SEED_BLOCK 1024
 #endif
 
+// "Direction tails" behind the seed table (round 3).  The rotation directions
+// of the stages AFTER the seeded ones depend only on the residual phase, again
+// as a monotone step function with exact integer break points -- so they can
+// be looked up too: a small second table per group of `t` stages, indexed by
+// the residual, hands the kernel the stage multipliers (no phase recurrence,
+// no multiplier extraction: 4 instead of 7 VALU instructions per stage, ~6 per
+// lookup).  The schedule -- how the R = NLIVE - M remaining stages are cut
+// into groups -- is fixed here for host and device alike: groups of 5 while
+// more than 6 remain, then one group of 3..6; fewer than 3 run the ordinary
+// stages on the residual phase.  A lookup is not free (a bucket and up to 44
+// bytes of LDS per sample and group, in a kernel at the socket's power cap):
+// cores with fewer than kDtMinStages stages behind the seeds keep the
+// recurrence.  Measured (profiles/r03/ab_tails.txt): 13 stages behind, cfg4,
+// +7.8 %; 5 stages behind, cfg2 / the slow NCO, +0.4 % / 0 on ramps and -0.9 %
+// on unrelated phases -- not worth a second instance of those kernels.
+constexpr int kDtMaxLevels = 4;
+#ifndef CORDIC_DT_MIN_STAGES
+#define CORDIC_DT_MIN_STAGES 9
+#endif
+constexpr int kDtMinStages = CORDIC_DT_MIN_STAGES;
+constexpr int dt_levels(int r)
+{
+	int n = 0;
+	if (r < kDtMinStages) return 0;
+	while (r >= 3) { r -= (r <= 6) ? r : 5; n++; }
+	return n;
+}
+constexpr int dt_size(int r, int level)		// stages of group `level`
+{
+	int t = 0;
+	for (int n = 0; n <= level && r >= 3; n++) { t = (r <= 6) ? r : 5; r -= t; }
+	return t;
+}
+constexpr int dt_first(int r, int level)	// stages before group `level`
+{
+	int done = 0;
+	for (int n = 0; n < level && r >= 3; n++) { const int t = (r <= 6) ? r : 5; r -= t; done += t; }
+	return done;
+}
+constexpr int dt_rest(int r)			// stages left to the phase chain
+{
+	while (r >= 3) r -= (r <= 6) ? r : 5;
+	return r;
+}
+// LDS entry of one leaf of a group of t stages (built by the kernel's prologue
+// from the table's {pattern, off'} pairs): the multipliers {-s_j, s_j} 2^LJ of
+// the first dt_pairs(t) stages as pairs, s_j 2^LJ alone for the others (the
+// kernel negates it: one more instruction, four bytes less to read), then
+// off'.  The lookup is bounded by the LDS's return bandwidth as much as by the
+// instruction issue (a 16-byte read costs the CU 8 cycles whether or not the
+// lanes agree on the address), so the entry is as many bytes as are used, read
+// with b128/b96/b64/b32 as they fit, 16-byte aligned.
+#ifndef CORDIC_DT_SINGLES
+#define CORDIC_DT_SINGLES 0
+#endif
+constexpr int dt_pairs(int t) { return t > CORDIC_DT_SINGLES ? t - CORDIC_DT_SINGLES : 0; }
+constexpr int dt_entry_dwords(int t) { return (t + dt_pairs(t) + 1 + 3) & ~3; }
+// Host-side description of one group (also what the kernel gets as arguments)
+struct DtLevel {
+	int32_t	t;		// stages in the group
+	int32_t	shift;		// bucket = u >> shift   (u = biased residual)
+	int32_t	nb;		// buckets (a power of two)
+	int32_t	nl;		// leaves
+	int32_t	word;		// offset of the group's buckets in the table words
+};
+struct DtInfo {
+	int32_t	n = 0;			// groups (0: the core has no direction tails)
+	uint32_t bias0 = 0;		// bias of the seed stage's residual
+	uint32_t bias_last = 0;		// bias of the residual behind the last group
+	DtLevel	lv[kDtMaxLevels] = {};
+};
+
 // ---- host: cordic_plan.cpp
 bool	seed_eligible(const cordic_config &c, int m);
-size_t	build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap);
+// `dt` (may be NULL) receives the direction tails appended behind the seed
+// table's words; the returned length includes them.
+size_t	build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap,
+		DtInfo *dt = nullptr);
 
 // ---- device launchers: cordic_kernels.hip
 extern thread_local int g_last_kernel;	// enum cordic_kernel_family
@@ -91,6 +166,7 @@ struct RotatorJob {
 	// optional seed table (cordic_plan): device words + their host header
 	const uint32_t *seed_table = nullptr;
 	int seed_m = 0, seed_S = 0, seed_nbuckets = 0, seed_nleaves = 0;
+	DtInfo	dt;			// direction tails of the plan (dt.n == 0: none)
 	// tile queue of the seeded kernel: CORDIC_QUEUE_BYTES of zeroed device
 	// memory that no other launch in flight uses (the kernel leaves it zeroed
 	// again: cordic_device.h queue_leave); NULL = static chunk-per-block sweep

@@ -548,10 +548,14 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			uint32_t *queue = (cfg.flags & CORDIC_FLAG_STATIC_CHUNKS)
 					? nullptr : j.queue;
 			SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets,
-					j.seed_nleaves, queue};
-			// buckets, seeds and the three tile-id slots of the queue
-			const size_t lds = (size_t)j.seed_nbuckets * 8
-					+ (size_t)j.seed_nleaves * 4 * 16 + 16;
+					j.seed_nleaves, queue, j.dt};
+			if (cfg.flags & CORDIC_FLAG_NO_TAILS)
+				sa.dt.n = 0;	// A/B: phase recurrence behind the seeds
+			// buckets, seeds, the three tile-id slots of the queue and the
+			// direction tails
+			const size_t lds = dt_lds_layout(sa.dt,
+					(uint32_t)((size_t)j.seed_nbuckets * 8
+					+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr);
 			// blocks per CU: 32 waves and 160 KiB of LDS to share
 			int per_cu = 32 / (kSeedBlock / 64);
 			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));

@@ -67,8 +67,11 @@ bool seed_eligible(const cordic_config &c, int m)
 
 // Returns the number of words written (0 if the table cannot be built within
 // `cap` words or the bucket constraint cannot be met).
-size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap)
+size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap,
+		DtInfo *dt)
 {
+	if (dt)
+		*dt = DtInfo{};
 	if (!seed_eligible(c, m))
 		return 0;
 	const int lsh = 32 - c.pw;
@@ -152,7 +155,126 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 		lf[2 * k + 0] = leaves[k].pattern;
 		lf[2 * k + 1] = (uint32_t)(leaves[k].off - LO);	// off + 2^29
 	}
-	return words;
+
+	// ---- direction tails (cordic_internal.h: dt_levels): groups of stages
+	// behind the seeded ones, each with its own bucket / leaf table over the
+	// residual phase.  Appended as
+	//   [words] n, bias0, bias_last, 0
+	//   per group: t, shift, nb, nl, 0, 0, then nb x {bound-1, first_leaf}
+	//   (u-domain: u = residual + bias of the incoming residual; 0x7fffffff:
+	//   no boundary), then nl x {pattern (t bits, first stage = MSB),
+	//   off'} with  u_next = u - off'  (the next group's -- or, behind the
+	//   last one, the phase chain's -- biased residual).
+	const int R = c.nlive - m;
+	const int ngroups = dt_levels(R);
+	if (ngroups == 0 || ngroups > kDtMaxLevels || c.ww < 33)
+		return words;		// (left-justified kernels only, for now)
+	std::vector<uint32_t> tail;
+	DtInfo info;
+	// residual range behind the seed stages
+	int64_t rmin = 0, rmax = 0;
+	bool first = true;
+	for (const Leaf &l : leaves) {
+		const int64_t a = l.lo - l.off, b = l.hi - 1 - l.off;
+		if (first || a < rmin) rmin = a;
+		if (first || b > rmax) rmax = b;
+		first = false;
+	}
+	int64_t bias = -rmin;
+	info.bias0 = (uint32_t)bias;
+	tail.assign(4, 0u);
+	size_t lds_extra = 0;
+	for (int g = 0; g < ngroups; g++) {
+		const int t = dt_size(R, g), s0 = m + dt_first(R, g);
+		uint32_t a2[8];
+		for (int i = 0; i < t; i++)
+			a2[i] = c.angle[s0 + i] << lsh;
+		std::vector<Leaf> lv;
+		split(a2, t, 0, rmin, rmax + 1, 0, 0u, lv);
+		std::sort(lv.begin(), lv.end(),
+			[](const Leaf &a, const Leaf &b) { return a.lo < b.lo; });
+		const size_t nl = lv.size();
+		if (nl == 0 || nl > 64)
+			return words;
+		const int64_t umax = rmax + bias;		// u in [0, umax]
+		if (umax >= ((int64_t)1 << 28))
+			return words;
+		// largest bucket with at most one boundary (not on its edge)
+		int S2 = 24;
+		std::vector<int> cnt;
+		for (; S2 >= 4; S2--) {
+			cnt.assign((size_t)(umax >> S2) + 1, 0);
+			int worst = 0;
+			for (size_t j = 1; j < nl; j++) {
+				const int64_t u = lv[j].lo + bias;
+				if (u & (((int64_t)1 << S2) - 1))
+					worst = std::max(worst, ++cnt[(size_t)(u >> S2)]);
+			}
+			if (worst <= 1)
+				break;
+		}
+		if (S2 < 4)
+			return words;
+		size_t nb2 = 1;
+		while (nb2 < (size_t)(umax >> S2) + 1)
+			nb2 <<= 1;
+		if (nb2 > 4096)
+			return words;
+		DtLevel &d = info.lv[g];
+		d.t = t; d.shift = S2; d.nb = (int32_t)nb2; d.nl = (int32_t)nl;
+		d.word = (int32_t)(words + tail.size() + 6);
+		const uint32_t hdr[6] = {(uint32_t)t, (uint32_t)S2, (uint32_t)nb2,
+				(uint32_t)nl, 0u, 0u};
+		tail.insert(tail.end(), hdr, hdr + 6);
+		const size_t b0 = tail.size();
+		tail.resize(b0 + nb2 * 2);
+		size_t j = 0;
+		for (size_t b = 0; b < nb2; b++) {
+			const int64_t start = ((int64_t)b << S2) - bias;	// residual
+			while (j + 1 < nl && lv[j + 1].lo <= start)
+				j++;
+			tail[b0 + 2 * b + 0] = 0x7fffffffu;
+			tail[b0 + 2 * b + 1] = (uint32_t)j;
+		}
+		for (size_t k = 1; k < nl; k++) {
+			const int64_t u = lv[k].lo + bias;
+			if ((u & (((int64_t)1 << S2) - 1)) == 0)
+				continue;
+			tail[b0 + 2 * (size_t)(u >> S2)] = (uint32_t)(u - 1);
+		}
+		// residual range behind this group, and its bias
+		int64_t nmin = 0, nmax = 0;
+		first = true;
+		for (const Leaf &l : lv) {
+			const int64_t a = l.lo - l.off, b = l.hi - 1 - l.off;
+			if (first || a < nmin) nmin = a;
+			if (first || b > nmax) nmax = b;
+			first = false;
+		}
+		const int64_t nbias = -nmin;
+		for (const Leaf &l : lv) {
+			tail.push_back(l.pattern);
+			// u_next = (r - off) + nbias = u - (off + bias - nbias)
+			tail.push_back((uint32_t)(l.off + bias - nbias));
+		}
+		// LDS the kernel needs for it: buckets (aligned to their own size)
+		// + the kernel's leaf entries (dt_entry_dwords: at most 64 bytes)
+		lds_extra += 2 * nb2 * 8 + nl * (size_t)dt_entry_dwords(t) * 4;
+		rmin = nmin; rmax = nmax; bias = nbias;
+	}
+	info.n = ngroups;
+	info.bias_last = (uint32_t)bias;
+	tail[0] = (uint32_t)ngroups;
+	tail[1] = info.bias0;
+	tail[2] = info.bias_last;
+	if (nb * 8 + L * 64 + 64 + lds_extra > CORDIC_SEED_LDS_BYTES)
+		return words;			// no room: seeds only
+	if (words + tail.size() > cap)
+		return words;
+	std::memcpy(buf + words, tail.data(), tail.size() * 4);
+	if (dt)
+		*dt = info;
+	return words + tail.size();
 }
 
 } // namespace cordic_amd

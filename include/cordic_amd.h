@@ -94,6 +94,10 @@ enum cordic_status {
 						   cordic_config_gain_annihilator */
 #define CORDIC_FLAG_NO_SEED		0x8u	/* plans: full recurrence, no
 						   seed table (for A/B)         */
+#define CORDIC_FLAG_NO_TAILS		0x40u	/* plans: seed table only; the
+						   stages behind it run the phase
+						   recurrence instead of looking
+						   their directions up (for A/B) */
 #define CORDIC_FLAG_STATIC_CHUNKS	0x20u	/* plans: one contiguous chunk
 						   per persistent block instead
 						   of the address-ordered tile

@@ -1006,3 +1006,66 @@ def test_one_plan_launched_from_four_host_threads():
         assert np.array_equal(to_np(j["a"]), j["want"][0])
         assert np.array_equal(to_np(j["b"]), j["want"][1])
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 20),
+                                  (ca.P2R, 32, 32, 2, 32, 24),
+                                  (ca.SP2R, 32, 32, 2, 32, 22),
+                                  (ca.P2R, 31, 31, 2, 30, 21),
+                                  (ca.P2R, 32, 32, 2, 32, 26)])
+def test_direction_tails_on_every_group_boundary(args):
+    """The stages behind the seeds take their multipliers from tables
+    indexed by the residual phase (direction tails) wherever a wave's row of
+    256 phases is coherent (first and last less than 2^16 apart), and run the
+    phase recurrence elsewhere.  (a) Unit-step ramps of 2^21 phases from
+    random starts in every quadrant: coherent rows that put the residual on
+    EVERY integer of several seed leaves, hence on every boundary of every
+    group; (b) 256-sample blocks around each boundary of the first group for
+    a spread of seed leaves; (c) unrelated phases (the recurrence path of the
+    same kernel); (d) the same batch with CORDIC_FLAG_NO_TAILS; (e) an NCO
+    with a small increment (tails) and a large one (plain instance).  All
+    equal the oracle."""
+    from test_seed_table import parse, parse_tails
+    cfg, ocfg = both(*args)
+    words = ca.seed_table(cfg)
+    m, S, nb, L, buckets, leaves = parse(words)
+    tails = parse_tails(words)
+    assert tails is not None
+    plan = ca.Plan(cfg)
+    assert plan.seed_info["stages"] == 11
+    lsh = 32 - cfg.pw
+    step = 1 << lsh                     # one LSB of the PW-bit phase, P units
+    rng = np.random.RandomState(5)
+    parts = []
+    for q in range(4):                  # (a)
+        start = int(rng.randint(0, 1 << 30)) + (q << 30)
+        parts.append((start + step * np.arange(1 << 21, dtype=np.int64)) & 0xffffffff)
+    g0 = tails["groups"][0]             # (b)
+    b0 = g0["buckets"]
+    bounds = b0[b0[:, 0] != 0x7fffffff, 0] + 1 - tails["bias0"]    # residuals
+    blk = step * (np.arange(256, dtype=np.int64) - 128)
+    for j in rng.choice(L, size=min(L, 24), replace=False):
+        off = int(leaves[j, 1]) - (1 << 29)
+        for b in bounds:
+            base = (off + int(b)) // step * step
+            parts.append((base + blk + (int(rng.randint(4)) << 30)) & 0xffffffff)
+    parts.append(rng.randint(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.int64))  # (c)
+    ph = (np.concatenate(parts).astype(np.uint64) >> np.uint64(lsh)).astype(np.uint32)
+    ph = ph[: ph.size - ph.size % 4]
+    x0 = (1 << (cfg.iw - 1)) - 1
+    want = O.rotate(ocfg, x0, -(x0 // 3), ph)
+    got = gpu_plan_p2r(plan, x0, -(x0 // 3), ph)
+    assert ca.last_kernel() == ca.KERNEL_SEEDED
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_TAILS))   # (d)
+    got = gpu_plan_p2r(plain, x0, -(x0 // 3), ph)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    for fcw in (1, 3, 0x01234567 >> lsh):               # (e)
+        a, b = gpu_plan_nco(plan, 1 << 21, 0x1234, fcw, 77, x0, 0)
+        idx = (np.arange(1 << 21, dtype=np.uint64) + np.uint64(77))
+        pn = ((np.uint64(0x1234) + idx * np.uint64(fcw))
+              & np.uint64((1 << cfg.pw) - 1)).astype(np.uint32)
+        wa, wb = O.rotate(ocfg, x0, 0, pn)
+        assert np.array_equal(a, wa) and np.array_equal(b, wb), fcw
+    plan.close(); plain.close()

@@ -95,3 +95,116 @@ def test_degenerate_angle_tables_are_not_seeded():
     assert ca.seed_table(cfg) is None
     # while ordinary cores of the same width are
     assert ca.seed_table(ca.Config.from_cli(ca.SP2R, 9, 31, 3, 24, 33)) is not None
+
+
+# ------------------------------------------------------- direction tails
+
+def parse_tails(words):
+    """the groups appended behind the seed table (cordic_plan.cpp)"""
+    m, S, nb, L, buckets, leaves = parse(words)
+    at = 4 + nb * 2 + L * 2
+    if at >= len(words):
+        return None
+    n, bias0, bias_last = int(words[at]), int(words[at + 1]), int(words[at + 2])
+    at += 4
+    groups = []
+    for _ in range(n):
+        t, S2, nb2, nl2 = (int(v) for v in words[at:at + 4])
+        at += 6
+        bk = words[at:at + nb2 * 2].reshape(nb2, 2).astype(np.int64)
+        at += nb2 * 2
+        lf = words[at:at + nl2 * 2].reshape(nl2, 2).astype(np.int64)
+        at += nl2 * 2
+        groups.append(dict(t=t, S=S2, nb=nb2, nl=nl2, buckets=bk, leaves=lf))
+    assert at == len(words)
+    return dict(bias0=bias0, bias_last=bias_last, groups=groups)
+
+
+def schedule(r):
+    out = []
+    if r < 9:
+        return out, r
+    while r >= 3:
+        t = r if r <= 6 else 5
+        out.append(t)
+        r -= t
+    return out, r
+
+
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 21),
+                                  (ca.P2R, 32, 32, 2, 32, 24),
+                                  (ca.SP2R, 32, 32, 2, 32, 22),
+                                  (ca.P2R, 32, 32, 2, 32, 26),
+                                  (ca.P2R, 32, 32, 2, 32, 20),
+                                  (ca.P2R, 31, 31, 2, 30, 21),
+                                  (ca.P2R, 30, 30, 3, 32, 23)])
+def test_direction_tails_match_the_recurrence(args):
+    """Behind the seed stages the directions of each group of stages, looked
+    up by the biased residual (bucket + one compare), are the directions the
+    exact phase recurrence takes, and the residual handed on is exact -- for
+    random phases and for every group boundary +-2."""
+    cfg = ca.Config.from_cli(*args)
+    words = ca.seed_table(cfg)
+    m, S, nb, L, buckets, leaves = parse(words)
+    tails = parse_tails(words)
+    sizes, rest = schedule(cfg.nlive - m)
+    assert tails is not None and [g["t"] for g in tails["groups"]] == sizes
+    ang = [a << (32 - cfg.pw) for a in cfg.angles]
+    rng = np.random.RandomState(7)
+    r = rng.randint(0, 1 << 30, 300000).astype(np.int64)
+
+    def first_level(r):
+        j = buckets[r >> S, 1] + (buckets[r >> S, 0] - r < 0)
+        off = leaves[j, 1] - (1 << 29)          # stored modulo 2^32
+        d = ((r - (1 << 29)) - off) & 0xffffffff
+        return np.where(d >= 1 << 31, d - (1 << 32), d)   # residual behind the seeds
+
+    res = first_level(r)
+    # plus residuals around every boundary of every group: walk the groups
+    # once with the random set to learn the biases, then add +-2 around each
+    # bound of each group, mapped back to the FIRST residual is not needed --
+    # each group is checked on its own incoming residual below
+    u = res + tails["bias0"]
+    assert u.min() >= 0 and u.max() < (1 << 28)
+    k0 = m
+    incoming = res.copy()
+    for g in tails["groups"]:
+        bk, lf, t = g["buckets"], g["leaves"], g["t"]
+        bounds = bk[bk[:, 0] != 0x7fffffff, 0] + 1
+        extra = np.concatenate([bounds + d for d in (-2, -1, 0, 1, 2)])
+        extra = extra[(extra >= 0) & (extra <= u.max())]
+        u = np.concatenate([u, extra])
+        # the residual those u stand for (bias of this group's input)
+        bias_in = u[0] - incoming[0]
+        incoming = u - bias_in
+        b = u >> g["S"]
+        assert b.max() < g["nb"]
+        j = bk[b, 1] + (bk[b, 0] - u < 0)
+        assert j.max() < g["nl"]
+        pat, after = recurrence(incoming, ang[k0:k0 + t], t)
+        assert np.array_equal(lf[j, 0], pat)
+        u = u - lf[j, 1]
+        # u is now the next group's (or the chain's) biased residual
+        assert np.array_equal(u - u[0], after - after[0])
+        incoming = after
+        k0 += t
+    assert np.array_equal(u - tails["bias_last"], incoming)
+    assert k0 + rest == cfg.nlive
+
+
+def test_cores_without_room_or_need_have_no_tails():
+    # fewer than three stages behind the seeds: nothing to look up
+    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 16, 16, 2, 16, 16))   # 13 live
+    assert parse_tails(w) is None
+    # fewer than nine: a lookup costs more than the stages save (measured)
+    for ns in (16, 18, 19):
+        w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns))
+        assert parse_tails(w) is None, ns
+    assert parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 20)))
+    # the last stages of a 29-stage core move the phase by 1..5 units: their
+    # leaves are narrower than the smallest bucket, so no tails at all
+    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30))
+    assert parse_tails(w) is None
+    # WW <= 32 cores keep the phase recurrence (narrow kernels)
+    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1))
+    assert parse_tails(w) is None

@@ -37,6 +37,13 @@ for t in range(ncfg):
     ocfg = O.config_cli(mode, iw, ow, xtra, pw, ns)
     n = int(rng.choice([1, 3, 4, 5, 257, 1024, 4099, 8192, 12293, 65541]))
     x, y, ph = rand_inputs(rng, iw, pw, n)
+    if rng.randint(2):
+        # slow ramps: the rows on which the seeded kernel takes its stage
+        # multipliers from the direction tails instead of the recurrence
+        h = n // 2
+        ramp = int(rng.randint(1 << pw)) + int(rng.choice([1, 2, 3, 17])) * np.arange(n - h)
+        ph = ph.copy()
+        ph[h:] = (ramp & ((1 << pw) - 1)).astype(ph.dtype)
     key = (mode, "wrap" if cfg.needs_wrap else ("wide" if cfg.ww > 35 else
            "lj" if cfg.ww > 32 else "narrow"))
     paths[key] = paths.get(key, 0) + 1
@@ -58,6 +65,8 @@ for t in range(ncfg):
                                            a[1][bad[0]], b[0][bad[0]],
                                            b[1][bad[0]], bad.size))
         fcw, p0, i0 = int(rng.randint(1 << 32)), int(rng.randint(1 << 32)), int(rng.randint(1 << 40))
+        if rng.randint(2):
+            fcw = int(rng.choice([1, 2, 5, (1 << pw) - 3])) & 0xffffffff   # slow NCO: tails
         a = gpu_plan_nco(plan, n, p0, fcw, i0, x0, y0)
         b = O.nco(ocfg, n, p0 & 0xffffffff, fcw, i0, x0, y0)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (t, "nco")
