@@ -1171,7 +1171,11 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			}
 			// one group: bucket read, compare, entry read, T stages of 4
 			// instructions; per sample lshr, and_or | sub, lshr, lshl_add
-			// (| sub for the next group's u) = 5-6 VALU instructions
+			// (| sub for the next group's u) = 5-6 VALU instructions.
+			// (The reads of a group depend on each other and on the group
+			// before; pipelining them by hand across the groups, with
+			// scheduling fences, measured 1.6 % SLOWER -- the four waves per
+			// SIMD cover the latency; profiles/r03/ab_tails.txt, form 7.)
 			auto group = [&](auto G_) {
 				constexpr int G = decltype(G_)::value;
 				constexpr int T = dt_size(kDtR, G);
