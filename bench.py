@@ -1542,7 +1542,14 @@ def main():
                     "instead of the direction-tail lookups (A/B)")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
+    ap.add_argument("--nstages", type=int, default=0,
+                    help="experiments: the workload's core with this many stages "
+                    "(gencordic -n); the line's config says so")
     args = ap.parse_args()
+    if args.nstages:
+        w0 = WORKLOADS[args.workload]
+        w0["cli"] = tuple(w0["cli"][:5]) + (args.nstages,)
+        w0["desc"] += " [--nstages %d]" % args.nstages
     if args.no_placement:
         # read by cordic_group_create / cordic_arrays_alloc (and inherited by
         # the ranks and sub-runs this process starts)

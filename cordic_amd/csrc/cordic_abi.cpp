@@ -168,7 +168,7 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		return CORDIC_ERR_NOMEM;
 	p->cfg = *cfg;
 	std::vector<uint32_t> words(4 + 4096 * 4 + 4096 * 2
-			+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 64));
+			+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 256));
 	const size_t nw = build_seed_table(*cfg, CORDIC_SEED_STAGES, words.data(),
 			words.size(), &p->dt);
 	if (nw) {
@@ -854,7 +854,7 @@ size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_wor
 		return 0;
 	if (!buf || cap_words == 0) {
 		std::vector<uint32_t> tmp(4 + 4096 * 4 + 4096 * 2
-				+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 64));
+				+ 4 + kDtMaxLevels * (6 + 2 * 4096 + 2 * 256));
 		return build_seed_table(*cfg, CORDIC_SEED_STAGES, tmp.data(), tmp.size());
 	}
 	return build_seed_table(*cfg, CORDIC_SEED_STAGES, buf, cap_words);

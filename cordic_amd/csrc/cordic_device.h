@@ -1250,6 +1250,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				stage(std::integral_constant<int, 3>{});
 				stage(std::integral_constant<int, 4>{});
 				stage(std::integral_constant<int, 5>{});
+				stage(std::integral_constant<int, 6>{});
 				if constexpr (more) {
 #pragma unroll
 					for (int v = 0; v < kVec; v++)

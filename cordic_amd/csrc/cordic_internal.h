@@ -70,42 +70,40 @@ int	quad_write_header(const cordic_quad_config *q, const char *name,
 // the residual, hands the kernel the stage multipliers (no phase recurrence,
 // no multiplier extraction: 4 instead of 7 VALU instructions per stage, ~6 per
 // lookup).  The schedule -- how the R = NLIVE - M remaining stages are cut
-// into groups -- is fixed here for host and device alike: groups of 5 while
-// more than 6 remain, then one group of 3..6; fewer than 3 run the ordinary
-// stages on the residual phase.  A lookup is not free (a bucket and up to 44
-// bytes of LDS per sample and group, in a kernel at the socket's power cap):
-// cores with fewer than kDtMinStages stages behind the seeds keep the
-// recurrence.  Measured (profiles/r03/ab_tails.txt): 13 stages behind, cfg4,
-// +7.8 %; 5 stages behind, cfg2 / the slow NCO, +0.4 % / 0 on ramps and -0.9 %
-// on unrelated phases -- not worth a second instance of those kernels.
+// into groups -- is fixed here for host and device alike: as few groups as
+// hold at most seven stages each (a 64-byte entry), of equal size with the
+// longer ones last.  A lookup is not free -- a bucket and up to 60 bytes of
+// LDS per sample and group, and the LDS returns 128 bytes a cycle per CU
+// whether or not the lanes agree on the address -- so fewer, longer groups
+// win: 13 stages as 6+7 run 4 % faster than as 5+5+3, those 5 % faster than
+// as 3+3+3+4 (profiles/r03/ab_tails.txt).  Measured gains on a phase ramp by
+// stages behind the seeds: 7 (one group) +10 %, 9 +7 %, 11 +9 %, 13 +12 %;
+// 5 (cfg2, the slow NCO) 0 to +0.4 % against -0.9 % on unrelated phases for
+// the row test: cores with fewer than kDtMinStages keep the recurrence.
 constexpr int kDtMaxLevels = 4;
 #ifndef CORDIC_DT_MIN_STAGES
-#define CORDIC_DT_MIN_STAGES 9
+#define CORDIC_DT_MIN_STAGES 7
 #endif
 constexpr int kDtMinStages = CORDIC_DT_MIN_STAGES;
+constexpr int kDtMaxT = 7;		// stages per group at most (entry: 15 dwords)
 constexpr int dt_levels(int r)
 {
-	int n = 0;
-	if (r < kDtMinStages) return 0;
-	while (r >= 3) { r -= (r <= 6) ? r : 5; n++; }
-	return n;
+	return r < kDtMinStages ? 0 : (r + kDtMaxT - 1) / kDtMaxT;
 }
 constexpr int dt_size(int r, int level)		// stages of group `level`
 {
-	int t = 0;
-	for (int n = 0; n <= level && r >= 3; n++) { t = (r <= 6) ? r : 5; r -= t; }
-	return t;
+	const int n = dt_levels(r);
+	return n == 0 ? 0 : r / n + (level >= n - r % n ? 1 : 0);
 }
 constexpr int dt_first(int r, int level)	// stages before group `level`
 {
 	int done = 0;
-	for (int n = 0; n < level && r >= 3; n++) { const int t = (r <= 6) ? r : 5; r -= t; done += t; }
+	for (int g = 0; g < level; g++) done += dt_size(r, g);
 	return done;
 }
 constexpr int dt_rest(int r)			// stages left to the phase chain
 {
-	while (r >= 3) r -= (r <= 6) ? r : 5;
-	return r;
+	return dt_levels(r) == 0 ? r : 0;
 }
 // LDS entry of one leaf of a group of t stages (built by the kernel's prologue
 // from the table's {pattern, off'} pairs): the multipliers {-s_j, s_j} 2^LJ of

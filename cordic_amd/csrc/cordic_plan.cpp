@@ -194,7 +194,7 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 		std::sort(lv.begin(), lv.end(),
 			[](const Leaf &a, const Leaf &b) { return a.lo < b.lo; });
 		const size_t nl = lv.size();
-		if (nl == 0 || nl > 64)
+		if (nl == 0 || nl > 256)
 			return words;
 		const int64_t umax = rmax + bias;		// u in [0, umax]
 		if (umax >= ((int64_t)1 << 28))

@@ -121,17 +121,16 @@ def parse_tails(words):
 
 
 def schedule(r):
-    out = []
-    if r < 9:
-        return out, r
-    while r >= 3:
-        t = r if r <= 6 else 5
-        out.append(t)
-        r -= t
-    return out, r
+    """cordic_internal.h: dt_levels / dt_size -- the fewest groups of at most
+    seven stages, equal sizes, the longer ones last; none under seven stages."""
+    if r < 7:
+        return [], r
+    n = (r + 6) // 7
+    return [r // n + (1 if g >= n - r % n else 0) for g in range(n)], 0
 
 
-@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 21),
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
+                                  (ca.P2R, 32, 32, 2, 32, 21),
                                   (ca.P2R, 32, 32, 2, 32, 24),
                                   (ca.SP2R, 32, 32, 2, 32, 22),
                                   (ca.P2R, 32, 32, 2, 32, 26),
@@ -196,11 +195,11 @@ def test_cores_without_room_or_need_have_no_tails():
     # fewer than three stages behind the seeds: nothing to look up
     w = ca.seed_table(ca.Config.from_cli(ca.P2R, 16, 16, 2, 16, 16))   # 13 live
     assert parse_tails(w) is None
-    # fewer than nine: a lookup costs more than the stages save (measured)
-    for ns in (16, 18, 19):
+    # fewer than seven: a lookup costs what the stages save (measured)
+    for ns in (14, 16, 17):
         w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns))
         assert parse_tails(w) is None, ns
-    assert parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 20)))
+    assert parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 18)))
     # the last stages of a 29-stage core move the phase by 1..5 units: their
     # leaves are narrower than the smallest bucket, so no tails at all
     w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30))

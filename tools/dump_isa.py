@@ -29,7 +29,7 @@ KERNELS = [
     ("rotator_seeded_lj29_24", "cordic_inst_seed_lj29.o",
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true>",
      "cfg4: seeded p2r, 24 stages (13 after the seed: direction tails in groups of "
-     "5, 5, 3 on coherent rows, phase recurrence on the others)"),
+     "6 and 7 on coherent rows, phase recurrence on the others)"),
     ("rotator_seeded_lj29_24_notails", "cordic_inst_seed_lj29.o",
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, false>",
      "cfg4 with the phase recurrence only (CORDIC_FLAG_NO_TAILS)"),
