@@ -1175,7 +1175,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			// (The reads of a group depend on each other and on the group
 			// before; pipelining them by hand across the groups, with
 			// scheduling fences, measured 1.6 % SLOWER -- the four waves per
-			// SIMD cover the latency; profiles/r03/ab_tails.txt, form 7.)
+			// SIMD cover the latency; profiles/r03/ab_tails.txt, form 7.
+			// Multipliers in SGPRs for rows that sit on ONE entry: at most
+			// +4 % before the cost of the exact test, form 11: not built.)
 			auto group = [&](auto G_) {
 				constexpr int G = decltype(G_)::value;
 				constexpr int T = dt_size(kDtR, G);

@@ -152,7 +152,7 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	}
 	switch (nlive) {
 	// static instances; where the plan carries direction tails for the
-	// stages behind the seeds (left-justified cores with 3 or more of them),
+	// stages behind the seeds (left-justified cores with kDtMinStages or more of them),
 	// the instance that looks their multipliers up
 #define X(N) case N: { \
 	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
