@@ -539,6 +539,16 @@ def finish_power(sampler, step, sync, t0, elapsed, steps, samples_per_step):
         power["sustained"]["steps"] = more
         power["sustained"]["msamples_per_s_local_shards"] = (
             samples_per_step * more / (t2 - t1) / 1e6)
+        # At the cap the clock is whatever the power budget allows: a kernel
+        # that stalls less then runs at a lower clock, and what raises the
+        # rate is less ENERGY per sample (fewer / cheaper instructions, fewer
+        # LDS and HBM bytes), not fewer stalls.
+        w = power["sustained"].get("socket_w_median")
+        if w and power["limit_w"]:
+            power["at_cap"] = bool(w >= 0.985 * power["limit_w"])
+            if samples_per_step:
+                power["nj_per_sample"] = (
+                    w / (power["sustained"]["msamples_per_s_local_shards"] * 1e6) * 1e9)
     return power
 
 
