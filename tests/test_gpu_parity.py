@@ -626,20 +626,18 @@ def _digest2(a, b, index0=0):
     return (gpu_digest(a, index0) + gpu_digest(b, index0 + (1 << 40))) % 2**64
 
 
-def test_full_size_cfg2_checksum_of_checksums_and_spot_check():
-    """2^30 samples (BASELINE config 2): one launch vs 64 launches of 2^24
-    with the shard's global index -- digests must add up -- plus a strided
-    subset and both ends against the oracle."""
-    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+def _full_size_p2r(nstages, shift):
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, nstages)
     n = 1 << 30
     x0 = 2**31 - 1
     phase = torch.empty(n, dtype=torch.int32, device=DEV)
     a = torch.empty(n, dtype=torch.int32, device=DEV)
     b = torch.empty(n, dtype=torch.int32, device=DEV)
-    ca.fill_phase_ramp(phase, 0, 2)
+    ca.fill_phase_ramp(phase, 0, shift)
     plan = ca.Plan(cfg)
     plan.p2r_const(x0, 0, phase, a, b)
     torch.cuda.synchronize()
+    assert ca.last_kernel() == ca.KERNEL_SEEDED
     whole = _digest2(a, b)
     # same work as 64 shards through the full-recurrence kernel
     plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
@@ -655,14 +653,33 @@ def test_full_size_cfg2_checksum_of_checksums_and_spot_check():
     idx = np.unique(np.concatenate([np.arange(4096), np.arange(n - 4096, n),
                                     np.arange(0, n, 65521)])).astype(np.int64)
     ti = torch.from_numpy(idx).to(DEV)
-    rx, ry = O.rotate(ocfg, x0, 0, ((idx << 2) & 0xffffffff).astype(np.uint32))
+    rx, ry = O.rotate(ocfg, x0, 0, ((idx << shift) & 0xffffffff).astype(np.uint32))
     assert np.array_equal(a[ti].cpu().numpy(), rx)
     assert np.array_equal(b[ti].cpu().numpy(), ry)
-    # linearity in the index: the NCO with fcw = 4 regenerates the same ramp
+    # linearity in the index: the NCO with fcw = 2^shift regenerates the same ramp
     a.zero_(); b.zero_()
-    plan.nco(n, 0, 4, 0, x0, 0, a, b)
+    plan.nco(n, 0, 1 << shift, 0, x0, 0, a, b)
     torch.cuda.synchronize()
     assert _digest2(a, b) == whole
+    # and the seeds with the phase recurrence behind them (no direction tails)
+    a.zero_(); b.zero_()
+    ca.Plan(cfg.with_flags(ca.FLAG_NO_TAILS)).p2r_const(x0, 0, phase, a, b)
+    torch.cuda.synchronize()
+    assert _digest2(a, b) == whole
+
+
+def test_full_size_cfg2_checksum_of_checksums_and_spot_check():
+    """2^30 samples (BASELINE config 2): one launch vs 64 launches of 2^24
+    with the shard's global index -- digests must add up -- plus a strided
+    subset and both ends against the oracle."""
+    _full_size_p2r(16, 2)
+
+
+def test_full_size_cfg4_direction_tails_checksum_of_checksums_and_spot_check():
+    """The same for one GPU's share of BASELINE config 4 (24 stages, phase =
+    index): the seeded kernel with its direction tails (array feed and NCO
+    instance) against the full recurrence and the oracle."""
+    _full_size_p2r(24, 0)
 
 
 def test_full_size_cfg5_nco_4g_samples():
