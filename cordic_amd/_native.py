@@ -916,7 +916,7 @@ def last_kernel():
 def seed_table(cfg):
     """Host-side seed table words of a core (numpy uint32) or None."""
     import numpy as np
-    cap = 4 + 4096 * 6 + 4 + 4 * (6 + 2 * 4096 + 2 * 64)
+    cap = 4 + 4096 * 6 + 4 + 4 * (6 + 2 * 4096 + 2 * 256)
     buf = np.zeros(cap, dtype=np.uint32)
     n = lib().cordic_seed_table(cfg.ref, buf.ctypes.data_as(_u32p), cap)
     return buf[:n].copy() if n else None
