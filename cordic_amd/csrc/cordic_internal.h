@@ -86,14 +86,24 @@ constexpr int kDtMaxLevels = 4;
 #endif
 constexpr int kDtMinStages = CORDIC_DT_MIN_STAGES;
 constexpr int kDtMaxT = 7;		// stages per group at most (entry: 15 dwords)
+// Stage i turns the phase by ~2^32 / (2 pi 2^(i+1)) left-justified units
+// whatever PW is: behind stage 24 the leaves of a group get narrower than the
+// 16 units of the smallest bucket.  The tails stop there; later stages (the
+// 29-30 stage cores gencordic derives for 32-bit outputs) run the recurrence
+// on the residual the last group leaves.
+constexpr int kDtLastStage = 25;
+constexpr int dt_covered(int r)			// stages served by lookups
+{
+	return r < kDtLastStage - CORDIC_SEED_STAGES ? r : kDtLastStage - CORDIC_SEED_STAGES;
+}
 constexpr int dt_levels(int r)
 {
-	return r < kDtMinStages ? 0 : (r + kDtMaxT - 1) / kDtMaxT;
+	return r < kDtMinStages ? 0 : (dt_covered(r) + kDtMaxT - 1) / kDtMaxT;
 }
 constexpr int dt_size(int r, int level)		// stages of group `level`
 {
-	const int n = dt_levels(r);
-	return n == 0 ? 0 : r / n + (level >= n - r % n ? 1 : 0);
+	const int n = dt_levels(r), c = dt_covered(r);
+	return n == 0 ? 0 : c / n + (level >= n - c % n ? 1 : 0);
 }
 constexpr int dt_first(int r, int level)	// stages before group `level`
 {
@@ -103,7 +113,7 @@ constexpr int dt_first(int r, int level)	// stages before group `level`
 }
 constexpr int dt_rest(int r)			// stages left to the phase chain
 {
-	return dt_levels(r) == 0 ? r : 0;
+	return dt_levels(r) == 0 ? r : r - dt_covered(r);
 }
 // LDS entry of one leaf of a group of t stages (built by the kernel's prologue
 // from the table's {pattern, off'} pairs): the multipliers {-s_j, s_j} 2^LJ of

@@ -9,8 +9,14 @@
 
 // The unrolled instances that exist (number of live rotations).  Anything
 // else runs on the generic kernels (same results, lower throughput).
-#define CORDIC_ROT_STAGES(X) X(13) X(14) X(16) X(18) X(20) X(22) X(24) X(30)
-#define CORDIC_POL_STAGES(X) X(16) X(18) X(20) X(24) X(30)
+// (Round 3: every count from 13 / 16 to 29 -- gencordic's own derivation gives
+// odd counts, WW for p2r and PW-3 for r2p: 19 live stages for 16-bit sin/cos,
+// 27 for 24-bit, 29 for 32-bit and for 24-bit r2p -- and 29 is the most a
+// 32-bit phase leaves alive.)
+#define CORDIC_ROT_STAGES(X) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
+	X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29)
+#define CORDIC_POL_STAGES(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
+	X(25) X(26) X(27) X(28) X(29)
 
 namespace cordic_amd {
 

@@ -1027,6 +1027,10 @@ def test_one_plan_launched_from_four_host_threads():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
+                                  (ca.P2R, 32, 32, 2, 32, 30),
+                                  (ca.SP2R, 32, 32, 2, 32, -1),
+                                  (ca.P2R, 31, 31, 2, 30, 28),
+                                  (ca.P2R, 32, 32, 2, 32, 19),
                                   (ca.P2R, 32, 32, 2, 32, 20),
                                   (ca.P2R, 32, 32, 2, 32, 24),
                                   (ca.SP2R, 32, 32, 2, 32, 22),

@@ -121,15 +121,19 @@ def parse_tails(words):
 
 
 def schedule(r):
-    """cordic_internal.h: dt_levels / dt_size -- the fewest groups of at most
-    seven stages, equal sizes, the longer ones last; none under seven stages."""
+    """cordic_internal.h: dt_levels / dt_size -- stages 11..24 at most, in the
+    fewest groups of at most seven stages, equal sizes, the longer ones last;
+    none under seven stages; what is left runs the recurrence."""
     if r < 7:
         return [], r
-    n = (r + 6) // 7
-    return [r // n + (1 if g >= n - r % n else 0) for g in range(n)], 0
+    c = min(r, 25 - 11)
+    n = (c + 6) // 7
+    return [c // n + (1 if g >= n - c % n else 0) for g in range(n)], r - c
 
 
 @pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
+                                  (ca.P2R, 32, 32, 2, 32, 30),
+                                  (ca.SP2R, 32, 32, 2, 32, -1),
                                   (ca.P2R, 32, 32, 2, 32, 21),
                                   (ca.P2R, 32, 32, 2, 32, 24),
                                   (ca.SP2R, 32, 32, 2, 32, 22),
@@ -201,9 +205,9 @@ def test_cores_without_room_or_need_have_no_tails():
         assert parse_tails(w) is None, ns
     assert parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 18)))
     # the last stages of a 29-stage core move the phase by 1..5 units: their
-    # leaves are narrower than the smallest bucket, so no tails at all
-    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30))
-    assert parse_tails(w) is None
+    # leaves are narrower than the smallest bucket; the tails stop at stage 24
+    t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30)))
+    assert [g["t"] for g in t["groups"]] == [7, 7]
     # WW <= 32 cores keep the phase recurrence (narrow kernels)
     w = ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1))
     assert parse_tails(w) is None
