@@ -152,6 +152,19 @@ WORKLOADS = {
                       "ramp n"),
     "cfg3": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, 20), bytes=16,
                  desc="topolar 20-stage, 24-bit I/Q ramps -> mag + phase"),
+    # the cores gencordic derives when -p / -n are left to it (the ones that
+    # pass the reference's acceptance criteria)
+    "nat32": dict(kind="p2r", cli=("p2r", 32, 32, 2, 32, -1), bytes=12, shift=2,
+                  desc="gencordic -t p2r -i 32 -o 32 -p 32: 29 stages, phase "
+                  "ramp n<<2"),
+    "nat24": dict(kind="p2r", cli=("p2r", 24, 24, 2, -1, -1), bytes=12, shift=0,
+                  desc="gencordic -t p2r -i 24 -o 24: WW27 PW31, 27 stages, "
+                  "phase ramp n"),
+    "nat16": dict(kind="p2r", cli=("p2r", 16, 16, 2, -1, -1), bytes=12, shift=0,
+                  desc="gencordic -t p2r -i 16 -o 16: WW19 PW23, 19 stages, "
+                  "32-bit containers, phase ramp n"),
+    "natr2p24": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, -1), bytes=16,
+                     desc="gencordic -t r2p -i 24 -o 24: WW32 PW32, 29 stages"),
     "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
                  desc="fused NCO (phase = n*0x01234567) + 16-stage p2r, "
                  "store only"),
@@ -333,6 +346,8 @@ def from_profile(key, samples_per_launch=1 << 30):
 KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
              "cfg5": "rotator_seeded", "cfg5seq": "rotator_seeded",
              "cfg1": "rotator_seeded", "cfg3": "topolar_lj",
+             "nat32": "rotator_seeded", "nat24": "rotator_seeded",
+             "nat16": "rotator_seeded", "natr2p24": "topolar_lj",
              "p2rxy": "rotator_unrolled", "quadtbl": "quad_lookup",
              "quadtbl24": "quad_lookup", "sintbl": "table_lookup",
              "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup",
@@ -1555,7 +1570,13 @@ def main():
     ap.add_argument("--nstages", type=int, default=0,
                     help="experiments: the workload's core with this many stages "
                     "(gencordic -n); the line's config says so")
+    ap.add_argument("--ramp-shift", type=int, default=-1,
+                    help="experiments: phase ramp n << this (steeper ramps)")
     args = ap.parse_args()
+    if args.ramp_shift >= 0:
+        w0 = WORKLOADS[args.workload]
+        w0["shift"] = args.ramp_shift
+        w0["desc"] += " [--ramp-shift %d]" % args.ramp_shift
     if args.nstages:
         w0 = WORKLOADS[args.workload]
         w0["cli"] = tuple(w0["cli"][:5]) + (args.nstages,)

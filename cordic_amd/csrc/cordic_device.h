@@ -368,6 +368,17 @@ __device__ __forceinline__ void rot_stage_lj_dir(int64_t &x, int64_t &y, int32_t
 	op_mad(y, sx, s);
 }
 
+// ... and for the 32-bit container (WW <= 32: x and y in the low words,
+// multipliers -/+ 1)
+template <int K>
+__device__ __forceinline__ void rot_stage_dir32(int64_t &x, int64_t &y, int32_t ns,
+		int32_t s)
+{
+	const int32_t sy = asr_lo<K>(y), sx = asr_lo<K>(x);
+	op_mad(x, sy, ns);
+	op_mad(y, sx, s);
+}
+
 // The first 31-LJ stages (k < 32-LJ) on the same left-justified pairs:
 // (y >>> k) no longer fits the high word alone,
 //     y >>> k = hi(y~) * 2^D + r,   D = 32-LJ-k,   r = the top D bits of lo(y~),
@@ -1017,7 +1028,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	constexpr int kDtN = DT ? dt_levels(kDtR) : 0;
 	uint32_t dt_bk[kDtMaxLevels] = {}, dt_lf[kDtMaxLevels] = {};
 	if constexpr (DT) {
-		static_assert(C::lj != 0 && !DYN && !UG, "direction tails: static LJ instances");
+		static_assert((C::lj != 0 || !C::wide) && !DYN && !UG,
+			"direction tails: static left-justified or 32-bit instances");
 		static_assert(kDtN >= 1 && kDtN <= kDtMaxLevels, "no group to look up");
 		dt_lds_layout(sa.dt, seed_base + 4u * (uint32_t)L * 16u + 16u, dt_bk, dt_lf);
 #pragma unroll
@@ -1038,8 +1050,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				for (int jj = 0; jj < lv.t; jj++) {
 					// bit set: residual >= 0 at that stage, s = +1
 					const bool pos = (pat >> (lv.t - 1 - jj)) & 1u;
-					const uint32_t plus = LjConst<C::lj>::bit;
-					const uint32_t minus = LjConst<C::lj>::mask | plus;
+					// +/- 2^LJ (left-justified pairs) or +/- 1 (Narrow32)
+					const uint32_t plus = C::lj != 0 ? LjConst<C::lj>::bit : 1u;
+					const uint32_t minus = C::lj != 0
+						? (LjConst<C::lj>::mask | LjConst<C::lj>::bit) : 0xffffffffu;
 					if (jj < np) {
 						d[2 * jj + 0] = pos ? minus : plus;	// -s 2^LJ (x)
 						d[2 * jj + 1] = pos ? plus : minus;	//  s 2^LJ (y)
@@ -1110,19 +1124,20 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 	};
 	// Direction tails trade VALU instructions for LDS reads (a bucket and up
-	// to 44 bytes of multipliers per group and sample).  Where the lanes of a
-	// wave read the SAME entries -- a phase ramp, an NCO with a small
-	// increment: what the benches feed -- those reads are broadcasts and
-	// nearly free; on unrelated phases they collide on the LDS banks and the
-	// lookup loses to the recurrence (-22 % on the pseudo-random NCO of cfg5,
-	// profiles/r03/ab_tails.txt).  So each wave decides per row: first and
-	// last phase of the row less than 2^16 apart -> tails, else the phase
-	// recurrence (two lane reads and a scalar compare; a row of unrelated
-	// phases passes by chance once in 2^15).
+	// to 60 bytes of multipliers per group and sample).  Where the lanes of a
+	// wave read the same or neighbouring entries -- a phase ramp of any slope,
+	// an NCO with a small increment -- the reads spread over the banks; on
+	// unrelated phases the larger tables collide and the lookup loses a few
+	// per cent to the recurrence (cordic_internal.h: kDtCoherentLog2).  So each
+	// wave decides per row: first and last phase of the row less than 2^24
+	// apart -> tails, else the phase recurrence (two lane reads and a scalar
+	// compare; a row of unrelated phases passes by chance once in 2^7).
 	auto row_is_coherent = [](const uint32_t (&pb)[kVec]) -> bool {
 		const uint32_t pf = __builtin_amdgcn_readfirstlane(pb[0]);
 		const uint32_t pl = __builtin_amdgcn_readlane(pb[kVec - 1], 63);
-		return (pl - pf + 0x10000u) < 0x20000u;
+		if constexpr (kDtCoherentLog2 >= 31)
+			return true;		// (A/B builds: every row)
+		return (pl - pf + (1u << kDtCoherentLog2)) < (2u << kDtCoherentLog2);
 	};
 	// One row: 4 samples per lane with their folded phases in pb; results in
 	// rx / ry (the caller stores them).
@@ -1164,10 +1179,17 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			uint32_t u[kVec];
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {
-				x[v] = (int64_t)(((uint64_t)se[v][1] << 32) | se[v][0]);
-				y[v] = (int64_t)(((uint64_t)se[v][3] << 32) | se[v][2]);
-				asm("v_bfe_u32 %0, %1, 0, 29" : "=v"(u[v])
-					: "v"(pb[v] - se[v][0] + sa.dt.bias0));
+				if constexpr (C::lj != 0) {
+					x[v] = (int64_t)(((uint64_t)se[v][1] << 32) | se[v][0]);
+					y[v] = (int64_t)(((uint64_t)se[v][3] << 32) | se[v][2]);
+					asm("v_bfe_u32 %0, %1, 0, 29" : "=v"(u[v])
+						: "v"(pb[v] - se[v][0] + sa.dt.bias0));
+				} else {
+					x[v] = (int64_t)se[v][0];
+					y[v] = (int64_t)se[v][1];
+					asm("v_bfe_u32 %0, %1, 0, 30" : "=v"(u[v])
+						: "v"(pb[v] - se[v][2] + sa.dt.bias0));
+				}
 			}
 			// one group: bucket read, compare, entry read, T stages of 4
 			// instructions; per sample lshr, and_or | sub, lshr, lshl_add
@@ -1202,9 +1224,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					if constexpr ((kStride & (kStride - 1)) == 0)
 						asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(ea[v])
 							: "v"(c), "n"(__builtin_ctz(kStride)), "v"(b2[v][1]));
-					else
+					else if constexpr (kStride <= 64)
 						asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ea[v])
 							: "v"(c), "n"(kStride), "v"(b2[v][1]));
+					else		// (no inline constant above 64)
+						asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ea[v])
+							: "v"(c), "s"(kStride), "v"(b2[v][1]));
 				}
 				uint32_t en[kVec][16];
 #pragma unroll
@@ -1237,12 +1262,14 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					if constexpr (J < T) {
 #pragma unroll
 						for (int v = 0; v < kVec; v++) {
-							if constexpr (J < P)
-								rot_stage_lj_dir<LJ, K0 + J + 1>(x[v], y[v],
-									(int32_t)en[v][2 * J], (int32_t)en[v][2 * J + 1]);
+							const int32_t ns_ = (J < P) ? (int32_t)en[v][2 * J]
+									: -(int32_t)en[v][P + J];
+							const int32_t s_ = (J < P) ? (int32_t)en[v][2 * J + 1]
+									: (int32_t)en[v][P + J];
+							if constexpr (C::lj != 0)
+								rot_stage_lj_dir<LJ, K0 + J + 1>(x[v], y[v], ns_, s_);
 							else
-								rot_stage_lj_dir<LJ, K0 + J + 1>(x[v], y[v],
-									-(int32_t)en[v][P + J], (int32_t)en[v][P + J]);
+								rot_stage_dir32<K0 + J + 1>(x[v], y[v], ns_, s_);
 						}
 					}
 				};
@@ -1269,10 +1296,16 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 #pragma unroll
 				for (int v = 0; v < kVec; v++) {
 					const int32_t r = (int32_t)(u[v] - sa.dt.bias_last);
-					p[v] = (int64_t)(((uint64_t)(uint32_t)(r >> 1) << 32)
-							| ((uint32_t)r << 31));
+					if constexpr (C::lj != 0)
+						p[v] = (int64_t)(((uint64_t)(uint32_t)(r >> 1) << 32)
+								| ((uint32_t)r << 31));
+					else
+						p[v] = (int64_t)r;
 				}
-				RotChainLJ<LJ, NLIVE, NLIVE - kRest, false>::run(x, y, p, kp, ljc);
+				if constexpr (C::lj != 0)
+					RotChainLJ<LJ, NLIVE, NLIVE - kRest, false>::run(x, y, p, kp, ljc);
+				else
+					RotChain<C, NLIVE, 0, NLIVE - kRest, false>::run(x, y, p, kp);
 			}
 		} else {
 #pragma unroll
@@ -1298,7 +1331,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 
 		if constexpr (C::lj == 0) {
-			RotChain<C, NLIVE, 0, M, DYN>::run(x, y, p, kp);
+			if constexpr (!kTails)
+				RotChain<C, NLIVE, 0, M, DYN>::run(x, y, p, kp);
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {
 				rx[v] = round_to_ow<T>((T)x[v], kp);

@@ -140,15 +140,16 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 			j.n / kVec);
 		return true;
 	}
-	// Direction tails pay where the lanes of a wave read the same table
+	// Direction tails pay where the lanes of a wave read neighbouring table
 	// entries.  A phase ARRAY is judged by the kernel itself, wave by wave; an
 	// NCO's phases are known here: a row of 64 lanes x 4 samples spans
-	// 256 increments, which has to stay under the 2^16 the kernel's own test
-	// allows -- otherwise the plain instance runs, without that test.
+	// 256 increments, which has to stay under the 2^kDtCoherentLog2 the
+	// kernel's own test allows -- otherwise the plain instance runs, without
+	// that test.
 	bool tails_pay = true;
 	if (FEED == Feed::Nco_ConstXY) {
 		const int32_t f = (int32_t)kp.fcw;	// left-justified increment
-		tails_pay = (f < 0 ? -(int64_t)f : (int64_t)f) < 256;
+		tails_pay = (f < 0 ? -(int64_t)f : (int64_t)f) < ((int64_t)1 << (kDtCoherentLog2 - 8));
 	}
 	switch (nlive) {
 	// static instances; where the plan carries direction tails for the
@@ -156,7 +157,7 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	// the instance that looks their multipliers up
 #define X(N) case N: { \
 	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
-	if constexpr (CORDIC_INST_CONTAINER::lj != 0 \
+	if constexpr ((CORDIC_INST_CONTAINER::lj != 0 || !CORDIC_INST_CONTAINER::wide) \
 			&& dt_levels(N - kSeedStages) >= 1 \
 			&& dt_levels(N - kSeedStages) <= kDtMaxLevels) { \
 		if (sa.dt.n == dt_levels(N - kSeedStages) && tails_pay) \

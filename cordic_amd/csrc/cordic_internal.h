@@ -85,6 +85,18 @@ constexpr int kDtMaxLevels = 4;
 #define CORDIC_DT_MIN_STAGES 7
 #endif
 constexpr int kDtMinStages = CORDIC_DT_MIN_STAGES;
+// A row of 256 phases takes the tails when its first and last phase are less
+// than 2^kDtCoherentLog2 left-justified units apart.  With the entries spread
+// over the banks (dt_entry_dwords) a ramp of ANY slope gains or breaks even
+// (cfg4: +12 % at one unit per sample, +3...8 % at 2^7...2^11, 0 at 2^13 and
+// 2^16); only unrelated phases lose on the cores with 64-128 leaves per group
+// (cfg4 -5.6 %, the 29-stage core -8 %; smaller tables GAIN there too:
+// 19 stages +9 %, 23 stages +5 %), and a row of those passes the test once
+// in 2^7.  profiles/r03/ab_tails.txt, parts 13-15.
+#ifndef CORDIC_DT_COHERENT_LOG2
+#define CORDIC_DT_COHERENT_LOG2 24
+#endif
+constexpr int kDtCoherentLog2 = CORDIC_DT_COHERENT_LOG2;
 constexpr int kDtMaxT = 7;		// stages per group at most (entry: 15 dwords)
 // Stage i turns the phase by ~2^32 / (2 pi 2^(i+1)) left-justified units
 // whatever PW is: behind stage 24 the leaves of a group get narrower than the
@@ -127,7 +139,18 @@ constexpr int dt_rest(int r)			// stages left to the phase chain
 #define CORDIC_DT_SINGLES 0
 #endif
 constexpr int dt_pairs(int t) { return t > CORDIC_DT_SINGLES ? t - CORDIC_DT_SINGLES : 0; }
-constexpr int dt_entry_dwords(int t) { return (t + dt_pairs(t) + 1 + 3) & ~3; }
+#ifndef CORDIC_DT_STRIDE16
+#define CORDIC_DT_STRIDE16 20
+#endif
+constexpr int dt_entry_dwords(int t)
+{
+	// a 16-dword stride puts every entry of a 6- or 7-stage group on the
+	// same four bank groups: measured -29...-45 % on unrelated phases and
+	// -21 % on a ramp of 2^9 units per sample, where 20 dwords give -6...+5 %
+	// and +3 %
+	const int d = (t + dt_pairs(t) + 1 + 3) & ~3;
+	return d == 16 ? CORDIC_DT_STRIDE16 : d;
+}
 // Host-side description of one group (also what the kernel gets as arguments)
 struct DtLevel {
 	int32_t	t;		// stages in the group

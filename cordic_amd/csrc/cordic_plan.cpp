@@ -167,8 +167,8 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	//   last one, the phase chain's -- biased residual).
 	const int R = c.nlive - m;
 	const int ngroups = dt_levels(R);
-	if (ngroups == 0 || ngroups > kDtMaxLevels || c.ww < 33)
-		return words;		// (left-justified kernels only, for now)
+	if (ngroups == 0 || ngroups > kDtMaxLevels)
+		return words;
 	std::vector<uint32_t> tail;
 	DtInfo info;
 	// residual range behind the seed stages
@@ -183,7 +183,7 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	int64_t bias = -rmin;
 	info.bias0 = (uint32_t)bias;
 	tail.assign(4, 0u);
-	size_t lds_extra = 0;
+	size_t lds_at = nb * 8 + L * 64 + 16;	// behind the seeds and the tile slots
 	for (int g = 0; g < ngroups; g++) {
 		const int t = dt_size(R, g), s0 = m + dt_first(R, g);
 		uint32_t a2[8];
@@ -257,9 +257,10 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 			// u_next = (r - off) + nbias = u - (off + bias - nbias)
 			tail.push_back((uint32_t)(l.off + bias - nbias));
 		}
-		// LDS the kernel needs for it: buckets (aligned to their own size)
-		// + the kernel's leaf entries (dt_entry_dwords: at most 64 bytes)
-		lds_extra += 2 * nb2 * 8 + nl * (size_t)dt_entry_dwords(t) * 4;
+		// LDS the kernel needs for it (cordic_device.h: dt_lds_layout):
+		// buckets, aligned to their own size, then the leaf entries
+		lds_at = (lds_at + nb2 * 8 - 1) & ~(nb2 * 8 - 1);
+		lds_at += nb2 * 8 + nl * (size_t)dt_entry_dwords(t) * 4;
 		rmin = nmin; rmax = nmax; bias = nbias;
 	}
 	info.n = ngroups;
@@ -267,7 +268,7 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	tail[0] = (uint32_t)ngroups;
 	tail[1] = info.bias0;
 	tail[2] = info.bias_last;
-	if (nb * 8 + L * 64 + 64 + lds_extra > CORDIC_SEED_LDS_BYTES)
+	if (lds_at > CORDIC_SEED_LDS_BYTES)
 		return words;			// no room: seeds only
 	if (words + tail.size() > cap)
 		return words;

@@ -1031,6 +1031,9 @@ def test_one_plan_launched_from_four_host_threads():
                                   (ca.SP2R, 32, 32, 2, 32, -1),
                                   (ca.P2R, 31, 31, 2, 30, 28),
                                   (ca.P2R, 32, 32, 2, 32, 19),
+                                  (ca.P2R, 24, 24, 2, -1, -1),     # WW 27: 32-bit container
+                                  (ca.P2R, 16, 16, 2, -1, -1),     # WW 19, PW 23
+                                  (ca.SP2R, 20, 20, 2, -1, -1),
                                   (ca.P2R, 32, 32, 2, 32, 20),
                                   (ca.P2R, 32, 32, 2, 32, 24),
                                   (ca.SP2R, 32, 32, 2, 32, 22),

@@ -134,6 +134,8 @@ def schedule(r):
 @pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
                                   (ca.P2R, 32, 32, 2, 32, 30),
                                   (ca.SP2R, 32, 32, 2, 32, -1),
+                                  (ca.P2R, 24, 24, 2, -1, -1),
+                                  (ca.P2R, 16, 16, 2, -1, -1),
                                   (ca.P2R, 32, 32, 2, 32, 21),
                                   (ca.P2R, 32, 32, 2, 32, 24),
                                   (ca.SP2R, 32, 32, 2, 32, 22),
@@ -208,6 +210,8 @@ def test_cores_without_room_or_need_have_no_tails():
     # leaves are narrower than the smallest bucket; the tails stop at stage 24
     t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30)))
     assert [g["t"] for g in t["groups"]] == [7, 7]
-    # WW <= 32 cores keep the phase recurrence (narrow kernels)
-    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1))
+    # (WW <= 32 cores have tails like the wide ones: multipliers -/+ 1)
+    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1))   # 16 live
     assert parse_tails(w) is None
+    t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 16, 16, 2, -1, -1)))
+    assert [g["t"] for g in t["groups"]] == [4, 4]

@@ -68,7 +68,7 @@ d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['ro
 		done; done ;;
 	sweep)	# one bench.py line per workload x {ramp, random}
 		mkdir -p gpurun_out/bench_sweep
-		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy sintbl qtrtbl qtrtbl16 qtrtbl24 quadtbl quadtbl24; do
+		for w in cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy nat32 nat24 nat16 natr2p24 sintbl qtrtbl qtrtbl16 qtrtbl24 quadtbl quadtbl24; do
 			for inp in ramp random; do
 				python bench.py --workload $w --input $inp --no-cpu-baseline --no-other-paths --no-pmc \
 					> gpurun_out/bench_sweep/${w}_${inp}.json 2>> $log
