@@ -15,6 +15,10 @@ over 2^30-word arrays allocated by torch (hipMalloc underneath).
          slowest reader as input and the fastest / slowest writers as outputs
   pairs  [N=8]                 every (input; output pair) out of N arrays,
          grouped by their distance in allocation order
+  slab   [GIB=40]              ONE allocation; the three arrays at chosen
+         offsets inside it: role permutations, displacements of one array,
+         spacings, shifts of the whole triple -- is there a rule in the
+         addresses?
 """
 import collections
 import ctypes
@@ -130,6 +134,51 @@ def mode_rw(N=6):
               % ((name, i, a, b) + copy(P[i], P[a], P[b]) + kernel(i, a, b)))
 
 
+def mode_slab(gib=40):
+    G, M = 1 << 30, 1 << 20
+    slab = torch.empty(gib * G, dtype=torch.uint8, device="cuda")
+    slab.zero_()
+    torch.cuda.synchronize()
+    base = (slab.data_ptr() + (2 * M - 1)) & ~(2 * M - 1)
+    room = slab.data_ptr() + gib * G - base
+    print("# slab of %d GiB at %x (2 MiB-aligned base %x); arrays of 4 GiB at "
+          "byte offsets from the base; 1R2W one-shot-tile copy, 20 launches"
+          % (gib, slab.data_ptr(), base))
+
+    def run(tag, oi, o0, o1):
+        assert max(oi, o0, o1) + 4 * G <= room, (tag, oi, o0, o1)
+        ms, f = copy(base + oi, base + o0, base + o1)
+        print("%-34s in %6.0f M  out0 %6.0f M  out1 %6.0f M   %.3f ms  %.3f"
+              % (tag, oi / M, o0 / M, o1 / M, ms, f))
+        sys.stdout.flush()
+        return f
+
+    print("## roles over the ranges 0 / 4 / 8 GiB")
+    for perm in itertools.permutations((0, 4 * G, 8 * G)):
+        run("roles", *perm)
+    print("## the input displaced (outputs at 0 and 4 GiB)")
+    for k in range(0, 12):
+        run("in at 8 GiB + 2^%d MiB" % (k + 1), 8 * G + (2 * M << k), 0, 4 * G)
+    print("## out1 displaced (in at 10 GiB... , out0 at 0)")
+    for k in range(0, 11):
+        run("out1 at 4 GiB + 2^%d MiB" % (k + 1), 10 * G + 2 * G, 0, 4 * G + (2 * M << k))
+    print("## out0 displaced (the read array LOWEST)")
+    for k in range(0, 11):
+        run("in 0, out0 at 4 GiB + 2^%d MiB" % (k + 1), 0, 4 * G + (2 * M << k), 10 * G)
+    print("## spacing: arrays at 0, 4 GiB + d, 8 GiB + 2 d")
+    for k in range(0, 11):
+        d = 2 * M << k
+        run("d = 2^%d MiB, in lowest" % (k + 1), 0, 4 * G + d, 8 * G + 2 * d)
+        run("d = 2^%d MiB, in highest" % (k + 1), 8 * G + 2 * d, 0, 4 * G + d)
+    print("## the whole triple (0 / 4 / 8 GiB, in lowest; then in highest) shifted")
+    for k in range(0, 14):
+        sft = 2 * M << k
+        if sft + 12 * G > room:
+            break
+        run("shift 2^%d MiB, in lowest" % (k + 1), sft, sft + 4 * G, sft + 8 * G)
+        run("shift 2^%d MiB, in highest" % (k + 1), sft + 8 * G, sft, sft + 4 * G)
+
+
 def mode_pairs(N=8):
     arr = arrays(N)
     P = [t.data_ptr() for t in arr]
@@ -154,7 +203,7 @@ def mode_pairs(N=8):
 
 if __name__ == "__main__":
     modes = {"sets": mode_sets, "roles": mode_roles, "rw": mode_rw,
-             "pairs": mode_pairs}
+             "pairs": mode_pairs, "slab": mode_slab}
     if len(sys.argv) < 2 or sys.argv[1] not in modes:
         sys.exit(__doc__)
     modes[sys.argv[1]](*[int(v) for v in sys.argv[2:]])
