@@ -498,6 +498,19 @@ __device__ __forceinline__ int32_t round_to_ow_lj32(int64_t v, const CoreParams 
 	return (int32_t)((uint64_t)v >> 32);
 }
 
+// r + LJ > 32 (e.g. WW 33 / 34 -> OW 30 / 31, and every WW <= 32 core carried
+// at LJ = 30): the same on the high word, then the remaining r + LJ - 32 bits
+// are dropped with one 32-bit shift.
+template <int LJ>
+__device__ __forceinline__ int32_t round_to_ow_lj_hi(int64_t v, const CoreParams &kp,
+		uint32_t sh)
+{
+	const uint32_t b = ((uint32_t)((uint64_t)v >> 32) >> sh) & kp.round_bit;
+	const int32_t t = (int32_t)(b + (uint32_t)kp.round_base);
+	op_mad_s(v, 1u << LJ, t);
+	return (int32_t)((uint64_t)v >> 32) >> sh;
+}
+
 template <int LJ>
 __device__ __forceinline__ int32_t round_to_ow_lj(int64_t v, const CoreParams &kp)
 {
@@ -808,6 +821,13 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 				for (int v = 0; v < kVec; v++) {
 					rx[v] = round_to_ow_lj32<LJ>(x[v], kp);
 					ry[v] = round_to_ow_lj32<LJ>(y[v], kp);
+				}
+			} else if (kp.r_lj > 32 && kp.r < 31) {
+				const uint32_t sh = (uint32_t)kp.r_lj - 32u;
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj_hi<LJ>(x[v], kp, sh);
+					ry[v] = round_to_ow_lj_hi<LJ>(y[v], kp, sh);
 				}
 			} else {
 #pragma unroll
@@ -1348,6 +1368,13 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				for (int v = 0; v < kVec; v++) {
 					rx[v] = round_to_ow_lj32<LJ>(x[v], kp);
 					ry[v] = round_to_ow_lj32<LJ>(y[v], kp);
+				}
+			} else if (kp.r_lj > 32 && kp.r < 31) {
+				const uint32_t sh = (uint32_t)kp.r_lj - 32u;
+#pragma unroll
+				for (int v = 0; v < kVec; v++) {
+					rx[v] = round_to_ow_lj_hi<LJ>(x[v], kp, sh);
+					ry[v] = round_to_ow_lj_hi<LJ>(y[v], kp, sh);
 				}
 			} else {
 #pragma unroll

@@ -568,9 +568,11 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 				if (j.io16)
 					done = launch_seed_narrow16(FEED, cfg.nlive, g2, st,
 							kp, sa, j, lds);
-				else if (cfg.ww <= 32)
+				else if (cfg.ww <= 32 && (cfg.needs_wrap
+						|| (cfg.flags & CORDIC_FLAG_NO_LJ)))
 					done = launch_seed_narrow(FEED, cfg.nlive, g2, st,
 							kp, sa, j, lds);
+				// (every other WW <= 34 core: left-justified by 30)
 				else if (cfg.ww == 35)
 					done = launch_seed_lj29(FEED, cfg.nlive, g2, st, kp,
 							sa, j, lds);
@@ -586,8 +588,17 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			const int ngen = general_stages_for(cfg.ww);
 			if (j.io16) {
 				done = launch_rot_narrow16(FEED, cfg.nlive, grid, st, kp, j);
-			} else if (cfg.ww <= 32) {
+			} else if (cfg.ww <= 32 && (cfg.needs_wrap
+					|| (cfg.flags & CORDIC_FLAG_NO_LJ))) {
+				// 32-bit container: its wrap IS the WW = 32 wrap
 				done = launch_rot_narrow(FEED, cfg.nlive, grid, st, kp, j);
+			} else if (cfg.ww <= 32) {
+				// Round 3: WW <= 32 cores run in the left-justified 64-bit
+				// container too (LJ = 30: 7 instead of 8 instructions per
+				// stage; full recurrence 19 / 27 stages +11 / +17 %, seeded
+				// on unrelated phases +4 / +8 %, on ramps -2.5 / 0 %;
+				// profiles/r03/ab_tails.txt, part 16)
+				done = launch_rot_lj30(FEED, cfg.nlive, grid, st, kp, j);
 			} else {
 				// left-justified forms first (WW 33..40), the plain
 				// 64-bit kernels for everything else

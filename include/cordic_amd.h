@@ -86,8 +86,11 @@ enum cordic_status {
 
 /* flags (cordic_config.flags) -- implementation selectors for A/B work */
 #define CORDIC_FLAG_FORCE_GENERIC	0x1u	/* never use an unrolled kernel */
-#define CORDIC_FLAG_NO_LJ		0x4u	/* WW 33..35: right-justified
-						   64-bit kernel (for A/B)      */
+#define CORDIC_FLAG_NO_LJ		0x4u	/* rotators with WW <= 35: the
+						   right-justified kernels (32-
+						   bit container for WW <= 32,
+						   64-bit above) instead of the
+						   left-justified ones (for A/B) */
 #define CORDIC_FLAG_UNIT_GAIN		0x10u	/* fuse the gain-annihilation
 						   multiply into the output:
 						   o = (o * K) >> 32, K =

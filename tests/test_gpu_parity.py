@@ -351,7 +351,12 @@ def test_left_justified_kernel_equals_right_justified_kernel():
                  (ca.P2R, 32, 24, 7, 32, 1), (ca.P2R, 32, 32, 7, 32, 2),
                  (ca.P2R, 32, 32, 7, 32, 7), (ca.P2R, 32, 32, 7, 32, 8),
                  (ca.P2R, 30, 32, 6, 28, 19), (ca.P2R, 32, 8, 4, 24, 12),
-                 (ca.P2R, 32, 32, 7, 32, 44)]:
+                 (ca.P2R, 32, 32, 7, 32, 44),
+                 # WW <= 32: left-justified by 30 against the 32-bit container
+                 # (static instances with and without direction tails)
+                 (ca.P2R, 24, 24, 2, -1, -1), (ca.P2R, 16, 16, 2, -1, -1),
+                 (ca.SP2R, 20, 20, 2, -1, -1), (ca.P2R, 13, 13, 2, -1, -1),
+                 (ca.P2R, 12, 20, 1, 17, 15), (ca.P2R, 29, 29, 2, 32, 26)]:
         cfg, ocfg = both(*args)
         rj = cfg.with_flags(ca.FLAG_NO_LJ)
         rng = np.random.RandomState(18)
@@ -363,7 +368,7 @@ def test_left_justified_kernel_equals_right_justified_kernel():
         assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), args
         lim = 1 << (cfg.iw - 1)
         for x0, y0 in ((lim - 1, 0), (-lim, -lim), (12345 % lim, -(777 % lim))):
-            for flags in (0, ca.FLAG_NO_SEED):
+            for flags in (0, ca.FLAG_NO_SEED, ca.FLAG_NO_LJ):
                 plan = ca.Plan(cfg.with_flags(flags))
                 a = gpu_plan_p2r(plan, x0, y0, ph)
                 c = O.rotate(ocfg, x0, y0, ph)
