@@ -808,10 +808,15 @@ def run_group(args, w, launch):
     kind = w["kind"]
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
-    seeded, seed_stages = False, 0
+    seeded, seed_stages, tails = False, 0, []
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
-        seed_stages = ca.Plan(cfg).seed_info["stages"]
+        probe_plan = ca.Plan(cfg)
+        seed_stages = probe_plan.seed_info["stages"]
         seeded = seed_stages > 0
+        # (what the plan carries; an NCO with a large increment and rows of
+        # unrelated phases still run the recurrence: DESIGN.md section 4.3)
+        tails = [] if args.no_tails else probe_plan.tail_groups
+        probe_plan.close()
 
     def fill(g):
         if kind == "p2r":
@@ -1087,8 +1092,10 @@ def run_group(args, w, launch):
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
-                    "seeded(%d)+unrolled, %s" % (
-                        seed_stages, "static chunks" if args.static_chunks
+                    "seeded(%d)%s+unrolled, %s" % (
+                        seed_stages,
+                        "+tails(%s)" % "+".join(map(str, tails)) if tails else "",
+                        "static chunks" if args.static_chunks
                         else "address-ordered tile queue")
                     if seeded else ("topolar_lj / topolar_unrolled"
                                     if kind == "r2p" else "unrolled")),

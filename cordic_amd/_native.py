@@ -110,6 +110,8 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_plan_tail_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
     "cordic_device_count": (C.c_int, []),
     "cordic_shard_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int,
                                      C.POINTER(C.c_uint64),
@@ -357,6 +359,15 @@ class Plan:
                                            C.byref(c)),
                "cordic_plan_seed_info")
         return dict(stages=a.value, nleaves=b.value, nbuckets=c.value)
+
+    @property
+    def tail_groups(self):
+        """stages per looked-up group behind the seeds ([] = no direction tails)"""
+        n = C.c_int32()
+        st = (C.c_int32 * 4)()
+        _check(lib().cordic_plan_tail_info(self._h, C.byref(n), st),
+               "cordic_plan_tail_info")
+        return [int(st[g]) for g in range(n.value)]
 
     def p2r_const(self, x0, y0, phase, ox, oy, n=None, stream=None):
         n = phase.numel() if n is None else n

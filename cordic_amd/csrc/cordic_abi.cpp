@@ -216,6 +216,18 @@ int cordic_plan_seed_info(const cordic_plan *plan, int32_t *stages,
 	return CORDIC_OK;
 }
 
+int cordic_plan_tail_info(const cordic_plan *plan, int32_t *ngroups,
+		int32_t stages[4])
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	if (ngroups) *ngroups = plan->dt.n;
+	if (stages)
+		for (int g = 0; g < 4; g++)
+			stages[g] = g < plan->dt.n ? plan->dt.lv[g].t : 0;
+	return CORDIC_OK;
+}
+
 static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 {
 	j.seed_table = plan->d_table;

@@ -255,6 +255,12 @@ const cordic_config *cordic_plan_config(const cordic_plan *plan);
 /* stages covered by the seed table (0 = none), its leaves and buckets */
 int	cordic_plan_seed_info(const cordic_plan *plan, int32_t *stages,
 		int32_t *nleaves, int32_t *nbuckets);
+/* The direction tails behind the seed table: the number of stage groups whose
+ * multipliers are looked up (0: none) and, in stages[0..3], their sizes; the
+ * stages behind the last group run the phase recurrence.  (Plans created with
+ * CORDIC_FLAG_NO_TAILS still report the table; the launch ignores it.)         */
+int	cordic_plan_tail_info(const cordic_plan *plan, int32_t *ngroups,
+		int32_t stages[4]);
 
 int	cordic_plan_p2r_const(const cordic_plan *plan, size_t n,
 		int32_t xval, int32_t yval, const uint32_t *d_phase,

@@ -1064,6 +1064,7 @@ def test_direction_tails_on_every_group_boundary(args):
     assert tails is not None
     plan = ca.Plan(cfg)
     assert plan.seed_info["stages"] == 11
+    assert plan.tail_groups == [g["t"] for g in tails["groups"]]
     lsh = 32 - cfg.pw
     step = 1 << lsh                     # one LSB of the PW-bit phase, P units
     rng = np.random.RandomState(5)
