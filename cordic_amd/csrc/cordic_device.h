@@ -961,6 +961,63 @@ __device__ __forceinline__ void for_each_queued_tile(uint32_t *queue,
 		queue_leave(queue);
 }
 
+// The same with the next tile's input fetched before this tile is worked on
+// (round 3: the table kernels run one or two 1024-thread blocks per CU, so
+// without it every tile waits out its own load): `load(tile)` returns the
+// lane's input registers, `body(tile, regs)` consumes them.
+template <int BS, typename R, typename LD, typename F>
+__device__ __forceinline__ void for_each_queued_tile_prefetched(uint32_t *queue,
+		volatile uint32_t *slot, uint32_t ntiles, LD load, F body)
+{
+	constexpr uint32_t kEnd = 0xffffffffu;
+	const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
+	uint32_t home = 0, tried = 0;		// lane 0 of the block only
+	auto grab = [&]() -> uint32_t {
+		while (tried < (uint32_t)kQueueCounters) {
+			const uint32_t j = (home + tried) % kQueueCounters;
+			const uint32_t lo = j * per;
+			const uint32_t cnt = lo >= ntiles ? 0u
+				: (ntiles - lo < per ? ntiles - lo : per);
+			if (cnt != 0) {
+				const uint32_t t = atomicAdd(&queue[j * kQueueStride], 1u);
+				if (t < cnt)
+					return lo + t;
+			}
+			tried++;
+		}
+		return kEnd;
+	};
+	auto lds_barrier = [] {		// LDS only: no wait for global stores
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	};
+	if (threadIdx.x == 0) {
+		home = xcc_id() % kQueueCounters;
+		slot[0] = grab();
+		slot[1] = grab();
+	}
+	lds_barrier();
+	uint32_t cur = slot[0];
+	int ring = 0;
+	R regs{};
+	if (cur != kEnd)
+		regs = load(cur);
+	while (cur != kEnd) {
+		const uint32_t nxt = slot[(ring + 1) % 3];
+		R pre{};
+		if (nxt != kEnd)
+			pre = load(nxt);
+		body(cur, regs);
+		if (threadIdx.x == 0)
+			slot[(ring + 2) % 3] = grab();
+		lds_barrier();
+		cur = nxt;
+		regs = pre;
+		ring = (ring + 1) % 3;
+	}
+	if (threadIdx.x == 0)
+		queue_leave(queue);
+}
+
 
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
 		typename IO = Io32, bool UG = false, bool DT = false>

@@ -175,16 +175,39 @@ __device__ __forceinline__ int32_t table_sample(const int32_t *__restrict__ tbl,
 // an arithmetic-free 1R1W stream runs at 0.58-0.63 of the HBM peak with one
 // contiguous chunk per block and at 0.72-0.79 this way, profiles/r02/
 // hbm_probe2.txt).  queue == NULL: the chunk-per-block sweep.
-template <typename F>
+// PF: fetch the next tile's phases before this tile is worked on.  Worth it
+// where ONE block fits a CU (the 128 KiB tables: +12 %) or the lookups leave
+// the CU (+1.3 %); with two blocks per CU the blocks already cover each
+// other's loads and the extra registers cost 2-4 % (profiles/r03/
+// tables_prefetch.txt).
+template <bool PF, typename F>
 __device__ __forceinline__ void sweep_tiles(uint32_t *queue, volatile uint32_t *slot,
-		size_t nvec, F one_vector)
+		size_t nvec, const u32x4g *pv, F one_vector)
 {
-	if (queue) {
+	if (queue && !PF) {
 		for_each_queued_tile<1024>(queue, slot,
 			(uint32_t)((nvec + 1023) / 1024), [&](uint32_t tile) {
 				const size_t g = (size_t)tile * 1024 + threadIdx.x;
 				if (g < nvec)
-					one_vector(g);
+					one_vector(g, __builtin_nontemporal_load(&pv[g]));
+			});
+		return;
+	}
+	if (queue) {
+		// the lane's vector of a tile, clamped into the batch (only the last
+		// tile is partial): the prefetch needs no predicate
+		const size_t last = nvec - 1;
+		for_each_queued_tile_prefetched<1024, u32x4>(queue, slot,
+			(uint32_t)((nvec + 1023) / 1024),
+			[&](uint32_t tile) -> u32x4 {
+				size_t g = (size_t)tile * 1024 + threadIdx.x;
+				g = g < last ? g : last;
+				return __builtin_nontemporal_load(&pv[g]);
+			},
+			[&](uint32_t tile, const u32x4 p) {
+				const size_t g = (size_t)tile * 1024 + threadIdx.x;
+				if (g < nvec)
+					one_vector(g, p);
 			});
 		return;
 	}
@@ -193,7 +216,20 @@ __device__ __forceinline__ void sweep_tiles(uint32_t *queue, volatile uint32_t *
 	const size_t lo = (size_t)blockIdx.x * chunk;
 	const size_t hi = (lo + chunk < nvec) ? lo + chunk : nvec;
 	for (size_t g = lo + threadIdx.x; g < hi; g += 1024)
-		one_vector(g);
+		one_vector(g, __builtin_nontemporal_load(&pv[g]));
+}
+
+// (without the prefetch: the placement probe, whose loads are its whole work)
+template <typename F>
+__device__ __forceinline__ void sweep_tiles(uint32_t *queue, volatile uint32_t *slot,
+		size_t nvec, F one_vector)
+{
+	for_each_queued_tile<1024>(queue, slot,
+		(uint32_t)((nvec + 1023) / 1024), [&](uint32_t tile) {
+			const size_t g = (size_t)tile * 1024 + threadIdx.x;
+			if (g < nvec)
+				one_vector(g);
+		});
 }
 
 template <bool QUARTER>
@@ -205,8 +241,7 @@ __global__ __launch_bounds__(1024) void table_lookup(
 	const size_t nvec = n / kVec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
+	sweep_tiles<true>(queue, slot, nvec, pv, [&](size_t g, const u32x4 p) {
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
@@ -260,8 +295,8 @@ __global__ __launch_bounds__(1024) void table_lookup_lds(
 	const size_t nvec = n / kVec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
+	// (32-bit entries: up to 128 KiB of LDS, one block per CU)
+	sweep_tiles<(sizeof(E) > 2)>(queue, slot, nvec, pv, [&](size_t g, const u32x4 p) {
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
@@ -335,8 +370,7 @@ __global__ __launch_bounds__(1024) void quad_lookup(
 	const size_t nvec = n / kVec;
 	const u32x4g *pv = reinterpret_cast<const u32x4g *>(phase);
 	i32x4g *ov = reinterpret_cast<i32x4g *>(val);
-	sweep_tiles(queue, slot, nvec, [&](size_t g) {
-		const u32x4 p = __builtin_nontemporal_load(&pv[g]);
+	sweep_tiles<false>(queue, slot, nvec, pv, [&](size_t g, const u32x4 p) {
 		i32x4 o;
 #pragma unroll
 		for (int v = 0; v < kVec; v++)
