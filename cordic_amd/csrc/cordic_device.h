@@ -867,7 +867,7 @@ struct SeedArgs {
 
 // LDS of the direction tails of a seeded kernel: per group its buckets
 // (8 bytes each, aligned to their total size so that the bucket address is
-// (index & mask) | base) and its 64-byte leaf entries.  `at` = first free byte
+// (index & mask) | base) and its leaf entries (dt_entry_dwords each).  `at` = first free byte
 // behind the seeds and the tile-id slots; returns the new end.
 __host__ __device__ inline uint32_t dt_lds_layout(const DtInfo &dt, uint32_t at,
 		uint32_t *bucket_base, uint32_t *leaf_base)

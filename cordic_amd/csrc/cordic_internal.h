@@ -71,7 +71,7 @@ int	quad_write_header(const cordic_quad_config *q, const char *name,
 // no multiplier extraction: 4 instead of 7 VALU instructions per stage, ~6 per
 // lookup).  The schedule -- how the R = NLIVE - M remaining stages are cut
 // into groups -- is fixed here for host and device alike: as few groups as
-// hold at most seven stages each (a 64-byte entry), of equal size with the
+// hold at most seven stages each (15 dwords of entry), of equal size with the
 // longer ones last.  A lookup is not free -- a bucket and up to 60 bytes of
 // LDS per sample and group, and the LDS returns 128 bytes a cycle per CU
 // whether or not the lanes agree on the address -- so fewer, longer groups

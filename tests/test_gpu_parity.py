@@ -1047,7 +1047,7 @@ def test_one_plan_launched_from_four_host_threads():
 def test_direction_tails_on_every_group_boundary(args):
     """The stages behind the seeds take their multipliers from tables
     indexed by the residual phase (direction tails) wherever a wave's row of
-    256 phases is coherent (first and last less than 2^16 apart), and run the
+    256 phases is coherent (first and last less than 2^24 apart), and run the
     phase recurrence elsewhere.  (a) Unit-step ramps of 2^21 phases from
     random starts in every quadrant: coherent rows that put the residual on
     EVERY integer of several seed leaves, hence on every boundary of every
