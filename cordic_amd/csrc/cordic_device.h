@@ -1201,14 +1201,15 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		}
 	};
 	// Direction tails trade VALU instructions for LDS reads (a bucket and up
-	// to 60 bytes of multipliers per group and sample).  Where the lanes of a
-	// wave read the same or neighbouring entries -- a phase ramp of any slope,
-	// an NCO with a small increment -- the reads spread over the banks; on
-	// unrelated phases the larger tables collide and the lookup loses a few
-	// per cent to the recurrence (cordic_internal.h: kDtCoherentLog2).  So each
-	// wave decides per row: first and last phase of the row less than 2^24
-	// apart -> tails, else the phase recurrence (two lane reads and a scalar
-	// compare; a row of unrelated phases passes by chance once in 2^7).
+	// to 60 bytes of multipliers per group and sample).  Groups of up to five
+	// stages have at most 32 leaves: their lookups win on ANY phases (unrelated
+	// ones included: 16-stage cores +1...+2.6 %, 19-21 stages +3...+9 %), and
+	// cores made of such groups look up on every row (dt_always).  With 64-128
+	// leaves per group unrelated phases collide on the banks and the lookup
+	// loses a few per cent to the recurrence, while a ramp of any slope or a
+	// slow NCO gains: there each wave decides per row -- first and last phase
+	// less than 2^24 apart -> tails, else the phase recurrence (two lane reads
+	// and a scalar compare; a row of unrelated phases passes once in 2^7).
 	auto row_is_coherent = [](const uint32_t (&pb)[kVec]) -> bool {
 		const uint32_t pf = __builtin_amdgcn_readfirstlane(pb[0]);
 		const uint32_t pl = __builtin_amdgcn_readlane(pb[kVec - 1], 63);
@@ -1573,7 +1574,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 					const size_t base = (size_t)cur * kTileVecs
 							+ (size_t)s * kSeedBlock;
 					i32x4 rx, ry;
-					if (DT && row_is_coherent(pb[s]))
+					if constexpr (DT && dt_always(kDtR))
+						pass_pb(std::true_type{}, pb[s], rx, ry);
+					else if (DT && row_is_coherent(pb[s]))
 						pass_pb(std::true_type{}, pb[s], rx, ry);
 					else
 						pass_pb(std::false_type{}, pb[s], rx, ry);
@@ -1640,7 +1643,9 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		i32x4 rx, ry;
 		uint32_t pb[kVec];
 		fold_pb(g, 0u, tph, pb);
-		if (DT && row_is_coherent(pb))
+		if constexpr (DT && dt_always(kDtR))
+			pass_pb(std::true_type{}, pb, rx, ry);
+		else if (DT && row_is_coherent(pb))
 			pass_pb(std::true_type{}, pb, rx, ry);
 		else
 			pass_pb(std::false_type{}, pb, rx, ry);

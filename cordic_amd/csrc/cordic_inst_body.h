@@ -149,7 +149,8 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	bool tails_pay = true;
 	if (FEED == Feed::Nco_ConstXY) {
 		const int32_t f = (int32_t)kp.fcw;	// left-justified increment
-		tails_pay = (f < 0 ? -(int64_t)f : (int64_t)f) < ((int64_t)1 << (kDtCoherentLog2 - 8));
+		tails_pay = kDtCoherentLog2 >= 31	// (A/B builds: every row)
+			|| (f < 0 ? -(int64_t)f : (int64_t)f) < ((int64_t)1 << (kDtCoherentLog2 - 8));
 	}
 	switch (nlive) {
 	// static instances; where the plan carries direction tails for the
@@ -160,7 +161,8 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	if constexpr ((CORDIC_INST_CONTAINER::lj != 0 || !CORDIC_INST_CONTAINER::wide) \
 			&& dt_levels(N - kSeedStages) >= 1 \
 			&& dt_levels(N - kSeedStages) <= kDtMaxLevels) { \
-		if (sa.dt.n == dt_levels(N - kSeedStages) && tails_pay) \
+		if (sa.dt.n == dt_levels(N - kSeedStages) \
+				&& (tails_pay || dt_always(N - kSeedStages))) \
 			kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, \
 					FEED, false, Io32, false, true>; \
 	} \

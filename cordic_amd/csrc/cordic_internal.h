@@ -77,12 +77,12 @@ int	quad_write_header(const cordic_quad_config *q, const char *name,
 // whether or not the lanes agree on the address -- so fewer, longer groups
 // win: 13 stages as 6+7 run 4 % faster than as 5+5+3, those 5 % faster than
 // as 3+3+3+4 (profiles/r03/ab_tails.txt).  Measured gains on a phase ramp by
-// stages behind the seeds: 7 (one group) +10 %, 9 +7 %, 11 +9 %, 13 +12 %;
-// 5 (cfg2, the slow NCO) 0 to +0.4 % against -0.9 % on unrelated phases for
-// the row test: cores with fewer than kDtMinStages keep the recurrence.
+// stages behind the seeds: 5 (cfg2: one group) +1.5 %, 7 +10 %, 9 +7 %,
+// 11 +9 %, 13 (cfg4) +12 %; the NCO of cfg5 (5 behind, unrelated phases)
+// +2.6 %.  Fewer than kDtMinStages: not measured, no tails.
 constexpr int kDtMaxLevels = 4;
 #ifndef CORDIC_DT_MIN_STAGES
-#define CORDIC_DT_MIN_STAGES 7
+#define CORDIC_DT_MIN_STAGES 5
 #endif
 constexpr int kDtMinStages = CORDIC_DT_MIN_STAGES;
 // A row of 256 phases takes the tails when its first and last phase are less
@@ -122,6 +122,15 @@ constexpr int dt_first(int r, int level)	// stages before group `level`
 	int done = 0;
 	for (int g = 0; g < level; g++) done += dt_size(r, g);
 	return done;
+}
+constexpr int dt_rest_stages(int r) { return dt_levels(r) == 0 ? r : r - dt_covered(r); }
+// every group small enough (<= 5 stages: <= 32 leaves on a 12-dword stride)
+// for its lookups to win on unrelated phases too: no per-row choice, no
+// recurrence body in the kernel
+constexpr bool dt_always(int r)
+{
+	const int n = dt_levels(r);
+	return n > 0 && dt_size(r, n - 1) <= 5 && dt_rest_stages(r) == 0;
 }
 constexpr int dt_rest(int r)			// stages left to the phase chain
 {

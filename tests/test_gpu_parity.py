@@ -1031,7 +1031,9 @@ def test_one_plan_launched_from_four_host_threads():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 16),      # cfg2: one group of 5
+                                  (ca.P2R, 32, 32, 2, 32, 17),
+                                  (ca.P2R, 32, 32, 2, 32, 18),
                                   (ca.P2R, 32, 32, 2, 32, 30),
                                   (ca.SP2R, 32, 32, 2, 32, -1),
                                   (ca.P2R, 31, 31, 2, 30, 28),

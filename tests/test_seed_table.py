@@ -123,15 +123,16 @@ def parse_tails(words):
 def schedule(r):
     """cordic_internal.h: dt_levels / dt_size -- stages 11..24 at most, in the
     fewest groups of at most seven stages, equal sizes, the longer ones last;
-    none under seven stages; what is left runs the recurrence."""
-    if r < 7:
+    none under five stages; what is left runs the recurrence."""
+    if r < 5:
         return [], r
     c = min(r, 25 - 11)
     n = (c + 6) // 7
     return [c // n + (1 if g >= n - c % n else 0) for g in range(n)], r - c
 
 
-@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 18),
+@pytest.mark.parametrize("args", [(ca.P2R, 32, 32, 2, 32, 16),
+                                  (ca.P2R, 32, 32, 2, 32, 18),
                                   (ca.P2R, 32, 32, 2, 32, 30),
                                   (ca.SP2R, 32, 32, 2, 32, -1),
                                   (ca.P2R, 24, 24, 2, -1, -1),
@@ -201,17 +202,18 @@ def test_cores_without_room_or_need_have_no_tails():
     # fewer than three stages behind the seeds: nothing to look up
     w = ca.seed_table(ca.Config.from_cli(ca.P2R, 16, 16, 2, 16, 16))   # 13 live
     assert parse_tails(w) is None
-    # fewer than seven: a lookup costs what the stages save (measured)
-    for ns in (14, 16, 17):
+    # fewer than five: not measured, none built
+    for ns in (13, 14, 15):
         w = ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns))
         assert parse_tails(w) is None, ns
-    assert parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 18)))
+    t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)))
+    assert [g["t"] for g in t["groups"]] == [5]
     # the last stages of a 29-stage core move the phase by 1..5 units: their
     # leaves are narrower than the smallest bucket; the tails stop at stage 24
     t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 30)))
     assert [g["t"] for g in t["groups"]] == [7, 7]
     # (WW <= 32 cores have tails like the wide ones: multipliers -/+ 1)
-    w = ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1))   # 16 live
-    assert parse_tails(w) is None
+    t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 13, 13, 2, -1, -1)))   # 16 live
+    assert [g["t"] for g in t["groups"]] == [5]
     t = parse_tails(ca.seed_table(ca.Config.from_cli(ca.P2R, 16, 16, 2, -1, -1)))
     assert [g["t"] for g in t["groups"]] == [4, 4]
