@@ -1276,8 +1276,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			// before; pipelining them by hand across the groups, with
 			// scheduling fences, measured 1.6 % SLOWER -- the four waves per
 			// SIMD cover the latency; profiles/r03/ab_tails.txt, form 7.
-			// Multipliers in SGPRs for rows that sit on ONE entry: at most
-			// +4 % before the cost of the exact test, form 11: not built.)
+			// Multipliers in SGPRs for rows that sit on ONE entry of the
+			// first group: +4 % without a test (form 11), but with the exact
+			// test, the entry read once and 13-15 v_readfirstlane the row
+			// stalls on that chain: -3.5...-6 % (form 18).  Not kept.)
 			auto group = [&](auto G_) {
 				constexpr int G = decltype(G_)::value;
 				constexpr int T = dt_size(kDtR, G);
