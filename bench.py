@@ -199,7 +199,25 @@ def _usable_cpus():
     return n
 
 
-def cpu_baseline(workload, seconds=12.0):
+def oracle_digest_leg(args, w, ocfg, start, n, x0, y0):
+    """The oracle's digest of ALL n samples this rank computed (threaded
+    orc_digest: every sample through the scalar restatement, condensed by the
+    device's position-aware digest).  This CPU work is also the cpu_baseline
+    sample, so it is done once.  None for inputs the oracle cannot regenerate
+    (--input random) and for 16-bit containers (two samples per word)."""
+    import oracle_lib as O
+    kind = w["kind"]
+    if (args.input != "ramp" or w.get("io16") or kind == "tbl"
+            or getattr(args, "no_full_digest", False)):
+        return None
+    fcw = 0x01234567 if kind == "nco" else (1 << w.get("shift", 0))
+    cores = _usable_cpus()
+    d, secs = O.job_digest(ocfg, kind, start, n, 0, fcw, x0, y0,
+                           threads=cores)
+    return {"digest": d, "samples": n, "seconds": secs, "cores": cores}
+
+
+def cpu_baseline(workload, seconds=12.0, leg=None):
     """The oracle (a restatement of the reference RTL, NOT reference code:
     the reference has no CPU compute path) timed on
     the host cores of this box on a bounded sample of the same workload:
@@ -221,19 +239,30 @@ def cpu_baseline(workload, seconds=12.0):
     t0 = time.perf_counter()
     n1 = L.orc_throughput(C.byref(ocfg), kind, 1, 1.0, mul, x0, 0)
     one = n1 / (time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    total = L.orc_throughput(C.byref(ocfg), kind, cores, seconds, mul, x0, 0)
-    wall = time.perf_counter() - t0
+    if leg is not None and leg["seconds"] >= 1.0:
+        # the digest leg already pushed every sample of this run through the
+        # oracle on all cores: that IS the bounded sample (not done twice)
+        total, wall, cores = leg["samples"], leg["seconds"], leg["cores"]
+        sample = ("all %d samples of this run's %s workload (%d threads "
+                  "drawing 2^16-sample blocks, %.1f s), whose outputs' digest "
+                  "is what digest_check compares with the device's; includes "
+                  "making the inputs and the digest (~4 %% of the work)"
+                  % (total, workload, cores, wall))
+    else:
+        t0 = time.perf_counter()
+        total = L.orc_throughput(C.byref(ocfg), kind, cores, seconds, mul,
+                                 x0, 0)
+        wall = time.perf_counter() - t0
+        sample = ("%d samples of the %s workload (%d threads x 2^16-sample "
+                  "blocks for %.0f s)" % (total, workload, cores, seconds))
     return {
         "value": total / wall / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d samples of the %s workload (%d threads x 2^16-sample "
-                  "blocks for %.0f s) through oracle/liboracle.so: gcc -O2 "
-                  "scalar restatement of the reference RTL -- the reference "
-                  "itself has no CPU compute path" % (total, workload, cores,
-                                                      seconds),
+        "sample": sample + " through oracle/liboracle.so: gcc -O2 scalar "
+                  "restatement of the reference RTL -- the reference itself "
+                  "has no CPU compute path",
         "value_1thread": one / 1e6,
         "cpu": _cpu_model(),
         "cpus_visible": os.cpu_count(),
@@ -290,6 +319,8 @@ def other_paths(args, steps=24, warmup=4):
              "kernel": d["config"]["kernel"],
              "bit_exact_vs_oracle": d["bit_exact_vs_oracle"],
              "digest": d["digest"],
+             "digest_check": {k: (d.get("digest_check") or {}).get(k) for k in (
+                 "samples", "equal", "oracle", "oracle_seconds")},
              "roofline": {k: roof[k] for k in (
                  "bound", "achieved", "peak", "unit", "frac", "valu_fraction",
                  "valu", "kernel_ms_avg", "kernel_ms_min") if k in roof},
@@ -373,7 +404,8 @@ def measure_pmc(args):
     base = [sys.executable, os.path.abspath(__file__), "--workload",
             args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
             str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
-            "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power"]
+            "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power",
+            "--no-full-digest"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks),
                      ("--no-tails", args.no_tails)):
@@ -898,14 +930,14 @@ def run_group(args, w, launch):
     kern_avg_s = kern_total_ms / args.steps / 1e3
 
     # ---- after the timed region: correctness of what was just computed
-    digest = grp.digest(n_total)
+    digest = local_digest = grp.digest(n_total)
     if dist is not None:
         d = torch.tensor([digest - (1 << 64) if digest >= 1 << 63 else digest],
                          dtype=torch.int64, device=coll_device(dev))
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
         digest = int(d.item()) & 0xFFFFFFFFFFFFFFFF
 
-    check = digest_check = None
+    check = digest_check = leg = None
     if rank == 0:
         ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
         start0 = grp.range(n_total, first)[0]
@@ -943,6 +975,23 @@ def run_group(args, w, launch):
             got = int(dd.cpu().numpy().view(np.uint64)[0])
         digest_check = {"samples": cnt, "device": "%016x" % got,
                         "oracle": "%016x" % want, "equal": got == want}
+        # ... and EVERY output this process computed (its nlocal shards are
+        # one contiguous global range) against the oracle
+        lo = grp.range(n_total, first)[0]
+        cnt_all = sum(grp.range(n_total, first + sh)[1] for sh in range(nlocal))
+        leg = oracle_digest_leg(args, w, ocfg, lo, cnt_all, x0, y0)
+        if leg is not None:
+            digest_check = {
+                "samples": cnt_all, "device": "%016x" % local_digest,
+                "oracle": "%016x" % leg["digest"],
+                "equal": local_digest == leg["digest"],
+                "oracle_seconds": leg["seconds"], "oracle_threads": leg["cores"],
+                "what": "position-aware 64-bit digest of ALL outputs of this "
+                        "process's shards: device digest kernel over what the "
+                        "timed kernels wrote vs oracle/cordic_oracle.c: "
+                        "orc_digest (every sample through the scalar oracle)",
+                "leading_2^20_also_equal": got == want}
+            check = check and digest_check["equal"]
 
     # ---- constant-vector feeds: also time the full-recurrence kernel (every
     # sample runs all micro-rotations) so both numbers are on record
@@ -1132,7 +1181,7 @@ def run_group(args, w, launch):
         if single is not None:
             out["single_process_cordic_group"] = single
         if not args.no_cpu_baseline and total == 1:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.workload, leg=leg)
         if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
             torch.cuda.empty_cache()
             out["other_paths"] = other_paths(args)
@@ -1379,14 +1428,15 @@ def run_direct(args, w, launch):
     ca.digest_u32(a.view(torch.int32), index0 // (2 if io16 else 1), d)
     ca.digest_u32(b.view(torch.int32),
                   index0 // (2 if io16 else 1) + (1 << 40), d)
+    torch.cuda.synchronize()
+    local_digest = int(d.cpu().numpy().view(np.uint64)[0])
     if dist is not None:
-        torch.cuda.synchronize()
         d = d.to(coll_device(dev))
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
     torch.cuda.synchronize()
     digest = int(d.cpu().numpy().view(np.uint64)[0])
 
-    check = None
+    check = digest_check = leg = None
     if rank == 0:
         import oracle_lib as O
         ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
@@ -1415,6 +1465,17 @@ def run_direct(args, w, launch):
                   * np.uint64(0x01234567) & np.uint64(0xffffffff))
             ra, rb = O.rotate(ocfg, x0, y0, ph.astype(np.uint32))
         check = bool(np.array_equal(ga, ra) and np.array_equal(gb, rb))
+        # EVERY output of this rank against the oracle
+        leg = oracle_digest_leg(args, w, ocfg, index0, n, x0, y0)
+        if leg is not None:
+            digest_check = {
+                "samples": n, "device": "%016x" % local_digest,
+                "oracle": "%016x" % leg["digest"],
+                "equal": local_digest == leg["digest"],
+                "oracle_seconds": leg["seconds"], "oracle_threads": leg["cores"],
+                "what": "position-aware 64-bit digest of ALL outputs: device "
+                        "digest kernel vs oracle/cordic_oracle.c: orc_digest"}
+            check = check and digest_check["equal"]
 
     # ---- constant-vector feeds: also time the full-recurrence kernel (every
     # sample runs all micro-rotations) so both numbers are on record
@@ -1493,6 +1554,7 @@ def run_direct(args, w, launch):
                 args.workload + ("_noseed" if args.no_seed else "")),
             "bit_exact_vs_oracle": check,
             "digest": "%016x" % digest,
+            "digest_check": digest_check,
         }
         roof = out["roofline"]
         if power is not None:
@@ -1512,7 +1574,7 @@ def run_direct(args, w, launch):
         if full is not None:
             out["full_recurrence_kernel"] = full
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.workload, leg=leg)
         emit(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
@@ -1540,6 +1602,9 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=30,
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-digest", action="store_true",
+                    help="skip the oracle digest over ALL samples (rank 0, "
+                    "all host cores, ~2 s per 2^30 samples on 16 cores)")
     ap.add_argument("--no-copy-probe", action="store_true")
     ap.add_argument("--no-placement", action="store_true",
                     help="take the group's arrays as hipMalloc hands them out "

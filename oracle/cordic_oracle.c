@@ -1084,6 +1084,120 @@ uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
 	return total;
 }
 
+/* ---------------------------------------------------- whole-job digests
+ *
+ * The oracle's answer for EVERY sample of a synthetic job, condensed to the
+ * 64-bit position-aware digest the device computes over its own outputs
+ * (cordic_digest_u32, cordic_amd/csrc/cordic_kernels.hip: digest_mix):
+ *     sum over g in [start, start+n) of mix(g, out0[g]) + mix(g + 2^40, out1[g])
+ * so that a BASELINE-size run (2^30 .. 2^33 samples) is compared with the
+ * oracle on 100 % of its outputs instead of on a strided subset.  The
+ * per-sample arithmetic is orc_rotate / orc_topolar, unchanged (rtl/cordic.v:
+ * 131-188,231-314, rtl/topolar.v:122-152,195-271); only the inputs are made
+ * here, by the same rules as the device's fill kernels:
+ *   kind 0  rotator, constant (x0, y0), phase[g] = phase0 + g*fcw mod 2^32
+ *           (cfg2: fcw 4; cfg4: fcw 1; cfg5 NCO: fcw 0x01234567)
+ *   kind 1  converter, x[g] = sext_iw(((uint32)g*mulx) >> 8), y likewise
+ *   kind 2  rotator with the per-sample vectors of kind 1 and kind 0's phase
+ * Threads draw 2^16-sample blocks from a shared counter. */
+typedef struct {
+	const orc_config *cfg;
+	int kind;
+	uint64_t start, n;
+	uint32_t phase0, fcw, mulx, muly;
+	int32_t x0, y0;
+	uint64_t next;		/* shared block counter (atomic) */
+	uint64_t sum;		/* per-thread result */
+	void *shared;
+} orc_djob;
+
+static inline uint64_t orc_mix(uint64_t idx, uint32_t w)
+{
+	uint64_t z = (idx + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)w;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+uint64_t orc_digest_words(const uint32_t *w, size_t n, uint64_t index0)
+{
+	uint64_t s = 0;
+	for (size_t i = 0; i < n; i++)
+		s += orc_mix(index0 + i, w[i]);
+	return s;
+}
+
+static void *orc_digest_worker(void *arg)
+{
+	orc_djob *j = (orc_djob *)arg;
+	orc_djob *sh = (orc_djob *)j->shared;
+	const size_t per = 1u << 16;
+	uint32_t *ph = malloc(per * 4);
+	int32_t *a = malloc(per * 4), *b = malloc(per * 4);
+	int32_t *x = malloc(per * 4), *y = malloc(per * 4);
+	const int shf = 32 - j->cfg->iw;
+	uint64_t sum = 0;
+	for (;;) {
+		const uint64_t blk = __atomic_fetch_add(&sh->next, 1,
+				__ATOMIC_RELAXED);
+		const uint64_t off = blk * per;
+		if (off >= j->n)
+			break;
+		const size_t cnt = (j->n - off < per) ? (size_t)(j->n - off) : per;
+		const uint64_t g0 = j->start + off;
+		for (size_t i = 0; i < cnt; i++) {
+			const uint32_t g = (uint32_t)(g0 + i);
+			ph[i] = j->phase0 + g * j->fcw;
+			if (j->kind != 0) {
+				x[i] = (int32_t)(((g * j->mulx) >> 8) << shf) >> shf;
+				y[i] = (int32_t)(((g * j->muly) >> 8) << shf) >> shf;
+			}
+		}
+		if (j->kind == 1)
+			orc_topolar(j->cfg, cnt, x, y, a, (uint32_t *)b);
+		else if (j->kind == 2)
+			orc_rotate(j->cfg, cnt, x, y, 1, ph, a, b);
+		else
+			orc_rotate(j->cfg, cnt, &j->x0, &j->y0, 0, ph, a, b);
+		sum += orc_digest_words((const uint32_t *)a, cnt, g0);
+		sum += orc_digest_words((const uint32_t *)b, cnt,
+				g0 + (1ull << 40));
+	}
+	j->sum = sum;
+	free(ph); free(a); free(b); free(x); free(y);
+	return NULL;
+}
+
+uint64_t orc_digest(const orc_config *cfg, int kind, int nthreads,
+		uint64_t start, uint64_t n, uint32_t phase0, uint32_t fcw,
+		int32_t x0, int32_t y0, uint32_t mulx, uint32_t muly,
+		double *seconds)
+{
+	if (nthreads < 1)
+		nthreads = 1;
+	pthread_t *th = malloc(sizeof(pthread_t) * (size_t)nthreads);
+	orc_djob *jobs = calloc((size_t)nthreads, sizeof(orc_djob));
+	const double t0 = now_s();
+	uint64_t total = 0;
+	for (int t = 0; t < nthreads; t++) {
+		jobs[t].cfg = cfg; jobs[t].kind = kind;
+		jobs[t].start = start; jobs[t].n = n;
+		jobs[t].phase0 = phase0; jobs[t].fcw = fcw;
+		jobs[t].mulx = mulx; jobs[t].muly = muly;
+		jobs[t].x0 = x0; jobs[t].y0 = y0;
+		jobs[t].shared = &jobs[0];
+		pthread_create(&th[t], NULL, orc_digest_worker, &jobs[t]);
+	}
+	for (int t = 0; t < nthreads; t++) {
+		pthread_join(th[t], NULL);
+		total += jobs[t].sum;
+	}
+	if (seconds)
+		*seconds = now_s() - t0;
+	free(th); free(jobs);
+	return total;
+}
+
 /* ------------------------------------------------------------ table cores
  *
  * sintable / quarterwav (sw/sintable.cpp): plain table lookups, outside the

@@ -147,6 +147,20 @@ void	orc_quad_lookup(const orc_quad *q, const long *ctbl, const long *ltbl,
 uint64_t orc_throughput(const orc_config *cfg, int kind, int nthreads,
 		double seconds, uint32_t phase_mul, int32_t x0, int32_t y0);
 
+/* The oracle's outputs for EVERY sample g in [start, start+n) of a synthetic
+ * job, as the device's position-aware digest (cordic_digest_u32):
+ *   sum mix(g, out0[g]) + mix(g + 2^40, out1[g])  mod 2^64.
+ * kind 0: rotator, constant (x0,y0), phase[g] = phase0 + (uint32)g*fcw;
+ * kind 1: converter on x[g] = sext_iw(((uint32)g*mulx)>>8), y likewise (muly);
+ * kind 2: rotator on kind 1's vectors and kind 0's phases.
+ * nthreads POSIX threads; *seconds (may be NULL) receives the wall time. */
+uint64_t orc_digest(const orc_config *cfg, int kind, int nthreads,
+		uint64_t start, uint64_t n, uint32_t phase0, uint32_t fcw,
+		int32_t x0, int32_t y0, uint32_t mulx, uint32_t muly,
+		double *seconds);
+/* sum over i of mix(index0 + i, w[i]): CPU twin of cordic_digest_u32 */
+uint64_t orc_digest_words(const uint32_t *w, size_t n, uint64_t index0);
+
 #ifdef __cplusplus
 }
 #endif

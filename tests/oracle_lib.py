@@ -86,6 +86,13 @@ def lib():
         L.orc_throughput.restype = C.c_uint64
         L.orc_throughput.argtypes = [cfgp, C.c_int, C.c_int, C.c_double,
                                      C.c_uint32, C.c_int32, C.c_int32]
+        L.orc_digest.restype = C.c_uint64
+        L.orc_digest.argtypes = [cfgp, C.c_int, C.c_int, C.c_uint64,
+                                 C.c_uint64, C.c_uint32, C.c_uint32,
+                                 C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_double)]
+        L.orc_digest_words.restype = C.c_uint64
+        L.orc_digest_words.argtypes = [u32p, C.c_size_t, C.c_uint64]
         _lib = L
     return _lib
 
@@ -152,6 +159,47 @@ def nco(cfg, n, phase0, fcw, index0, x0, y0):
     lib().orc_nco(C.byref(cfg), n, phase0, fcw, index0, x0, y0,
                   _i32(ox), _i32(oy))
     return ox, oy
+
+
+IQ_MULX, IQ_MULY = 0x9E3779B1, 0x85EBCA77      # SURVEY.md 8(d) config 3 ramps
+
+
+def usable_cpus():
+    """Hardware threads this process may use: affinity mask cut down to the
+    cgroup CPU quota (the GPU boxes show 256 CPUs and grant 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def job_digest(cfg, kind, start, n, phase0=0, fcw=1, x0=0, y0=0,
+               mulx=IQ_MULX, muly=IQ_MULY, threads=None):
+    """(digest, seconds): the oracle's outputs for EVERY sample of a synthetic
+    job as the device's position-aware digest -- sum of mix(g, out0[g]) +
+    mix(g + 2^40, out1[g]) over g in [start, start+n).  kind "p2r" / "nco":
+    constant (x0, y0), phase[g] = phase0 + g*fcw; "r2p": the I/Q ramps;
+    "p2rxy": the I/Q ramps rotated by phase[g]."""
+    k = {"p2r": 0, "nco": 0, "r2p": 1, "p2rxy": 2}[kind]
+    sec = C.c_double(0.0)
+    d = lib().orc_digest(C.byref(cfg), k, threads or usable_cpus(), start, n,
+                         phase0 & 0xffffffff, fcw & 0xffffffff, x0, y0,
+                         mulx, muly, C.byref(sec))
+    return int(d), sec.value
+
+
+def digest_words(words, index0=0):
+    """C twin of gpu_util.cpu_digest (for arrays too large for numpy temps)"""
+    w = np.ascontiguousarray(words).view(np.uint32)
+    return int(lib().orc_digest_words(_u32(w), w.size, index0))
 
 
 class SeqRegs(C.Structure):

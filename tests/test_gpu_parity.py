@@ -644,6 +644,11 @@ def _full_size_p2r(nstages, shift):
     torch.cuda.synchronize()
     assert ca.last_kernel() == ca.KERNEL_SEEDED
     whole = _digest2(a, b)
+    # PRIMARY: every one of the 2^30 output pairs against the oracle (threaded
+    # scalar restatement of rtl/cordic.v:131-188,231-314, condensed by the same
+    # position-aware digest; oracle/cordic_oracle.c: orc_digest)
+    want, _ = O.job_digest(ocfg, "p2r", 0, n, 0, 1 << shift, x0, 0)
+    assert whole == want, ("%016x" % whole, "%016x" % want)
     # same work as 64 shards through the full-recurrence kernel
     plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
     a2 = torch.empty(1 << 24, dtype=torch.int32, device=DEV)
@@ -699,6 +704,10 @@ def test_full_size_cfg5_nco_4g_samples():
     plan = ca.Plan(cfg)
     plan.nco(n, 0, fcw, 0, x0, 0, a, b)
     torch.cuda.synchronize()
+    # PRIMARY: all 2^32 output pairs against the oracle
+    want, _ = O.job_digest(ocfg, "nco", 0, n, 0, fcw, x0, 0)
+    got = _digest2(a, b)
+    assert got == want, ("%016x" % got, "%016x" % want)
     q = 1 << 30
     a2 = torch.empty(q, dtype=torch.int32, device=DEV)
     b2 = torch.empty(q, dtype=torch.int32, device=DEV)
@@ -728,6 +737,11 @@ def test_full_size_cfg3_r2p_round_trip_and_spot_check():
     ca.fill_iq_ramp(x, y, 0, 0x9E3779B1, 0x85EBCA77, 24)
     ca.r2p(cfg, x, y, mag, ph)
     torch.cuda.synchronize()
+    # PRIMARY: all 2^30 (magnitude, phase) pairs against the oracle
+    # (rtl/topolar.v:122-152,195-271), which regenerates the I/Q ramps itself
+    want, _ = O.job_digest(ocfg, "r2p", 0, n)
+    got = _digest2(mag, ph)
+    assert got == want, ("%016x" % got, "%016x" % want)
     idx = np.unique(np.concatenate([np.arange(4096), np.arange(n - 4096, n),
                                     np.arange(0, n, 65521)])).astype(np.int64)
     ti = torch.from_numpy(idx).to(DEV)

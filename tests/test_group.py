@@ -355,8 +355,11 @@ def _multi_proc(args, timeout=300):
     shim = os.path.join(root, "tests", "rccl_shim", "librccl_shim.so")
     if not (os.path.exists(exe) and os.path.exists(shim)):
         pytest.skip("tools/multi_proc or the RCCL shim not built")
+    # the stand-in is asynchronous (exchanges complete on a helper thread,
+    # stream-ordered); 5 ms of injected latency per exchange keeps the host far
+    # ahead of the transfers, as it is with real RCCL on a loaded node
     env = dict(os.environ, CORDIC_RCCL_LIB=shim, HSA_ENABLE_IPC_MODE_LEGACY="0",
-               CORDIC_GROUP_PLACEMENT="0")
+               CORDIC_GROUP_PLACEMENT="0", CORDIC_SHIM_DELAY_MS="5")
     return subprocess.run([exe] + args, capture_output=True, text=True,
                           timeout=timeout, env=env)
 
@@ -407,6 +410,7 @@ if rank == ROOT_SHARD:
     dst = [ca.Group(cfg, devices=[0]) for _ in P0]
     for d in dst:
         d.reserve(n_total, 0)
+t0 = time.perf_counter()
 for k, p0 in enumerate(P0):          # different jobs, no sync in between
     if rank == ROOT_SHARD:
         ptrs = dst[k].buffers(0)[1]
@@ -414,7 +418,11 @@ for k, p0 in enumerate(P0):          # different jobs, no sync in between
     else:
         g.set_gather_rccl(ROOT_SHARD, None, None, 3)
     g.nco(n_total, p0, 0x01234567, AMP, 0)
+t1 = time.perf_counter()
 g.sync()
+t2 = time.perf_counter()
+print("rank %d enqueue_ms %.2f total_ms %.2f" % (rank, (t1 - t0) * 1e3,
+                                                  (t2 - t0) * 1e3))
 if rank == ROOT_SHARD:
     ocfg = O.config_cli(O.P2R, 32, 32, 2, 32, 16)
     idx = np.arange(n_total, dtype=np.uint64)
@@ -429,10 +437,7 @@ g.close()
 """
 
 
-def test_group_over_the_shim_from_python_two_ranks(tmp_path):
-    """Two PROCESSES, one shard each, root shard 1, three DIFFERENT successive
-    jobs (NCO blocks with changing phase0) without a sync in between: the
-    arrays gathered on the root equal the oracle element by element."""
+def _two_python_ranks(tmp_path, extra_env):
     import os
     import subprocess
     import sys
@@ -441,11 +446,13 @@ def test_group_over_the_shim_from_python_two_ranks(tmp_path):
     if not os.path.exists(shim):
         pytest.skip("RCCL shim not built")
     env = dict(os.environ, CORDIC_RCCL_LIB=shim, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env)
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     n_total = (1 << 18) + 77
+    idfile = tmp_path / ("id%d.bin" % len(list(tmp_path.iterdir())))
     procs = [subprocess.Popen([sys.executable, str(script), root, str(r),
-                               str(tmp_path / "id.bin"), str(n_total)],
+                               str(idfile), str(n_total)],
                               env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True)
              for r in range(2)]
@@ -457,6 +464,129 @@ def test_group_over_the_shim_from_python_two_ranks(tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    return procs, outs
+
+
+def _ms(out, key):
+    import re
+    return float(re.search(key + r" ([0-9.]+)", out).group(1))
+
+
+@pytest.mark.parametrize("delay_ms", [0, 5, 20])
+def test_group_over_the_shim_from_python_two_ranks(tmp_path, delay_ms):
+    """Two PROCESSES, one shard each, root shard 1, three DIFFERENT successive
+    jobs (NCO blocks with changing phase0) without a sync in between: the
+    arrays gathered on the root equal the oracle element by element -- over a
+    stand-in whose exchanges complete asynchronously, `delay_ms` after the
+    data is ready (9 exchanges per rank: 3 jobs x 3 pieces)."""
+    procs, outs = _two_python_ranks(tmp_path,
+                                    {"CORDIC_SHIM_DELAY_MS": str(delay_ms)})
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so[-2000:] + se[-3000:]
     assert "gathered arrays equal the oracle for 3 jobs" in outs[1][0]
+    if delay_ms >= 20:
+        # the calls only enqueue: the host is done long before the transfers
+        for so, _ in outs:
+            assert _ms(so, "total_ms") >= 9 * delay_ms
+            assert _ms(so, "enqueue_ms") < 0.5 * _ms(so, "total_ms"), so
+
+
+def test_async_shim_catches_a_missing_job_order(tmp_path):
+    """The proof that the stand-in bites: the SAME two ranks against
+    cordic_amd/lib_fault.so -- the library built without the wait of a job's
+    kernels for the previous job's forwarded pieces (cordic_group.cpp,
+    -DCORDIC_FAULT_SKIP_JOB_ORDER; tools/fault_build.sh) -- must gather WRONG
+    data: job k+1 overwrites out0 / out1 while job k's delayed transfer has not
+    read them.  With CORDIC_SHIM_SYNC=1 (the round-3 stand-in: exchange
+    complete inside ncclGroupEnd) the same faulty build passes unnoticed."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fault = os.path.join(root, "cordic_amd", "lib_fault.so")
+    if not os.path.exists(fault):
+        pytest.skip("cordic_amd/lib_fault.so not built (tools/fault_build.sh)")
+    procs, outs = _two_python_ranks(tmp_path, {"CORDIC_SHIM_DELAY_MS": "5",
+                                               "CORDIC_AMD_LIB": fault})
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    assert procs[1].returncode != 0, "the faulty build went unnoticed"
+    assert "AssertionError" in outs[1][1]
+    procs, outs = _two_python_ranks(tmp_path, {"CORDIC_SHIM_SYNC": "1",
+                                               "CORDIC_AMD_LIB": fault})
+    assert [p.returncode for p in procs] == [0, 0]
+
+
+# ------------------------------------------------ BASELINE config 4 at its size
+#
+# "basiccordic 24-stage, 32-bit, 8G samples sharded across 8 x MI355X": the
+# whole 2^33-sample job as its 8 shards on ONE device (3 x 32 GiB of shard
+# arrays + 64 GiB for the gathered result: fits 288 GB).  Shards 4-7 hold
+# global indices >= 2^32 (the phase ramp (uint32)n wraps) and the other three
+# quarters of the phase circle.  Every one of the 2^33 output pairs is compared
+# with the oracle through the position-aware digest (orc_digest, threaded).
+
+def _oracle_cfg4_digest(n_total, result):
+    _, ocfg = both(*CFG4)
+    result.append(O.job_digest(ocfg, "p2r", 0, n_total, 0, 1, AMP, 0))
+
+
+def test_cfg4_all_8g_samples_as_8_shards_on_one_device():
+    import threading
+    import torch
+    from gpu_util import gpu_digest
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 << 30:
+        pytest.skip("needs 200 GiB of free HBM")
+    cfg, ocfg = both(*CFG4)
+    n_total = 1 << 33
+    res = []
+    th = threading.Thread(target=_oracle_cfg4_digest, args=(n_total, res))
+    th.start()                      # ~20 s on 16 cores, beside the GPU work
+    g = ca.Group(cfg, devices=[0] * 8)
+    g.fill_phase_ramp(n_total, 0)
+    g.p2r_const(n_total, AMP, 0)
+    g.sync()
+    for s in range(8):
+        assert g.range(n_total, s) == (s << 30, 1 << 30)
+    got = g.digest(n_total)
+    # shard 5's own first and last samples, read back, against the oracle
+    for off in (0, (1 << 30) - 4096):
+        rx, ry = oracle_p2r(ocfg, (5 << 30) + off, 4096)
+        assert np.array_equal(g.read(5, g.OUT0, off, 4096), rx)
+        assert np.array_equal(g.read(5, g.OUT1, off, 4096), ry)
+    th.join()
+    want, secs = res[0]
+    assert got == want, ("%016x" % got, "%016x" % want)
+    # the final gather (peer-copy path), pieces behind the compute
+    out0 = torch.empty(n_total, dtype=torch.int32, device="cuda")
+    out1 = torch.empty(n_total, dtype=torch.int32, device="cuda")
+    for chunks in (1, 8):
+        out0.zero_(); out1.zero_()
+        torch.cuda.synchronize()
+        g.set_gather(0, out0.data_ptr(), out1.data_ptr(), chunks)
+        g.p2r_const(n_total, AMP, 0)
+        g.sync()
+        gathered = (gpu_digest(out0, 0) + gpu_digest(out1, 1 << 40)) % 2**64
+        assert gathered == want, (chunks, "%016x" % gathered)
+    g.set_gather(-1)
+    g.close()
+
+
+@pytest.mark.parametrize("ranks,root,chunks", [(2, 1, 8), (3, 2, 1)])
+def test_processes_gather_2_30_samples_per_rank_through_the_shim(ranks, root,
+                                                                 chunks):
+    """2-3 PROCESSES on the one GPU, 2^30 samples each (BASELINE's per-GPU
+    share of config 4), RCCL send/recv path to a root != 0; the gathered
+    arrays' digest must equal the oracle's digest of all ranks * 2^30 samples."""
+    import re
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < (ranks * 12 + 8 * ranks + 8 << 30):
+        pytest.skip("not enough free HBM")
+    _, ocfg = both(*CFG4)
+    r = _multi_proc(["-d", ",".join(["0"] * ranks), "-l", "30", "-n", "24",
+                     "-k", "1", "-c", str(chunks), "-R", str(root)], timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(equal)" in r.stdout
+    got = int(re.search(r"digest of the gathered  : ([0-9a-f]{16})",
+                        r.stdout).group(1), 16)
+    want, _ = O.job_digest(ocfg, "p2r", 0, ranks << 30, 0, 1, AMP, 0)
+    assert got == want

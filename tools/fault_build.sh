@@ -1,0 +1,23 @@
+#!/bin/bash
+# fault_build.sh -- cordic_amd/lib_fault.so: the library with ONE ordering
+# edge removed (cordic_group.cpp: the wait of a job's kernels for the previous
+# job's forwarded pieces, -DCORDIC_FAULT_SKIP_JOB_ORDER).  Test infrastructure:
+# tests/test_group.py::test_async_shim_catches_a_missing_job_order runs the
+# back-to-back jobs over the asynchronous RCCL stand-in against this build and
+# expects WRONG gathered data -- the proof that the stand-in can see what the
+# round-3 one (exchange complete inside ncclGroupEnd) could not.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT/cordic_amd/csrc"
+mkdir -p build_fault
+# every other object is identical: reuse the product build's
+for o in build/*.o; do
+	b=$(basename $o)
+	[ "$b" = cordic_group.o ] || ln -sf ../$o build_fault/$b
+done
+g++ -O3 -std=c++17 -fPIC -fwrapv -Wall -Wno-unused-function -I"$ROOT/include" -I. \
+	-ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include \
+	-DCORDIC_FAULT_SKIP_JOB_ORDER -c cordic_group.cpp -o build_fault/cordic_group.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/cordic_amd/lib_fault.so" \
+	build_fault/*.o -ldl
+echo "built cordic_amd/lib_fault.so"
