@@ -339,6 +339,96 @@ def other_paths(args, steps=24, warmup=4):
     return res
 
 
+def host_paths(log2n=28, reps=3):
+    """The host-array entry points (cordic_p2r_host / cordic_r2p_host: what a
+    caller holding the reference bench's plain `int` arrays uses,
+    bench/cpp/cordic_tb.cpp:94-178) timed beside the raw PCIe rates of this
+    box: pinned 1 GiB hipMemcpy each way, then BASELINE config 2's core on
+    2^log2n host samples -- pinned arrays (DMA'd in place) and pageable numpy
+    arrays (staged by the library's copy threads) -- and config 3's converter.
+    Informational, never `value`: inputs start in HOST memory here.  Outputs
+    are checked against the oracle's digest of every sample."""
+    import ctypes as C
+    import cordic_amd as ca
+    import oracle_lib as O
+    n = 1 << log2n
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dev = torch.empty(n, dtype=torch.int32, device="cuda")
+    pin = [ca.HostArray(n, "int32") for _ in range(4)]
+    res = {"samples": n, "reps": reps}
+
+    def best(fn):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+    pin[0].array[:] = 1
+    h2d = best(lambda: hip.hipMemcpy(dev.data_ptr(), pin[0].array.ctypes.data,
+                                     n * 4, 1))
+    d2h = best(lambda: hip.hipMemcpy(pin[0].array.ctypes.data, dev.data_ptr(),
+                                     n * 4, 2))
+    res["pcie"] = {"h2d_GBps": n * 4 / h2d / 1e9, "d2h_GBps": n * 4 / d2h / 1e9,
+                   "what": "hipMemcpy of %d MiB, pinned host memory, best of "
+                           "%d" % (n * 4 >> 20, reps)}
+    del dev
+
+    def line(seconds, up, down, want, got):
+        # the direction that takes longer at the raw rates is the bound
+        t_up = up * n / (res["pcie"]["h2d_GBps"] * 1e9)
+        t_down = down * n / (res["pcie"]["d2h_GBps"] * 1e9)
+        return {"Msamples_per_s": n / seconds / 1e6, "seconds": seconds,
+                "up_GBps": up * n / seconds / 1e9,
+                "down_GBps": down * n / seconds / 1e9,
+                "frac_of_slower_pcie_direction": max(t_up, t_down) / seconds,
+                "stats": {k: v for k, v in ca.host_last_stats().items()
+                          if k != "seconds"},
+                "digest_equals_oracle": want == got}
+
+    def dig(a, b):
+        return (O.digest_words(a, 0) + O.digest_words(b, 1 << 40)) % (1 << 64)
+    # config 2: constant vector, phase ramp n << 2
+    m, iw, ow, xtra, pw, ns = WORKLOADS["cfg2"]["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    x0 = (1 << (iw - 1)) - 1
+    ramp = (np.arange(n, dtype=np.uint32) << np.uint32(2))
+    want, _ = O.job_digest(ocfg, "p2r", 0, n, 0, 4, x0, 0)
+    pin[0].array.view(np.uint32)[:] = ramp
+    out = (pin[1].array, pin[2].array)
+    ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32), out=out)   # set-up
+    t = best(lambda: ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32),
+                                 out=out))
+    res["p2r_const_pinned"] = line(t, 4, 8, want, dig(*out))
+    pa, pb = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb))
+    t = best(lambda: ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb)))
+    res["p2r_const_pageable"] = line(t, 4, 8, want, dig(pa, pb))
+    # config 3: converter on the I/Q ramps (8 B up, 8 B down)
+    m, iw, ow, xtra, pw, ns = WORKLOADS["cfg3"]["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    g = np.arange(n, dtype=np.uint32)
+    sh = 32 - iw
+    for k, mul in ((0, O.IQ_MULX), (1, O.IQ_MULY)):
+        with np.errstate(over="ignore"):
+            v = ((g * np.uint32(mul)) >> np.uint32(8)) << np.uint32(sh)
+        pin[k].array[:] = v.view(np.int32) >> sh
+    want, _ = O.job_digest(ocfg, "r2p", 0, n)
+    out = (pin[2].array, pin[3].array.view(np.uint32))
+    ca.r2p_host(cfg, pin[0].array, pin[1].array, out=out)
+    t = best(lambda: ca.r2p_host(cfg, pin[0].array, pin[1].array, out=out))
+    res["r2p_pinned"] = line(t, 8, 8, want, dig(*out))
+    for h in pin:
+        h.close()
+    ca.host_release()
+    return res
+
+
 def _profile_entry(key):
     """Counters of a workload from the COMMITTED rocprofv3 passes
     (profiles/pmc_latest.json; tools/profile_workload.sh produced them in an
@@ -1185,6 +1275,10 @@ def run_group(args, w, launch):
         if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
             torch.cuda.empty_cache()
             out["other_paths"] = other_paths(args)
+            try:
+                out["other_paths"]["host_arrays"] = host_paths()
+            except Exception as e:            # never lose the main line
+                out["other_paths"]["host_arrays"] = {"error": repr(e)}
         emit(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
@@ -1599,6 +1693,9 @@ def main():
     ap.add_argument("--no-other-paths", action="store_true",
                     help="skip the informational rates of the other entry "
                     "points after the default (cfg2) run")
+    ap.add_argument("--host-paths-only", action="store_true",
+                    help="print only the host-array entry points' rates "
+                    "(other_paths.host_arrays of the default line)")
     ap.add_argument("--log2-samples", type=int, default=30,
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1658,6 +1755,9 @@ def main():
         # the ranks and sub-runs this process starts)
         os.environ["CORDIC_GROUP_PLACEMENT"] = "0"
 
+    if args.host_paths_only:
+        print(json.dumps(host_paths()))
+        return
     launch = resolve_launch(args)
     if launch == "spawn":
         respawn(args)               # does not return

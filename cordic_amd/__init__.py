@@ -20,7 +20,7 @@ from ._native import (  # noqa: F401
     Config, CordicError, Plan, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED,
     lib, lib_path,
     p2r, p2r_const, nco, r2p,
-    p2r_host, r2p_host,
+    p2r_host, r2p_host, HostArray, host_last_stats, host_release,
     fill_phase_ramp, fill_iq_ramp, digest_u32,
 )
 

@@ -112,6 +112,9 @@ ABI = {
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
     "cordic_plan_tail_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
+    "cordic_plan_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_table_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_quad_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_device_count": (C.c_int, []),
     "cordic_shard_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int,
                                      C.POINTER(C.c_uint64),
@@ -201,6 +204,10 @@ ABI = {
                                       C.c_void_p, C.c_void_p]),
     "cordic_p2r_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, C.c_int,
                                   _u32p, _i32p, _i32p]),
+    "cordic_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cordic_host_free": (None, [C.c_void_p]),
+    "cordic_host_release": (None, []),
+    "cordic_host_last_stats": (C.c_int, [C.c_void_p]),
     "cordic_r2p_host": (C.c_int, [_cfgp, C.c_size_t, _i32p, _i32p, _i32p,
                                   _u32p]),
     "cordic_fill_phase_ramp": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64,
@@ -359,6 +366,11 @@ class Plan:
                                            C.byref(c)),
                "cordic_plan_seed_info")
         return dict(stages=a.value, nleaves=b.value, nbuckets=c.value)
+
+    @property
+    def queue_info(self):
+        """tile-queue ring of the handle (include/cordic_amd.h)"""
+        return _queue_info("cordic_plan_queue_info", self._h)
 
     @property
     def tail_groups(self):
@@ -622,6 +634,17 @@ class _CTableConfig(C.Structure):
                 ("entries", C.c_int32)]
 
 
+class _CQueueInfo(C.Structure):
+    _fields_ = [("eager_slots", C.c_int32), ("captured_capacity", C.c_int32),
+                ("captured_used", C.c_int32), ("fallback_launches", C.c_uint64)]
+
+
+def _queue_info(fn, handle):
+    q = _CQueueInfo()
+    _check(getattr(lib(), fn)(handle, C.byref(q)), fn)
+    return {k: int(getattr(q, k)) for k, _ in _CQueueInfo._fields_}
+
+
 class Table:
     """A -t tbl / -t qtr core: cordic_table_config + its device table."""
 
@@ -651,6 +674,10 @@ class Table:
     @property
     def lds_mode(self):
         return lib().cordic_table_lds_mode(self._h)
+
+    @property
+    def queue_info(self):
+        return _queue_info("cordic_table_queue_info", self._h)
 
     def lookup(self, phase, val, n=None, stream=None):
         n = phase.numel() if n is None else n
@@ -718,6 +745,10 @@ class Quad:
         if n < 0:
             raise CordicError(n, "cordic_quad_write_header")
         return buf.value.decode()
+
+    @property
+    def queue_info(self):
+        return _queue_info("cordic_quad_queue_info", self._h)
 
     def lookup(self, phase, val, n=None, stream=None):
         n = phase.numel() if n is None else n
@@ -1011,16 +1042,64 @@ def r2p(cfg, x, y, mag, ophase, n=None, stream=None):
                             _ptr(ophase), _stream(stream)), "cordic_r2p")
 
 
-def p2r_host(cfg, x, y, phase):
-    """numpy in / numpy out through the host-buffer entry point."""
+class _CHostStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("chunks", C.c_int32),
+                ("chunk_samples", C.c_int32), ("staged_inputs", C.c_int32),
+                ("staged_outputs", C.c_int32), ("copy_threads", C.c_int32),
+                ("seeded_plan", C.c_int32), ("seconds", C.c_double)]
+
+
+class HostArray:
+    """n 32-bit words of PINNED host memory (cordic_host_alloc) as a numpy
+    array: what the host-array entry points DMA in place."""
+
+    def __init__(self, n, dtype="int32"):
+        import numpy as np
+        p = C.c_void_p()
+        _check(lib().cordic_host_alloc(C.byref(p), max(1, n) * 4),
+               "cordic_host_alloc")
+        self._p = p
+        buf = (C.c_uint32 * max(1, n)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=np.uint32, count=n).view(dtype)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().cordic_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_last_stats():
+    st = _CHostStats()
+    _check(lib().cordic_host_last_stats(C.byref(st)), "cordic_host_last_stats")
+    return {k: getattr(st, k) for k, _ in _CHostStats._fields_}
+
+
+def host_release():
+    lib().cordic_host_release()
+
+
+def p2r_host(cfg, x, y, phase, out=None):
+    """cordic_p2r_host on numpy arrays (x, y scalars: constant vectors).
+    out = (ox, oy): write into these int32 arrays (e.g. HostArray.array)."""
     import numpy as np
     phase = np.ascontiguousarray(phase, dtype=np.uint32)
     n = phase.size
     scalar = np.ndim(x) == 0
-    xa = np.ascontiguousarray(np.atleast_1d(x), dtype=np.int32)
-    ya = np.ascontiguousarray(np.atleast_1d(y), dtype=np.int32)
-    ox = np.empty(n, dtype=np.int32)
-    oy = np.empty(n, dtype=np.int32)
+    if scalar:
+        xa = np.array([x], dtype=np.int32)
+        ya = np.array([y], dtype=np.int32)
+    else:
+        xa = np.ascontiguousarray(x, dtype=np.int32)
+        ya = np.ascontiguousarray(y, dtype=np.int32)
+    ox, oy = out if out is not None else (np.empty(n, dtype=np.int32),
+                                          np.empty(n, dtype=np.int32))
     _check(lib().cordic_p2r_host(
         cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
         1 if scalar else 0, phase.ctypes.data_as(_u32p),
@@ -1029,13 +1108,13 @@ def p2r_host(cfg, x, y, phase):
     return ox, oy
 
 
-def r2p_host(cfg, x, y):
+def r2p_host(cfg, x, y, out=None):
     import numpy as np
     xa = np.ascontiguousarray(x, dtype=np.int32)
     ya = np.ascontiguousarray(y, dtype=np.int32)
     n = xa.size
-    mag = np.empty(n, dtype=np.int32)
-    ph = np.empty(n, dtype=np.uint32)
+    mag, ph = out if out is not None else (np.empty(n, dtype=np.int32),
+                                           np.empty(n, dtype=np.uint32))
     _check(lib().cordic_r2p_host(
         cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
         mag.ctypes.data_as(_i32p), ph.ctypes.data_as(_u32p)),

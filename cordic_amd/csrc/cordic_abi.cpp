@@ -29,10 +29,16 @@ using namespace cordic_amd;
 //   - a launch issued while its stream is being CAPTURED keeps its slot baked
 //     into the graph node and may be replayed at any later time, so it takes a
 //     slot from [kEagerSlots, kQueueSlots) that is never handed out again
-//     (at most kQueueSlots - kEagerSlots captured launches per handle; further
-//     ones run the static sweep).  A graph exec never runs concurrently with
-//     itself, so one slot per captured node is enough.
-constexpr unsigned kQueueSlots = 64;
+//     (at most kQueueSlots - kEagerSlots = 208 captured launches per handle
+//     for its lifetime; further ones run the static sweep, -5...-8 %, and are
+//     counted: cordic_*_queue_info).  A graph exec never runs concurrently
+//     with itself, so one slot per captured node is enough; two execs
+//     instantiated from the SAME captured graph share the node's slot and
+//     must not run concurrently (include/cordic_amd.h says so).
+// Stream identity is never taken from the handle's address (a destroyed
+// stream's address can be reused): a slot whose event has not completed is
+// always waited for on the device, whatever stream asks.
+constexpr unsigned kQueueSlots = 256;
 constexpr unsigned kEagerSlots = 48;
 
 struct QueueRing {
@@ -41,8 +47,9 @@ struct QueueRing {
 	mutable std::mutex mu;
 	mutable hipEvent_t ev[kEagerSlots] = {};
 	mutable State state[kQueueSlots] = {};
-	mutable void *last_stream[kEagerSlots] = {};
+	mutable State prev[kEagerSlots] = {};	// state before the pending claim
 	mutable unsigned next = 0, next_captured = kEagerSlots;
+	mutable unsigned long long fallbacks = 0;	// launches that got no slot
 
 	bool alloc()
 	{
@@ -59,6 +66,14 @@ struct QueueRing {
 				return false;
 			}
 		return true;
+	}
+	void info(cordic_queue_info *out) const
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		out->eager_slots = d ? (int32_t)kEagerSlots : 0;
+		out->captured_capacity = d ? (int32_t)(kQueueSlots - kEagerSlots) : 0;
+		out->captured_used = (int32_t)(next_captured - kEagerSlots);
+		out->fallback_launches = fallbacks;
 	}
 	void release()
 	{
@@ -100,22 +115,24 @@ struct QueueRing {
 		}
 		std::lock_guard<std::mutex> lock(mu);
 		if (cs != hipStreamCaptureStatusNone) {
-			if (next_captured >= kQueueSlots)
+			if (next_captured >= kQueueSlots) {
+				fallbacks++;
 				return -1;
+			}
 			state[next_captured] = RETIRED;
 			return (int)next_captured++;
 		}
 		// round robin; a slot whose last launch may still be running is
-		// made safe ON THE DEVICE: same stream -> stream order already
-		// serialises the two kernels; another stream -> this stream waits
-		// for that launch's event (no host wait, and the host may run any
-		// number of launches ahead of the GPU without losing the queue)
+		// made safe ON THE DEVICE: this stream waits for that launch's
+		// event (on the stream that recorded it the wait is free: stream
+		// order already serialises the two kernels).  No host wait, and the
+		// host may run any number of launches ahead of the GPU without
+		// losing the queue.
 		for (unsigned i = 0; i < kEagerSlots; i++) {
 			const unsigned k = (next + i) % kEagerSlots;
 			if (state[k] == CLAIMED || state[k] == RETIRED)
 				continue;	// another thread is launching on it
-			if (state[k] == RECORDED && last_stream[k] != stream
-					&& hipEventQuery(ev[k]) != hipSuccess) {
+			if (state[k] == RECORDED && hipEventQuery(ev[k]) != hipSuccess) {
 				(void)hipGetLastError();	// hipErrorNotReady
 				if (hipStreamWaitEvent(static_cast<hipStream_t>(stream),
 						ev[k], 0) != hipSuccess) {
@@ -123,11 +140,12 @@ struct QueueRing {
 					continue;
 				}
 			}
+			prev[k] = state[k];
 			state[k] = CLAIMED;
-			last_stream[k] = stream;
 			next = (k + 1) % kEagerSlots;
 			return (int)k;
 		}
+		fallbacks++;
 		return -1;
 	}
 	// after the launch that uses `slot` has been enqueued (rc = its status)
@@ -137,7 +155,10 @@ struct QueueRing {
 			return;
 		std::lock_guard<std::mutex> lock(mu);
 		if (rc != CORDIC_OK)
-			state[slot] = FREE;	// nothing ran on it
+			// nothing new ran on it: what was there before the claim
+			// stands -- a RECORDED slot keeps its pending event, so the
+			// earlier launch is still waited for by the next taker
+			state[slot] = prev[slot];
 		else if (hipEventRecord(ev[slot], static_cast<hipStream_t>(stream)) == hipSuccess)
 			state[slot] = RECORDED;
 		else
@@ -187,6 +208,14 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		p->nleaves = (int)words[3];
 	}
 	*plan = p;
+	return CORDIC_OK;
+}
+
+int cordic_plan_queue_info(const cordic_plan *plan, cordic_queue_info *info)
+{
+	if (!plan || !info)
+		return CORDIC_ERR_ARGS;
+	plan->queues.info(info);
 	return CORDIC_OK;
 }
 
@@ -510,6 +539,14 @@ int cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl)
 	return CORDIC_OK;
 }
 
+int cordic_table_queue_info(const cordic_table *tbl, cordic_queue_info *info)
+{
+	if (!tbl || !info)
+		return CORDIC_ERR_ARGS;
+	tbl->queues.info(info);
+	return CORDIC_OK;
+}
+
 void cordic_table_destroy(cordic_table *tbl)
 {
 	if (!tbl)
@@ -595,6 +632,14 @@ int cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core)
 	if (!h->queues.alloc())
 		(void)hipGetLastError();
 	*core = h;
+	return CORDIC_OK;
+}
+
+int cordic_quad_queue_info(const cordic_quad *core, cordic_queue_info *info)
+{
+	if (!core || !info)
+		return CORDIC_ERR_ARGS;
+	core->queues.info(info);
 	return CORDIC_OK;
 }
 
@@ -872,25 +917,6 @@ size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_wor
 	return build_seed_table(*cfg, CORDIC_SEED_STAGES, buf, cap_words);
 }
 
-// Host-buffer conveniences.  Every HIP call is checked; buffers are released
-// on all paths.
-namespace {
-struct DevBuf {
-	void *p = nullptr;
-	~DevBuf() { if (p) (void)hipFree(p); }
-	bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess; }
-	template <typename T> T *as() { return static_cast<T *>(p); }
-};
-bool h2d(DevBuf &b, const void *src, size_t bytes)
-{
-	return b.alloc(bytes) && hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-}
-bool d2h(void *dst, DevBuf &b, size_t bytes)
-{
-	return hipMemcpy(dst, b.p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
-}
-}
-
 extern "C" {
 
 int cordic_abi_version(void) { return CORDIC_AMD_ABI_VERSION; }
@@ -1000,60 +1026,7 @@ int cordic_r2p(const cordic_config *cfg, size_t n, const int32_t *d_xval,
 	return launch_topolar(*cfg, n, d_xval, d_yval, d_omag, d_ophase, stream);
 }
 
-int cordic_p2r_host(const cordic_config *cfg, size_t n, const int32_t *xval,
-		const int32_t *yval, int xy_is_scalar, const uint32_t *phase,
-		int32_t *oxval, int32_t *oyval)
-{
-	if (!cfg || !xval || !yval || !phase || !oxval || !oyval)
-		return CORDIC_ERR_ARGS;
-	if (n == 0)
-		return CORDIC_OK;
-	const size_t bytes = n * sizeof(int32_t);
-	DevBuf dph, dx, dy, dox, doy;
-	if (!h2d(dph, phase, bytes) || !dox.alloc(bytes) || !doy.alloc(bytes))
-		return CORDIC_ERR_DEVICE;
-	int rc;
-	if (xy_is_scalar) {
-		rc = cordic_p2r_const(cfg, n, xval[0], yval[0], dph.as<uint32_t>(),
-				dox.as<int32_t>(), doy.as<int32_t>(), nullptr);
-	} else {
-		if (!h2d(dx, xval, bytes) || !h2d(dy, yval, bytes))
-			return CORDIC_ERR_DEVICE;
-		rc = cordic_p2r(cfg, n, dx.as<int32_t>(), dy.as<int32_t>(),
-				dph.as<uint32_t>(), dox.as<int32_t>(),
-				doy.as<int32_t>(), nullptr);
-	}
-	if (rc != CORDIC_OK)
-		return rc;
-	if (hipDeviceSynchronize() != hipSuccess)
-		return CORDIC_ERR_DEVICE;
-	if (!d2h(oxval, dox, bytes) || !d2h(oyval, doy, bytes))
-		return CORDIC_ERR_DEVICE;
-	return CORDIC_OK;
-}
-
-int cordic_r2p_host(const cordic_config *cfg, size_t n, const int32_t *xval,
-		const int32_t *yval, int32_t *omag, uint32_t *ophase)
-{
-	if (!cfg || !xval || !yval || !omag || !ophase)
-		return CORDIC_ERR_ARGS;
-	if (n == 0)
-		return CORDIC_OK;
-	const size_t bytes = n * sizeof(int32_t);
-	DevBuf dx, dy, dm, dp;
-	if (!h2d(dx, xval, bytes) || !h2d(dy, yval, bytes) || !dm.alloc(bytes)
-			|| !dp.alloc(bytes))
-		return CORDIC_ERR_DEVICE;
-	int rc = cordic_r2p(cfg, n, dx.as<int32_t>(), dy.as<int32_t>(),
-			dm.as<int32_t>(), dp.as<uint32_t>(), nullptr);
-	if (rc != CORDIC_OK)
-		return rc;
-	if (hipDeviceSynchronize() != hipSuccess)
-		return CORDIC_ERR_DEVICE;
-	if (!d2h(omag, dm, bytes) || !d2h(ophase, dp, bytes))
-		return CORDIC_ERR_DEVICE;
-	return CORDIC_OK;
-}
+// cordic_p2r_host / cordic_r2p_host: cordic_host.cpp (chunked copy pipeline)
 
 int cordic_fill_phase_ramp(uint32_t *d_phase, size_t n, uint64_t index0,
 		int shift, void *stream)

@@ -876,7 +876,9 @@ __host__ __device__ inline uint32_t dt_lds_layout(const DtInfo &dt, uint32_t at,
 		const uint32_t bb = (uint32_t)dt.lv[g].nb * 8u;
 		at = (at + bb - 1u) & ~(bb - 1u);
 		if (bucket_base) bucket_base[g] = at;
-		at += bb;
+		// the leaf entries are read with ds_read_b128 / b96: 16-byte
+		// aligned also behind a single 8-byte bucket
+		at = (at + bb + 15u) & ~15u;
 		if (leaf_base) leaf_base[g] = at;
 		at += (uint32_t)dt.lv[g].nl * (uint32_t)dt_entry_dwords(dt.lv[g].t) * 4u;
 	}

@@ -57,6 +57,9 @@ struct Shard {
 	void	*buf[4] = {nullptr, nullptr, nullptr, nullptr};	// in0 in1 out0 out1
 	uint64_t cap = 0;		// words allocated per array
 	int	inputs = 0;
+	// words [0, written[a]) of input array a were supplied by the caller
+	// (cordic_group_write) since the array was last allocated or filled
+	uint64_t written[2] = {0, 0};
 	uint64_t *d_digest = nullptr;
 	hipEvent_t marks[kMaxMarks] = {};
 	hipEvent_t piece[kMaxChunks] = {};
@@ -146,12 +149,12 @@ struct cordic_group {
 	int	chunks = 1;
 	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
 	bool	placement = true;
-	// the job size the shards' input arrays were last filled for (0: not
-	// filled, kCallerFilled: cordic_group_write supplied them)
+	// the job size the shards' input arrays were last filled for by the fill
+	// kernels (0: not filled), and how many of them; what the CALLER wrote is
+	// tracked per shard and array (Shard::written)
 	uint64_t filled_total = 0;
 	int	filled_inputs = 0;
 };
-constexpr uint64_t kCallerFilled = ~(uint64_t)0;
 
 namespace {
 
@@ -452,6 +455,7 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			// whatever the inputs held is gone
 			s.cap = 0;
 			s.inputs = 0;
+			s.written[0] = s.written[1] = 0;
 			g->filled_total = 0;
 			g->filled_inputs = 0;
 		}
@@ -541,10 +545,18 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 	DeviceScope scope;
 	if (int rc = ensure(g, n_total, inputs))
 		return rc;
-	// jobs that read input arrays need them filled for THIS job size
-	if (inputs > 0 && g->filled_total != kCallerFilled &&
-	    (g->filled_total != n_total || g->filled_inputs < inputs))
-		return CORDIC_ERR_ARGS;
+	// jobs that read input arrays need EVERY one of them, on every local
+	// shard, either filled for THIS job size or written by the caller over
+	// the shard's whole share
+	for (const Shard &s : g->shards) {
+		uint64_t start, cnt;
+		shard_span(n_total, s.index, g->total, &start, &cnt);
+		for (int a = 0; a < inputs; a++) {
+			const bool filled = g->filled_total == n_total && a < g->filled_inputs;
+			if (!filled && s.written[a] < cnt)
+				return CORDIC_ERR_ARGS;
+		}
+	}
 	const bool forward = g->root >= 0 || g->rroot >= 0;
 	const int chunks = forward ? g->chunks : 1;
 	for (Shard &s : g->shards) {
@@ -786,6 +798,8 @@ int cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift)
 				(size_t)cnt, start, shift, s.compute))
 			return rc;
 	}
+	for (Shard &s : grp->shards)
+		s.written[0] = 0;		// overwritten by the ramp
 	grp->filled_total = n_total;
 	grp->filled_inputs = 1;
 	return CORDIC_OK;
@@ -809,6 +823,8 @@ int cordic_group_fill_iq_ramp(cordic_group *grp, uint64_t n_total, uint32_t mulx
 				mulx, muly, bits, s.compute))
 			return rc;
 	}
+	for (Shard &s : grp->shards)
+		s.written[0] = s.written[1] = 0;
 	grp->filled_total = n_total;
 	grp->filled_inputs = 2;
 	return CORDIC_OK;
@@ -1102,8 +1118,10 @@ int cordic_group_write(cordic_group *grp, int local_shard, int array,
 	    !ok(hipMemcpy(static_cast<uint32_t *>(s.buf[array]) + offset, src,
 			(size_t)count * 4, hipMemcpyDefault)))
 		return CORDIC_ERR_DEVICE;
-	if (array < 2)
-		grp->filled_total = kCallerFilled;	// the caller's own inputs
+	// the caller's own inputs: coverage grows as a prefix (pieces may come
+	// in any order as long as they join up)
+	if (array < 2 && offset <= s.written[array] && offset + count > s.written[array])
+		s.written[array] = offset + count;
 	return CORDIC_OK;
 }
 

@@ -753,8 +753,9 @@ int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 			else if (lj_ok && cfg.ww <= 40)
 				done = launch_pol_ljw(cfg.nlive, grid, st, kp, x, y, mag,
 						phase, n);
-			g_last_kernel = done ? CORDIC_KERNEL_LEFT_JUSTIFIED
-					     : CORDIC_KERNEL_UNROLLED;
+			// io16 is served by the unrolled narrow kernel, not topolar_lj
+			g_last_kernel = (done && !io16) ? CORDIC_KERNEL_LEFT_JUSTIFIED
+							: CORDIC_KERNEL_UNROLLED;
 			if (done)
 				;
 			else if (io16)

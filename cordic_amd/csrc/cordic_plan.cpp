@@ -260,7 +260,8 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 		// LDS the kernel needs for it (cordic_device.h: dt_lds_layout):
 		// buckets, aligned to their own size, then the leaf entries
 		lds_at = (lds_at + nb2 * 8 - 1) & ~(nb2 * 8 - 1);
-		lds_at += nb2 * 8 + nl * (size_t)dt_entry_dwords(t) * 4;
+		lds_at = (lds_at + nb2 * 8 + 15) & ~(size_t)15;
+		lds_at += nl * (size_t)dt_entry_dwords(t) * 4;
 		rmin = nmin; rmax = nmax; bias = nbias;
 	}
 	info.n = ngroups;

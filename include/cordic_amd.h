@@ -246,10 +246,33 @@ int	cordic_last_kernel(void);
  * results are bit-identical for every phase and nothing is cached across
  * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 11 live
  * stages) simply run the ordinary kernels.
+ *
+ * Tile queues and HIP graphs.  A plan (likewise a table / quad handle) owns a
+ * ring of tile-queue counter blocks; every launch takes one and the ring hands
+ * a block out again only behind the launch that used it (on the device: no
+ * host wait).  A launch issued while its stream is being CAPTURED keeps its
+ * block for the life of the handle, because the graph may be replayed at any
+ * time: a handle serves at most `captured_capacity` (208) captured launches;
+ * later ones still compute the same bits but sweep static chunks (-5...-8 %)
+ * and are counted in `fallback_launches`.  Re-capturing per shape or per
+ * epoch therefore wants a fresh handle now and then.  Two graph execs
+ * instantiated from the SAME captured graph share the captured node's block:
+ * do not run them concurrently (one exec replayed any number of times, or
+ * execs of separately captured graphs, are fine).
  */
 typedef struct cordic_plan cordic_plan;
 
+typedef struct cordic_queue_info {
+	int32_t	eager_slots;		/* blocks rotated among eager launches  */
+	int32_t	captured_capacity;	/* blocks captured launches may take    */
+	int32_t	captured_used;		/* ... and how many they have taken     */
+	uint64_t fallback_launches;	/* launches that got no block: static
+					 * sweep (ring exhausted by captures, or
+					 * every eager block claimed right now) */
+} cordic_queue_info;
+
 int	cordic_plan_create(const cordic_config *cfg, cordic_plan **plan);
+int	cordic_plan_queue_info(const cordic_plan *plan, cordic_queue_info *info);
 void	cordic_plan_destroy(cordic_plan *plan);
 const cordic_config *cordic_plan_config(const cordic_plan *plan);
 /* stages covered by the seed table (0 = none), its leaves and buckets */
@@ -308,9 +331,16 @@ int	cordic_plan_nco16(const cordic_plan *plan, size_t n,
  *   nbuckets x {bound-1, first_leaf}   (r = phase + 2^29 domain; at most one
  *            leaf boundary per bucket, 0x7fffffff where there is none)
  *   nleaves  x {direction pattern, offset + 2^29}
- * on the left-justified phase (phase << (32-PW)) after the octant fold.
- * Returns the number of words, or 0 if the core is not eligible / cap is too
- * small.  buf may be NULL to query eligibility only when cap is 0. */
+ * on the left-justified phase (phase << (32-PW)) after the octant fold,
+ * followed -- when the core has them and cap_words leaves room -- by the
+ * direction tails behind the seeds (cordic_plan_tail_info):
+ *   [0] groups  [1] bias of the first group  [2] bias behind the last  [3] 0,
+ *   then per group {stages, bucket shift, nbuckets, nleaves, 0, 0},
+ *   nbuckets x {bound-1, first_leaf}, nleaves x {direction pattern, offset}.
+ * Returns the number of words written (call with buf = NULL, cap_words = 0 for
+ * the full size), or 0 if the core is not eligible or cap_words does not hold
+ * even the seed part; a cap between the two returns the SEED PART ONLY -- size
+ * the buffer with the query call to get the tails. */
 size_t	cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words);
 
 /*
@@ -343,6 +373,7 @@ int	cordic_table_values(const cordic_table_config *cfg, int32_t *out,
 		size_t cap);
 int	cordic_table_create(const cordic_table_config *cfg, cordic_table **tbl);
 void	cordic_table_destroy(cordic_table *tbl);
+int	cordic_table_queue_info(const cordic_table *tbl, cordic_queue_info *info);
 /* d_val[i] = o_val of the core for i_phase = d_phase[i] (low PW bits) */
 int	cordic_table_lookup(const cordic_table *tbl, size_t n,
 		const uint32_t *d_phase, int32_t *d_val, void *stream);
@@ -404,6 +435,7 @@ int	cordic_quad_write_header(const cordic_quad_config *cfg, const char *name,
 		char *buf, size_t cap);
 int	cordic_quad_create(const cordic_quad_config *cfg, cordic_quad **core);
 void	cordic_quad_destroy(cordic_quad *core);
+int	cordic_quad_queue_info(const cordic_quad *core, cordic_queue_info *info);
 /* d_sin[i] = o_sin of the core for i_phase = d_phase[i] (low PW bits),
  * sign-extended OW-bit values */
 int	cordic_quad_lookup(const cordic_quad *core, size_t n,
@@ -533,11 +565,14 @@ int	cordic_group_range(const cordic_group *grp, uint64_t n_total, int shard,
 /* (re)allocate the shards' buffers for jobs of n_total samples with `inputs`
  * (0, 1 or 2) input arrays; job calls do this implicitly on first use */
 int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
-/* A job that READS input arrays (p2r_const: in0; r2p: in0, in1) requires them
- * to have been filled for the same n_total -- by cordic_group_fill_* or by
- * cordic_group_write -- since the shards' arrays were last (re)allocated:
- * growing the capacity discards what the inputs held, and such a job then
- * returns CORDIC_ERR_ARGS instead of computing on uninitialised memory.
+/* A job that READS input arrays (p2r_const: in0; r2p: in0, in1) requires
+ * EACH of them, on EVERY local shard, to hold data for that job: filled by
+ * cordic_group_fill_* for the same n_total, or written by the caller
+ * (cordic_group_write; pieces in any order that join up from offset 0) over
+ * the shard's whole share, since the arrays were last (re)allocated.  Growing
+ * the capacity discards what the inputs held, a fill discards what the caller
+ * wrote; a job whose inputs are not all there returns CORDIC_ERR_ARGS instead
+ * of computing on uninitialised memory.
  * Back-to-back jobs need no cordic_group_sync between them, also with
  * forwarding set: a job's kernels wait (in stream order, on the device) until
  * the previous job's pieces have left out0 / out1. */
@@ -724,13 +759,49 @@ int	cordic_quality_r2p_result(cordic_quality *q, cordic_r2p_quality *out);
 int	cordic_fill_circle(int32_t *d_x, int32_t *d_y, size_t n, uint64_t index0,
 		int lgnsamples, int iw, int pw, void *stream);
 
-/* Host-buffer conveniences: allocate, copy in, run, copy out, synchronise. */
+/* Host-array entry points: the same calls on arrays in HOST memory -- the
+ * reference bench's own containers (`int` arrays filled and read by the CPU,
+ * bench/cpp/cordic_tb.cpp:94-100,127-178; topolar_tb.cpp:93-99,143-187) -- for
+ * callers that do not want to touch HIP.  Each call is a chunked copy pipeline
+ * (16 MiB per array and chunk, three slots, private upload / run / download
+ * streams chained by events): chunk k+1 uploads and chunk k-1 downloads while
+ * chunk k computes, constant vectors (xy_is_scalar) run the table-seeded plan,
+ * and only the pipeline's own streams are synchronised before the call
+ * returns (the results are then in the caller's arrays; other streams of the
+ * process are never stalled).  The kernels are ~100x faster than PCIe, so the
+ * rate is the interconnect's:
+ *   - arrays from cordic_host_alloc (or hipHostMalloc / hipHostRegister) are
+ *     DMA'd in place: the call runs at the PCIe rate of the busier direction
+ *     (p2r with constant vectors: 4 B up, 8 B down per sample);
+ *   - pageable arrays (malloc / new) are staged through pinned buffers by a
+ *     pool of host threads (CORDIC_HOST_THREADS, default 6): bounded by the
+ *     host's memcpy rate.
+ * Inputs and outputs may mix the two kinds.  The pipeline (streams, 3 x 5
+ * device arrays, staging, threads, plan) is created on first use per device,
+ * kept until cordic_host_release() or process exit, and serialises concurrent
+ * host-array calls on its device. */
 int	cordic_p2r_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval, int xy_is_scalar,
 		const uint32_t *phase, int32_t *oxval, int32_t *oyval);
 int	cordic_r2p_host(const cordic_config *cfg, size_t n,
 		const int32_t *xval, const int32_t *yval,
 		int32_t *omag, uint32_t *ophase);
+/* pinned host memory for the arrays of the calls above (hipHostMalloc) */
+int	cordic_host_alloc(void **p, size_t bytes);
+void	cordic_host_free(void *p);
+/* drop the current device's cached pipeline (memory, streams, threads) */
+void	cordic_host_release(void);
+/* what the most recent host-array call on the current device did */
+typedef struct cordic_host_stats {
+	uint64_t samples;
+	int32_t	chunks, chunk_samples;
+	int32_t	staged_inputs;		/* input arrays that were pageable   */
+	int32_t	staged_outputs;		/* output arrays that were pageable  */
+	int32_t	copy_threads;		/* host threads that staged (0: none) */
+	int32_t	seeded_plan;		/* 1: constant vectors, plan kernel  */
+	double	seconds;		/* wall time inside the call         */
+} cordic_host_stats;
+int	cordic_host_last_stats(cordic_host_stats *out);
 
 /* ------------------------------------------------ device-side test inputs */
 

@@ -974,6 +974,54 @@ def test_graph_replays_overlap_eager_launches_of_the_same_plan():
 
 
 @pytest.mark.gpu
+def test_queue_ring_bookkeeping_is_visible_and_survives_failed_launches():
+    """cordic_plan_queue_info: captured launches take a block each for the
+    life of the handle (208 of them), later ones sweep static chunks and are
+    counted; a launch that FAILS (null output: CORDIC_ERR_ARGS) must leave its
+    block's pending event in place (round-3 advice), so results stay complete
+    when many streams share the plan right after failures."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    q = plan.queue_info
+    assert q == {"eager_slots": 48, "captured_capacity": 208,
+                 "captured_used": 0, "fallback_launches": 0}
+    n = 1 << 22
+    x0 = (1 << 31) - 1
+    rng = np.random.RandomState(21)
+    ph = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    rx, ry = O.rotate(ocfg, x0, 0, ph)
+    dph = dev_i32(ph)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+    outs = [[torch.zeros(n, dtype=torch.int32, device=DEV) for _ in range(2)]
+            for _ in range(4)]
+    for rep in range(40):           # the ring wraps three times
+        for st, (a, b) in zip(streams, outs):
+            plan.p2r_const(x0, 0, dph, a, b, stream=st)
+            if rep % 5 == 0:        # a failing launch between good ones
+                rc = ca.lib().cordic_plan_p2r_const(
+                    plan._h, n, x0, 0, dph.data_ptr(), None, None,
+                    st.cuda_stream)
+                assert rc == ca.ERR_ARGS
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert np.array_equal(to_np(a), rx) and np.array_equal(to_np(b), ry)
+    assert plan.queue_info["fallback_launches"] == 0
+    # captures: 3 nodes in one graph
+    gx = torch.zeros(n, dtype=torch.int32, device=DEV)
+    gy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(3):
+            plan.p2r_const(x0, 0, dph, gx, gy)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(to_np(gx), rx) and np.array_equal(to_np(gy), ry)
+    q = plan.queue_info
+    assert q["captured_used"] == 3 and q["fallback_launches"] == 0
+    plan.close()
+
+
+@pytest.mark.gpu
 def test_the_fast_paths_are_the_ones_that_run():
     """cordic_last_kernel: BASELINE's cores land on the kernels the bench
     reports (a silently slower fallback would still be bit-exact)."""

@@ -336,6 +336,32 @@ def test_a_job_needs_inputs_filled_for_its_own_size():
     g2.p2r_const(4096, AMP, 0)
     assert np.array_equal(g2.read(0, g2.OUT0, 0, 4096), rx[:4096])
     g.close(); g2.close()
+    # ... but per shard and per array (round-3 advice): one write does not
+    # vouch for the other shard, for the rest of the array, nor for in1
+    g3 = ca.Group(cfg, devices=[0, 0])
+    g3.reserve(8192, 1)
+    g3.write(0, g3.IN0, 0, np.arange(4096, dtype=np.uint32))
+    with pytest.raises(ca.CordicError):
+        g3.p2r_const(8192, AMP, 0)                    # shard 1 never written
+    g3.write(1, g3.IN0, 2048, np.arange(2048, dtype=np.uint32))
+    with pytest.raises(ca.CordicError):
+        g3.p2r_const(8192, AMP, 0)                    # shard 1: hole at 0..2047
+    g3.write(1, g3.IN0, 0, np.arange(2048, dtype=np.uint32))
+    with pytest.raises(ca.CordicError):
+        g3.p2r_const(8192, AMP, 0)   # pieces must join up from offset 0 in order
+    g3.write(1, g3.IN0, 2048, np.arange(2048, dtype=np.uint32) + 2048)
+    g3.p2r_const(8192, AMP, 0)
+    assert np.array_equal(g3.read(1, g3.OUT0, 0, 4096), rx[:4096])
+    g3.close()
+    r2p_cfg, _ = both(ca.R2P, 24, 24, 2, -1, 20)
+    g4 = ca.Group(r2p_cfg, devices=[0])
+    g4.reserve(4096, 2)
+    g4.write(0, g4.IN0, 0, np.arange(4096, dtype=np.uint32))
+    with pytest.raises(ca.CordicError):
+        g4.r2p(4096)                                  # in1 unfilled
+    g4.write(0, g4.IN1, 0, np.arange(4096, dtype=np.uint32))
+    g4.r2p(4096)
+    g4.close()
 
 
 # ------------------------------------------------ two ranks, one GPU (shim)

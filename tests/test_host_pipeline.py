@@ -1,0 +1,126 @@
+"""cordic_p2r_host / cordic_r2p_host (cordic_host.cpp): the chunked copy
+pipeline behind the host-array entry points -- ragged sizes around the chunk
+boundaries, pageable / pinned / mixed arrays, constant and per-sample vectors,
+bit for bit against the oracle; and that a busy stream of the caller is never
+waited for."""
+import time
+
+import numpy as np
+import pytest
+
+import cordic_amd as ca
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 4 << 20
+
+
+def both(*a):
+    return ca.Config.from_cli(*a), O.config_cli(*a)
+
+
+def _inputs(n, iw, seed):
+    rng = np.random.RandomState(seed)
+    lo, hi = -(1 << (iw - 1)), (1 << (iw - 1))
+    x = rng.randint(lo, hi, size=n, dtype=np.int64).astype(np.int32)
+    y = rng.randint(lo, hi, size=n, dtype=np.int64).astype(np.int32)
+    ph = rng.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    return x, y, ph
+
+
+@pytest.mark.parametrize("n", [1, 3, 1000, (1 << 18) + 1, CHUNK - 1, CHUNK,
+                               CHUNK + 5, 3 * CHUNK + 77])
+def test_pageable_arrays_every_size(n):
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    x, y, ph = _inputs(n, 32, n & 0xffff)
+    a = ca.p2r_host(cfg, x, y, ph)
+    st = ca.host_last_stats()
+    assert st["samples"] == n and st["chunks"] == -(-n // CHUNK)
+    assert st["seeded_plan"] == 0
+    if n * 4 > 1 << 20:
+        assert st["staged_inputs"] == 3 and st["staged_outputs"] == 2
+        assert st["copy_threads"] >= 1
+    b = O.rotate(ocfg, x, y, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = ca.p2r_host(cfg, 2**31 - 1, 0, ph)
+    assert ca.host_last_stats()["seeded_plan"] == 1
+    b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+    x, y, _ = _inputs(n, 24, n + 1)
+    a = ca.r2p_host(cfg, x, y)
+    b = O.topolar(ocfg, x, y)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("pin_in,pin_out", [(True, True), (True, False),
+                                            (False, True)])
+def test_pinned_and_mixed_arrays(pin_in, pin_out):
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 24)
+    n = 5 * CHUNK + 12345
+    _, _, ph = _inputs(n, 32, 7)
+    keep = []
+    if pin_in:
+        h = ca.HostArray(n, "uint32"); keep.append(h)
+        h.array[:] = ph
+        ph_in = h.array
+    else:
+        ph_in = ph
+    out = None
+    if pin_out:
+        ox, oy = ca.HostArray(n), ca.HostArray(n); keep += [ox, oy]
+        ox.array[:] = -1; oy.array[:] = -1
+        out = (ox.array, oy.array)
+    a = ca.p2r_host(cfg, 2**31 - 1, 0, ph_in, out=out)
+    st = ca.host_last_stats()
+    assert st["staged_inputs"] == (0 if pin_in else 1)
+    assert st["staged_outputs"] == (0 if pin_out else 2)
+    b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # a second, different core through the same cached pipeline: new plan
+    cfg2, ocfg2 = both(ca.P2R, 32, 32, 2, 32, 16)
+    a = ca.p2r_host(cfg2, 12345, -777, ph_in, out=out)
+    b = O.rotate(ocfg2, 12345, -777, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for h in keep:
+        h.close()
+
+
+def test_other_streams_of_the_caller_are_not_waited_for():
+    """Round 3 synchronised the whole DEVICE; now only the pipeline's own
+    streams: a long-running stream of the caller must still be busy when the
+    host-array call returns."""
+    import torch
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    big_cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 24).with_flags(ca.FLAG_NO_SEED)
+    n_big = 1 << 28
+    phs = torch.zeros(n_big, dtype=torch.int32, device=dev)
+    oa = torch.empty_like(phs); ob = torch.empty_like(phs)
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    for _ in range(40):                     # ~40 x 1.5 ms of queued kernels
+        ca.p2r_const(big_cfg, 1, 0, phs, oa, ob, stream=side)
+    done.record(side)
+    _, _, ph = _inputs(1000, 32, 3)
+    t0 = time.perf_counter()
+    a = ca.p2r_host(cfg, 2**31 - 1, 0, ph)
+    dt = time.perf_counter() - t0
+    still_busy = not done.query()
+    torch.cuda.synchronize()
+    b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert still_busy, "the host-array call waited for an unrelated stream (%.1f ms)" % (dt * 1e3)
+
+
+def test_release_and_reuse():
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    _, _, ph = _inputs(CHUNK + 9, 32, 4)
+    a = ca.p2r_host(cfg, 5, 6, ph)
+    ca.host_release()
+    b = ca.p2r_host(cfg, 5, 6, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    r = O.rotate(ocfg, 5, 6, ph)
+    assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
