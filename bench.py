@@ -469,7 +469,7 @@ KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
              "cfg1": "rotator_seeded", "cfg3": "topolar_lj",
              "nat32": "rotator_seeded", "nat24": "rotator_seeded",
              "nat16": "rotator_seeded", "natr2p24": "topolar_lj",
-             "p2rxy": "rotator_unrolled", "quadtbl": "quad_lookup",
+             "p2rxy": "rotator_xydir", "quadtbl": "quad_lookup",
              "quadtbl24": "quad_lookup", "sintbl": "table_lookup",
              "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup",
              "qtrtbl24": "table_lookup"}
@@ -490,6 +490,8 @@ def measure_pmc(args):
         return {"error": "rocprofv3 not found"}
     kern = KERNEL_OF.get(args.workload)
     if args.no_seed and kern == "rotator_seeded":
+        kern = "rotator_unrolled"
+    if args.no_tails and kern == "rotator_xydir":
         kern = "rotator_unrolled"
     base = [sys.executable, os.path.abspath(__file__), "--workload",
             args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
@@ -1469,8 +1471,12 @@ def run_direct(args, w, launch):
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
             phase.random_(-2**31, 2**31 - 1, generator=gen)
 
+        # through a plan: the stage directions are looked up (cordic_xydir.h);
+        # --no-tails (CORDIC_FLAG_NO_TAILS) keeps cordic_p2r's kernel for A/B
+        plan = ca.Plan(cfg.with_flags(ca.FLAG_NO_TAILS) if args.no_tails else cfg)
+
         def step():
-            ca.p2r(cfg, xin, yin, phase, a, b)
+            plan.p2r(xin, yin, phase, a, b)
     elif w["kind"] == "r2p":
         xin = arrays.tensor(0, torch.int32)
         yin = arrays.tensor(1, torch.int32)
@@ -1628,7 +1634,10 @@ def run_direct(args, w, launch):
                 "iw": cfg.iw, "ow": cfg.ow, "ww": cfg.ww, "pw": cfg.pw,
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
-                    "unrolled" if (args.no_seed or w["kind"] in ("r2p", "p2rxy"))
+                    ("directions(%s)" % "+".join(map(str, plan.dir_groups))
+                     if plan.dir_groups and not args.no_tails else "unrolled")
+                    if w["kind"] == "p2rxy" else
+                    "unrolled" if (args.no_seed or w["kind"] == "r2p")
                     else "seeded(%d)+unrolled" % plan.seed_info["stages"]),
                 "input": args.input,
                 "parallelism": "shard%d" % world,

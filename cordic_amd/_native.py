@@ -110,9 +110,15 @@ ABI = {
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "cordic_seed_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
+    "cordic_dir_table": (C.c_size_t, [_cfgp, _u32p, C.c_size_t]),
     "cordic_plan_tail_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
     "cordic_plan_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_plan_p2r": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "cordic_plan_dir_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32)]),
     "cordic_table_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_quad_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_device_count": (C.c_int, []),
@@ -366,6 +372,23 @@ class Plan:
                                            C.byref(c)),
                "cordic_plan_seed_info")
         return dict(stages=a.value, nleaves=b.value, nbuckets=c.value)
+
+    @property
+    def dir_groups(self):
+        """stages per looked-up group of the per-sample-vector path
+        (cordic_plan_p2r); [] = that feed runs cordic_p2r's kernel"""
+        n = C.c_int32()
+        st = (C.c_int32 * 5)()
+        _check(lib().cordic_plan_dir_info(self._h, C.byref(n), st),
+               "cordic_plan_dir_info")
+        return [int(st[g]) for g in range(n.value)]
+
+    def p2r(self, x, y, phase, ox, oy, n=None, stream=None):
+        """per-sample vectors through the plan (directions looked up)"""
+        n = phase.numel() if n is None else n
+        _check(lib().cordic_plan_p2r(self._h, n, _ptr(x), _ptr(y), _ptr(phase),
+                                     _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_plan_p2r")
 
     @property
     def queue_info(self):
@@ -948,6 +971,7 @@ def fill_circle(x, y, index0, lgnsamples, iw, pw, n=None, stream=None):
 
 
 KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED = 1, 2, 3, 4
+KERNEL_DIRECTIONS = 5
 
 
 def last_kernel():
@@ -961,6 +985,16 @@ def seed_table(cfg):
     cap = 4 + 4096 * 6 + 4 + 4 * (6 + 2 * 4096 + 2 * 256)
     buf = np.zeros(cap, dtype=np.uint32)
     n = lib().cordic_seed_table(cfg.ref, buf.ctypes.data_as(_u32p), cap)
+    return buf[:n].copy() if n else None
+
+
+def dir_table(cfg):
+    """Host-side direction tables of the per-sample-vector path (numpy
+    uint32 words) or None."""
+    import numpy as np
+    cap = 4 + 5 * (6 + 2 * 4096 + 2 * 256)
+    buf = np.zeros(cap, dtype=np.uint32)
+    n = lib().cordic_dir_table(cfg.ref, buf.ctypes.data_as(_u32p), cap)
     return buf[:n].copy() if n else None
 
 

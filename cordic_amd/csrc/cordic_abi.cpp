@@ -171,6 +171,8 @@ struct cordic_plan {
 	uint32_t *d_table = nullptr;	// device copy of the seed table
 	int m = 0, S = 0, nbuckets = 0, nleaves = 0;
 	DtInfo dt;			// direction tails behind the seeds (dt.n == 0: none)
+	uint32_t *d_dir = nullptr;	// direction tables for per-sample vectors
+	DxInfo dx;			// (dx.n == 0: none)
 	QueueRing queues;
 };
 
@@ -207,8 +209,47 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		p->nbuckets = (int)words[2];
 		p->nleaves = (int)words[3];
 	}
+	// direction tables for per-sample vectors (cordic_plan_p2r); independent
+	// of the seed table
+	{
+		std::vector<uint32_t> dw(4 + kDxMaxLevels * (6 + 2 * 4096 + 2 * 256));
+		const size_t dn = build_dir_table(*cfg, dw.data(), dw.size(), &p->dx);
+		if (dn && (hipMalloc((void **)&p->d_dir, dn * 4) != hipSuccess ||
+		    hipMemcpy(p->d_dir, dw.data(), dn * 4,
+				hipMemcpyHostToDevice) != hipSuccess)) {
+			(void)hipGetLastError();
+			if (p->d_dir) (void)hipFree(p->d_dir);
+			p->d_dir = nullptr;
+			p->dx = DxInfo{};	// not fatal: cordic_p2r's kernel serves
+		}
+	}
 	*plan = p;
 	return CORDIC_OK;
+}
+
+int cordic_plan_dir_info(const cordic_plan *plan, int32_t *ngroups, int32_t stages[5])
+{
+	if (!plan || !ngroups)
+		return CORDIC_ERR_ARGS;
+	*ngroups = plan->d_dir ? plan->dx.n : 0;
+	if (stages)
+		for (int g = 0; g < kDxMaxLevels; g++)
+			stages[g] = g < *ngroups ? plan->dx.lv[g].t : 0;
+	return CORDIC_OK;
+}
+
+int cordic_plan_p2r(const cordic_plan *plan, size_t n, const int32_t *d_xval,
+		const int32_t *d_yval, const uint32_t *d_phase, int32_t *d_oxval,
+		int32_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x = d_xval; j.y = d_yval; j.phase = d_phase;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	j.dir_table = plan->d_dir;
+	j.dx = plan->dx;
+	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
 int cordic_plan_queue_info(const cordic_plan *plan, cordic_queue_info *info)
@@ -225,6 +266,8 @@ void cordic_plan_destroy(cordic_plan *plan)
 		return;
 	if (plan->d_table)
 		(void)hipFree(plan->d_table);
+	if (plan->d_dir)
+		(void)hipFree(plan->d_dir);
 	plan->queues.release();
 	delete plan;
 }
@@ -903,6 +946,17 @@ int cordic_seq_violations(cordic_seq *s, uint64_t *count)
 int cordic_table_lds_mode(const cordic_table *tbl)
 {
 	return tbl ? tbl->lds_mode : CORDIC_ERR_ARGS;
+}
+
+size_t cordic_dir_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)
+{
+	if (!cfg)
+		return 0;
+	if (!buf || cap_words == 0) {
+		std::vector<uint32_t> tmp(4 + kDxMaxLevels * (6 + 2 * 4096 + 2 * 256));
+		return build_dir_table(*cfg, tmp.data(), tmp.size(), nullptr);
+	}
+	return build_dir_table(*cfg, buf, cap_words, nullptr);
 }
 
 size_t cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words)

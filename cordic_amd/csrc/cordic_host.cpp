@@ -44,8 +44,23 @@
 
 namespace {
 
-constexpr size_t kChunk = (size_t)4 << 20;	// samples per chunk and array
 constexpr int kSlots = 3;
+// samples per chunk and array: 2^22 (16 MiB) unless CORDIC_HOST_CHUNK_LOG2
+// says otherwise (18..26; read once, when the first pipeline is made)
+size_t chunk_samples()
+{
+	static const size_t v = [] {
+		int lg = 22;
+		if (const char *e = std::getenv("CORDIC_HOST_CHUNK_LOG2")) {
+			const int x = std::atoi(e);
+			if (x >= 18 && x <= 26)
+				lg = x;
+		}
+		return (size_t)1 << lg;
+	}();
+	return v;
+}
+#define kChunk (chunk_samples())
 constexpr size_t kDirectBytes = (size_t)1 << 20;	// small jobs: no staging
 
 bool ok(hipError_t e) { return e == hipSuccess; }
@@ -383,6 +398,16 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 		// are on the wire
 		if (host_retires && c + 1 >= (size_t)kSlots) {
 			if (!retire(retired++))
+				rc = CORDIC_ERR_DEVICE;
+		} else if (!host_retires && c + 1 >= (size_t)kSlots) {
+			// Nothing for the host to do (every array DMA'd in place) --
+			// but it must not run ahead: with all 3 x nc copies queued at
+			// once the copy engines serve them in submission order and a
+			// download that waits for its kernel holds up the uploads
+			// queued behind it (measured: 0.51 of the PCIe rate unpaced,
+			// profiles/r04/host_paths_first.json).  Same pacing as the
+			// staged path: chunk c-2 has landed before chunk c+1 is queued.
+			if (!ok(hipEventSynchronize(hp.slot[(c + 1) % kSlots].down)))
 				rc = CORDIC_ERR_DEVICE;
 		}
 	}

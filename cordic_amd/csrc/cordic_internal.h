@@ -175,6 +175,46 @@ struct DtInfo {
 	DtLevel	lv[kDtMaxLevels] = {};
 };
 
+// ---- direction tables for PER-SAMPLE vectors (cordic_plan_p2r, round 4).
+// The directions of ALL stages depend on the phase alone, whatever i_xval /
+// i_yval are (rtl/cordic.v:262-280): the first micro-rotation comes out of the
+// octant fold's multiply-adds (cordic_device.h: fold1), every later stage up
+// to kDtLastStage takes its multipliers from lookups over the residual phase,
+// in groups of at most kDxMaxT = 5 stages (<= 32 leaves: the lookups win on
+// unrelated phases too, so every row looks up); stages behind that run the
+// phase recurrence on the residual the last group leaves.
+constexpr int kDxMaxLevels = 5;
+constexpr int kDxMaxT = 5;
+constexpr int kDxFirst = 1;		// stages the fold performs
+constexpr int dx_covered(int nlive)
+{
+	const int r = nlive - kDxFirst, lim = kDtLastStage - kDxFirst;
+	return r < 0 ? 0 : (r < lim ? r : lim);
+}
+constexpr int dx_levels(int nlive) { return (dx_covered(nlive) + kDxMaxT - 1) / kDxMaxT; }
+constexpr int dx_size(int nlive, int level)
+{
+	const int n = dx_levels(nlive), c = dx_covered(nlive);
+	return n == 0 ? 0 : c / n + (level >= n - c % n ? 1 : 0);
+}
+constexpr int dx_first(int nlive, int level)	// stages before group `level`
+{
+	int done = kDxFirst;
+	for (int g = 0; g < level; g++) done += dx_size(nlive, g);
+	return done;
+}
+constexpr int dx_rest(int nlive) { return nlive - kDxFirst - dx_covered(nlive); }
+struct DxInfo {
+	int32_t	n = 0;			// groups (0: no table)
+	uint32_t bias0 = 0;		// u_0 = p_1 + bias0 (p_1: residual behind stage 1)
+	uint32_t bias_last = 0;
+	DtLevel	lv[kDxMaxLevels] = {};
+};
+// words: [0] n [1] bias0 [2] bias_last [3] 0, then per group {t, shift, nb, nl,
+// 0, 0}, nb x {bound-1, first_leaf}, nl x {pattern, off'} (as the tails)
+size_t	build_dir_table(const cordic_config &c, uint32_t *buf, size_t cap,
+		DxInfo *info);
+
 // ---- host: cordic_plan.cpp
 bool	seed_eligible(const cordic_config &c, int m);
 // `dt` (may be NULL) receives the direction tails appended behind the seed
@@ -207,6 +247,9 @@ struct RotatorJob {
 	const uint32_t *seed_table = nullptr;
 	int seed_m = 0, seed_S = 0, seed_nbuckets = 0, seed_nleaves = 0;
 	DtInfo	dt;			// direction tails of the plan (dt.n == 0: none)
+	// per-sample vectors: the plan's direction tables (device words + header)
+	const uint32_t *dir_table = nullptr;
+	DxInfo	dx;
 	// tile queue of the seeded kernel: CORDIC_QUEUE_BYTES of zeroed device
 	// memory that no other launch in flight uses (the kernel leaves it zeroed
 	// again: cordic_device.h queue_leave); NULL = static chunk-per-block sweep

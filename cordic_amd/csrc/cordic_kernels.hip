@@ -12,6 +12,7 @@
 #include "cordic_device.h"
 #include "cordic_internal.h"
 #include "cordic_launch.h"
+#include "cordic_xydir.h"
 
 namespace cordic_amd {
 // cordic_last_kernel(): which kernel family served this thread's most recent
@@ -617,6 +618,20 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		}
 		if (done)
 			g_last_kernel = CORDIC_KERNEL_SEEDED;
+		// per-sample vectors with a plan: directions looked up
+		// (cordic_xydir.h); cores / counts without an instance fall through
+		if (FEED == Feed::PhaseArray_XYArray && j.dir_table && j.dx.n > 0
+				&& !j.io16 && j.n >= (size_t)kVec && kp.post_mul == 0
+				&& kp.in_shl >= 1 && kp.in_shl <= 30 && cfg.ww <= 35
+				&& !cfg.needs_wrap
+				&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))) {
+			dev::DirArgs da{j.dir_table, j.dx};
+			const size_t lds = dev::dx_lds_layout(j.dx, nullptr, nullptr);
+			done = launch_xydir(cfg.ww == 35 ? 29 : 30, cfg.nlive, grid, st,
+					kp, da, j, lds);
+			if (done)
+				g_last_kernel = CORDIC_KERNEL_DIRECTIONS;
+		}
 		if (!done && j.n >= (size_t)kVec) {
 			g_last_kernel = CORDIC_KERNEL_UNROLLED;
 			const int ngen = general_stages_for(cfg.ww);

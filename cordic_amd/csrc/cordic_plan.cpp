@@ -279,4 +279,126 @@ size_t build_seed_table(const cordic_config &c, int m, uint32_t *buf, size_t cap
 	return words + tail.size();
 }
 
+// Direction tables for per-sample vectors (cordic_internal.h: dx_*).  The
+// octant fold leaves p0 in [-2^29, 2^29) and performs stage 1 itself
+// (p1 = p0 -/+ a_0); group g then covers dx_size stages behind dx_first, its
+// table indexed by the biased residual u >= 0.
+size_t build_dir_table(const cordic_config &c, uint32_t *buf, size_t cap,
+		DxInfo *out)
+{
+	if (out)
+		*out = DxInfo{};
+	if (c.mode != CORDIC_P2R && c.mode != CORDIC_SP2R)
+		return 0;
+	if (c.needs_wrap || c.ww > 35 || c.nlive < kDxFirst + 2 || c.nlive > 40)
+		return 0;
+	const int ngroups = dx_levels(c.nlive);
+	if (ngroups < 1 || ngroups > kDxMaxLevels)
+		return 0;
+	const int lsh = 32 - c.pw;
+	// residual range behind stage 1
+	const int64_t LO = -((int64_t)1 << 29), HI = (int64_t)1 << 29;
+	const int64_t a0 = (int64_t)(c.angle[0] << lsh);
+	if (a0 <= 0 || a0 >= HI)
+		return 0;
+	int64_t rmin = std::min(LO + a0, -a0), rmax = std::max(a0 - 1, HI - 1 - a0);
+	int64_t bias = -rmin;
+	std::vector<uint32_t> tail(4, 0u);
+	DxInfo info;
+	info.bias0 = (uint32_t)bias;
+	size_t lds_at = 0;
+	for (int g = 0; g < ngroups; g++) {
+		const int t = dx_size(c.nlive, g), s0 = dx_first(c.nlive, g);
+		uint32_t a2[8];
+		for (int i = 0; i < t; i++)
+			a2[i] = c.angle[s0 + i] << lsh;
+		std::vector<Leaf> lv;
+		split(a2, t, 0, rmin, rmax + 1, 0, 0u, lv);
+		std::sort(lv.begin(), lv.end(),
+			[](const Leaf &a, const Leaf &b) { return a.lo < b.lo; });
+		const size_t nl = lv.size();
+		if (nl == 0 || nl > 256)
+			return 0;
+		const int64_t umax = rmax + bias;		// u in [0, umax]
+		if (umax >= ((int64_t)1 << 30))
+			return 0;
+		int S2 = 26;
+		std::vector<int> cnt;
+		for (; S2 >= 4; S2--) {
+			cnt.assign((size_t)(umax >> S2) + 1, 0);
+			int worst = 0;
+			for (size_t j = 1; j < nl; j++) {
+				const int64_t u = lv[j].lo + bias;
+				if (u & (((int64_t)1 << S2) - 1))
+					worst = std::max(worst, ++cnt[(size_t)(u >> S2)]);
+			}
+			if (worst <= 1)
+				break;
+		}
+		if (S2 < 4)
+			return 0;
+		size_t nb2 = 1;
+		while (nb2 < (size_t)(umax >> S2) + 1)
+			nb2 <<= 1;
+		if (nb2 > 4096)
+			return 0;
+		DtLevel &d = info.lv[g];
+		d.t = t; d.shift = S2; d.nb = (int32_t)nb2; d.nl = (int32_t)nl;
+		d.word = (int32_t)(tail.size() + 6);
+		const uint32_t hdr[6] = {(uint32_t)t, (uint32_t)S2, (uint32_t)nb2,
+				(uint32_t)nl, 0u, 0u};
+		tail.insert(tail.end(), hdr, hdr + 6);
+		const size_t b0 = tail.size();
+		tail.resize(b0 + nb2 * 2);
+		size_t j = 0;
+		for (size_t b = 0; b < nb2; b++) {
+			const int64_t start = ((int64_t)b << S2) - bias;	// residual
+			while (j + 1 < nl && lv[j + 1].lo <= start)
+				j++;
+			tail[b0 + 2 * b + 0] = 0x7fffffffu;
+			tail[b0 + 2 * b + 1] = (uint32_t)j;
+		}
+		for (size_t k = 1; k < nl; k++) {
+			const int64_t u = lv[k].lo + bias;
+			if ((u & (((int64_t)1 << S2) - 1)) == 0)
+				continue;
+			tail[b0 + 2 * (size_t)(u >> S2)] = (uint32_t)(u - 1);
+		}
+		int64_t nmin = 0, nmax = 0;
+		bool first = true;
+		for (const Leaf &l : lv) {
+			const int64_t a = l.lo - l.off, b = l.hi - 1 - l.off;
+			if (first || a < nmin) nmin = a;
+			if (first || b > nmax) nmax = b;
+			first = false;
+		}
+		const int64_t nbias = -nmin;
+		for (const Leaf &l : lv) {
+			tail.push_back(l.pattern);
+			tail.push_back((uint32_t)(l.off + bias - nbias));	// u_next = u - this
+		}
+		lds_at = (lds_at + nb2 * 8 - 1) & ~(nb2 * 8 - 1);
+		lds_at = (lds_at + nb2 * 8 + 15) & ~(size_t)15;
+		lds_at += nl * (size_t)dt_entry_dwords(t) * 4;
+		rmin = nmin; rmax = nmax; bias = nbias;
+	}
+	// the recurrence behind the last group carries the residual as a 29-bit
+	// signed number scaled by 2^31 (cordic_device.h: RotChainLJ)
+	if (dx_rest(c.nlive) > 0 && (rmin < -((int64_t)1 << 28) || rmax >= ((int64_t)1 << 28)))
+		return 0;
+	if (lds_at + 256 > 60 * 1024)		// (with the fold's rows; two blocks per CU at least)
+		return 0;
+	info.n = ngroups;
+	info.bias_last = (uint32_t)bias;
+	tail[0] = (uint32_t)ngroups;
+	tail[1] = info.bias0;
+	tail[2] = info.bias_last;
+	if (!buf || tail.size() > cap)
+		return 0;
+	std::memcpy(buf, tail.data(), tail.size() * 4);
+	if (out)
+		*out = info;
+	return tail.size();
+}
+
 } // namespace cordic_amd

@@ -227,7 +227,9 @@ enum cordic_kernel_family {
 	CORDIC_KERNEL_GENERIC		= 1,	/* run-time stage loop            */
 	CORDIC_KERNEL_UNROLLED		= 2,	/* unrolled, one lane = 4 samples */
 	CORDIC_KERNEL_SEEDED		= 3,	/* plan: seed table + unrolled    */
-	CORDIC_KERNEL_LEFT_JUSTIFIED	= 4	/* r2p: topolar_lj / topolar_ljw  */
+	CORDIC_KERNEL_LEFT_JUSTIFIED	= 4,	/* r2p: topolar_lj / topolar_ljw  */
+	CORDIC_KERNEL_DIRECTIONS	= 5	/* plan, per-sample vectors: stage
+						   directions looked up            */
 };
 int	cordic_last_kernel(void);
 
@@ -284,6 +286,22 @@ int	cordic_plan_seed_info(const cordic_plan *plan, int32_t *stages,
  * CORDIC_FLAG_NO_TAILS still report the table; the launch ignores it.)         */
 int	cordic_plan_tail_info(const cordic_plan *plan, int32_t *ngroups,
 		int32_t stages[4]);
+
+/* cordic_p2r through a plan: per-sample i_xval / i_yval / i_phase.  The
+ * rotation directions depend on the phase alone (rtl/cordic.v:262-280), so the
+ * plan's direction tables serve this feed too: every stage behind the first
+ * reads its multipliers instead of running the phase recurrence (4 instead of
+ * 7 instructions per micro-rotation; the vector state itself cannot be
+ * tabulated, every stage still runs).  Same results as cordic_p2r, bit for
+ * bit; cores without such a table (WW > 35, reachable overflow, stage counts
+ * without an instance) run cordic_p2r's kernel.  cordic_plan_dir_info: the
+ * number of looked-up stage groups (0: none) and their sizes. */
+int	cordic_plan_p2r(const cordic_plan *plan, size_t n,
+		const int32_t *d_xval, const int32_t *d_yval,
+		const uint32_t *d_phase, int32_t *d_oxval, int32_t *d_oyval,
+		void *stream);
+int	cordic_plan_dir_info(const cordic_plan *plan, int32_t *ngroups,
+		int32_t stages[5]);
 
 int	cordic_plan_p2r_const(const cordic_plan *plan, size_t n,
 		int32_t xval, int32_t yval, const uint32_t *d_phase,
@@ -342,6 +360,17 @@ int	cordic_plan_nco16(const cordic_plan *plan, size_t n,
  * even the seed part; a cap between the two returns the SEED PART ONLY -- size
  * the buffer with the query call to get the tails. */
 size_t	cordic_seed_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words);
+/* Host only: the direction tables of the per-sample-vector path
+ * (cordic_plan_p2r) as 32-bit words
+ *   [0] groups  [1] bias0  [2] bias behind the last group  [3] 0, then per group
+ *   {stages, bucket shift, nbuckets, nleaves, 0, 0},
+ *   nbuckets x {bound-1, first_leaf}, nleaves x {direction pattern, offset}:
+ * with p1 the residual phase behind the first micro-rotation (left-justified),
+ * u = p1 + bias0 indexes group 0; the leaf of u holds the directions of the
+ * group's stages (first stage = MSB, 1 = residual >= 0) and u - offset indexes
+ * the next group.  Returns the number of words (buf = NULL, cap_words = 0: the
+ * size), 0 if the core has no such table or cap_words is too small. */
+size_t	cordic_dir_table(const cordic_config *cfg, uint32_t *buf, size_t cap_words);
 
 /*
  * Table cores (row F4): the reference's plain and quarter-wave sine tables,

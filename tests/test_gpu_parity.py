@@ -973,6 +973,95 @@ def test_graph_replays_overlap_eager_launches_of_the_same_plan():
     plan.close()
 
 
+def _gpu_plan_p2r_xy(plan, x, y, ph):
+    n = ph.size
+    dx, dy, dph = dev_i32(x), dev_i32(y), dev_i32(ph)
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    plan.p2r(dx, dy, dph, ox, oy)
+    torch.cuda.synchronize()
+    return to_np(ox), to_np(oy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,groups", [
+    ((ca.P2R, 32, 32, 2, 32, 16), [5, 5, 5]),          # p2rxy: WW35, LJ 29
+    ((ca.P2R, 32, 32, 2, 32, 24), [4, 4, 5, 5, 5]),    # cfg4's core
+    ((ca.P2R, 32, 32, 2, 32, -1), [4, 5, 5, 5, 5]),    # gencordic's own: 29 st.
+    ((ca.P2R, 24, 24, 2, -1, -1), [4, 5, 5, 5, 5]),    # WW27 PW31 27 st., LJ 30
+    ((ca.P2R, 16, 16, 2, -1, -1), [4, 4, 5, 5]),       # WW19 PW23 19 st.
+    ((ca.P2R, 30, 30, 2, 32, 20), [4, 5, 5, 5]),       # WW33, LJ 30
+])
+def test_plan_p2r_per_sample_vectors_with_looked_up_directions(args, groups):
+    """cordic_plan_p2r: per-sample x / y / phase with the stage directions
+    read from the plan's tables (cordic_xydir.h) -- random inputs, the corners
+    of the ports, and unit-step phase ramps across EVERY leaf boundary of
+    every group, bit for bit against the oracle and against cordic_p2r."""
+    cfg, ocfg = both(*args)
+    plan = ca.Plan(cfg)
+    assert plan.dir_groups == groups
+    rng = np.random.RandomState(sum(groups) + cfg.ww)
+    x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, 100003)
+    a = _gpu_plan_p2r_xy(plan, x, y, ph)
+    assert ca.last_kernel() == ca.KERNEL_DIRECTIONS
+    b = O.rotate(ocfg, x, y, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # extreme vectors
+    lo, hi = -(1 << (cfg.iw - 1)), (1 << (cfg.iw - 1)) - 1
+    for xv, yv in ((hi, hi), (lo, lo), (lo, hi), (hi, 0), (0, lo), (0, 0), (1, -1)):
+        xs = np.full(ph.size, xv, dtype=np.int32)
+        ys = np.full(ph.size, yv, dtype=np.int32)
+        a = _gpu_plan_p2r_xy(plan, xs, ys, ph)
+        b = O.rotate(ocfg, xs, ys, ph)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (xv, yv)
+    # every direction boundary of the first stages: the phases whose residual
+    # changes sign at stage k are +/- partial sums of the arctan table; walk
+    # +/- 40 units around each of them in every quadrant
+    ang = [int(ocfg.angle[i]) for i in range(min(cfg.nlive, 12))]
+    sums = {0}
+    for a_ in ang[:10]:
+        sums |= {s + a_ for s in sums} | {s - a_ for s in sums}
+    base = np.array(sorted(sums), dtype=np.int64)
+    base = base[np.abs(base) < (1 << (cfg.pw - 3))]
+    if base.size > 4000:
+        base = base[rng.choice(base.size, 4000, replace=False)]
+    around = (base[:, None] + np.arange(-40, 41)[None, :]).ravel()
+    allq = (around[None, :] + (np.arange(4, dtype=np.int64)
+                               << (cfg.pw - 2))[:, None]).ravel()
+    phb = (allq & ((1 << cfg.pw) - 1)).astype(np.uint32)
+    xs, ys, _ = rand_inputs(rng, cfg.iw, cfg.pw, phb.size)
+    a = _gpu_plan_p2r_xy(plan, xs, ys, phb)
+    b = O.rotate(ocfg, xs, ys, phb)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # ragged length: the tail goes through the generic kernel
+    a = _gpu_plan_p2r_xy(plan, x[:1003], y[:1003], ph[:1003])
+    assert np.array_equal(a[0], b_ := O.rotate(ocfg, x[:1003], y[:1003], ph[:1003])[0])
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_plan_p2r_without_a_direction_table_runs_the_plain_kernel():
+    for args in ((ca.P2R, 32, 32, 3, 32, 16),          # WW 36
+                 (ca.P2R, 32, 32, 2, 32, 17)):          # no instance for 17
+        cfg, ocfg = both(*args)
+        plan = ca.Plan(cfg)
+        rng = np.random.RandomState(5)
+        x, y, ph = rand_inputs(rng, cfg.iw, cfg.pw, 20001)
+        a = _gpu_plan_p2r_xy(plan, x, y, ph)
+        assert ca.last_kernel() == ca.KERNEL_UNROLLED
+        b = O.rotate(ocfg, x, y, ph)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        plan.close()
+    # and with the A/B flag the table is ignored
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg.with_flags(ca.FLAG_NO_TAILS))
+    a = _gpu_plan_p2r_xy(plan, x, y, ph)
+    assert ca.last_kernel() == ca.KERNEL_UNROLLED
+    b = O.rotate(ocfg, x, y, ph)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    plan.close()
+
+
 @pytest.mark.gpu
 def test_queue_ring_bookkeeping_is_visible_and_survives_failed_launches():
     """cordic_plan_queue_info: captured launches take a block each for the
