@@ -37,6 +37,9 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import build_stamp  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # TEST SWITCH (tests/test_bench_launch.py): BENCH_TEST_SHARE_GPU=1 lets N ranks
@@ -795,6 +798,7 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
+            "build": build_stamp.stamp(),
             "config": {"workload": "%s: %s" % (args.workload, w["desc"]),
                        "samples_per_gpu": n, "pw": tab.pw, "ow": tab.ow,
                        "entries": tab.entries,
@@ -1227,6 +1231,7 @@ def run_group(args, w, launch):
             "vs_baseline": None,
             "dtype": "int64" if cfg.ww > 32 else "int32",
             "data": "synthetic",
+            "build": build_stamp.stamp(),
             "config": {
                 "workload": "%s: %s" % (args.workload, w["desc"]),
                 "samples_per_gpu": n,
@@ -1628,6 +1633,7 @@ def run_direct(args, w, launch):
             "vs_baseline": None,
             "dtype": "int64" if cfg.ww > 32 else "int32",
             "data": "synthetic",
+            "build": build_stamp.stamp(),
             "config": {
                 "workload": "%s: %s" % (args.workload, w["desc"]),
                 "samples_per_gpu": n,

@@ -286,8 +286,9 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 	const auto t_begin = std::chrono::steady_clock::now();
 	if (!hp.init())
 		return CORDIC_ERR_DEVICE;
-	// the table-seeded plan for constant vectors, kept with the pipeline
-	if (j.scalar) {
+	// the plan (seed table for constant vectors, direction tables for
+	// per-sample ones), kept with the pipeline
+	if (!j.r2p) {
 		if (!hp.have_plan || std::memcmp(&hp.plan_cfg, j.cfg, sizeof *j.cfg) != 0) {
 			if (hp.plan) cordic_plan_destroy(hp.plan);
 			hp.plan = nullptr;
@@ -373,7 +374,7 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 					static_cast<int32_t *>(s.dout[0]),
 					static_cast<int32_t *>(s.dout[1]), hp.s_run);
 		else
-			rc = cordic_p2r(j.cfg, cnt, static_cast<int32_t *>(s.din[1]),
+			rc = cordic_plan_p2r(hp.plan, cnt, static_cast<int32_t *>(s.din[1]),
 					static_cast<int32_t *>(s.din[2]),
 					static_cast<uint32_t *>(s.din[0]),
 					static_cast<int32_t *>(s.dout[0]),
@@ -430,7 +431,7 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 	for (int a = 0; a < j.nin; a++) st.staged_inputs += stage_in[a] ? 1 : 0;
 	st.staged_outputs = (stage_out[0] ? 1 : 0) + (stage_out[1] ? 1 : 0);
 	st.copy_threads = any_stage && hp.pool ? hp.pool->threads() : 0;
-	st.seeded_plan = (j.scalar && hp.plan) ? 1 : 0;
+	st.seeded_plan = (j.scalar && hp.plan) ? 1 : 0;	// (vectors: its direction tables)
 	st.seconds = std::chrono::duration<double>(
 			std::chrono::steady_clock::now() - t_begin).count();
 	return rc;

@@ -1,8 +1,9 @@
-// cordic_inst_xydir.hip -- instantiation unit of rotator_xydir (per-sample
-// vectors, looked-up directions: cordic_xydir.h).  Static instances for the
-// live-stage counts listed in CORDIC_XYDIR_STAGES, in the two left-justified
-// containers the WW <= 35 cores run in; every other count keeps the
-// phase-recurrence kernel (rotator_unrolled).
+// cordic_inst_xydir_body.h -- instantiation unit of rotator_xydir (per-sample
+// vectors, looked-up directions: cordic_xydir.h).  The including .hip defines
+// CORDIC_XYDIR_NAME (the launcher it exports) and CORDIC_XYDIR_LJ (29: WW 35,
+// 30: WW <= 34).  Static instances for every live-stage count of
+// CORDIC_ROT_STAGES; any other count keeps the phase-recurrence kernel
+// (rotator_unrolled).
 #include <hip/hip_runtime.h>
 
 #include "cordic_xydir.h"
@@ -24,7 +25,7 @@ bool launch_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 		kp, da, (const i32x4g *)j.x, (const i32x4g *)j.y, \
 		(const u32x4g *)j.phase, (i32x4g *)j.ox, (i32x4g *)j.oy, j.n / kVec); \
 	return true;
-	CORDIC_XYDIR_STAGES(X)
+	CORDIC_ROT_STAGES(X)
 #undef X
 	default:
 		return false;
@@ -32,15 +33,11 @@ bool launch_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 }
 } // namespace
 
-bool launch_xydir(int lj, int nlive, int grid, hipStream_t st,
+bool CORDIC_XYDIR_NAME(int nlive, int grid, hipStream_t st,
 		const dev::CoreParams &kp, const dev::DirArgs &da,
 		const RotatorJob &j, size_t lds)
 {
-	if (lj == 29)
-		return launch_lj<29>(nlive, grid, st, kp, da, j, lds);
-	if (lj == 30)
-		return launch_lj<30>(nlive, grid, st, kp, da, j, lds);
-	return false;
+	return launch_lj<CORDIC_XYDIR_LJ>(nlive, grid, st, kp, da, j, lds);
 }
 
 } // namespace cordic_amd

@@ -627,8 +627,9 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 				&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))) {
 			dev::DirArgs da{j.dir_table, j.dx};
 			const size_t lds = dev::dx_lds_layout(j.dx, nullptr, nullptr);
-			done = launch_xydir(cfg.ww == 35 ? 29 : 30, cfg.nlive, grid, st,
-					kp, da, j, lds);
+			done = cfg.ww == 35
+				? launch_xydir_lj29(cfg.nlive, grid, st, kp, da, j, lds)
+				: launch_xydir_lj30(cfg.nlive, grid, st, kp, da, j, lds);
 			if (done)
 				g_last_kernel = CORDIC_KERNEL_DIRECTIONS;
 		}

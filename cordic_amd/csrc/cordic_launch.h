@@ -18,12 +18,6 @@
 #define CORDIC_POL_STAGES(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
 	X(25) X(26) X(27) X(28) X(29)
 
-// per-sample vectors with looked-up directions (cordic_xydir.h): the counts
-// that have an instance
-#ifndef CORDIC_XYDIR_STAGES
-#define CORDIC_XYDIR_STAGES(X) X(16) X(19) X(20) X(24) X(27) X(29)
-#endif
-
 namespace cordic_amd {
 
 // stage counts without a static instance run on one instance unrolled to
@@ -60,9 +54,12 @@ CORDIC_SEED_LAUNCHER(launch_seed_narrow);	// WW <= 32
 CORDIC_SEED_LAUNCHER(launch_seed_lj29);		// WW == 35
 CORDIC_SEED_LAUNCHER(launch_seed_lj30);		// WW == 33, 34
 namespace dev { struct DirArgs; }
-bool launch_xydir(int lj, int nlive, int grid, hipStream_t st,
-		const dev::CoreParams &kp, const dev::DirArgs &da,
-		const RotatorJob &j, size_t lds);
+// per-sample vectors with looked-up directions (cordic_xydir.h)
+#define CORDIC_XYDIR_LAUNCHER(NAME) \
+	bool NAME(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp, \
+		const dev::DirArgs &da, const RotatorJob &j, size_t lds)
+CORDIC_XYDIR_LAUNCHER(launch_xydir_lj29);	// WW == 35
+CORDIC_XYDIR_LAUNCHER(launch_xydir_lj30);	// WW <= 34
 CORDIC_POL_LAUNCHER(launch_pol_narrow);
 // WW <= 32, no reachable overflow: left-justified form, 7 instructions per
 // micro-rotation (cordic_device.h: topolar_lj)

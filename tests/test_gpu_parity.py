@@ -1042,7 +1042,7 @@ def test_plan_p2r_per_sample_vectors_with_looked_up_directions(args, groups):
 @pytest.mark.gpu
 def test_plan_p2r_without_a_direction_table_runs_the_plain_kernel():
     for args in ((ca.P2R, 32, 32, 3, 32, 16),          # WW 36
-                 (ca.P2R, 32, 32, 2, 32, 17)):          # no instance for 17
+                 (ca.P2R, 32, 32, 2, 32, 12)):          # 12 stages: no instance
         cfg, ocfg = both(*args)
         plan = ca.Plan(cfg)
         rng = np.random.RandomState(5)

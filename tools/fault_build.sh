@@ -10,6 +10,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT/cordic_amd/csrc"
 mkdir -p build_fault
+find build_fault -type l -delete	# objects of an earlier source layout
 # every other object is identical: reuse the product build's
 for o in build/*.o; do
 	b=$(basename $o)

@@ -35,7 +35,7 @@ def counters(sub):
 
 
 def short(name):
-    for key in ("rotator_seeded", "rotator_unrolled", "rotator_generic",
+    for key in ("rotator_seeded", "rotator_xydir", "rotator_unrolled", "rotator_generic",
                 "topolar_lj", "topolar_unrolled", "topolar_generic",
                 "table_lookup", "quad_lookup"):
         if key in name:
