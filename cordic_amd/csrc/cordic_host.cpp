@@ -190,9 +190,17 @@ struct HostPipe {
 	{
 		if (s_up)
 			return true;
-		if (!ok(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)) ||
-		    !ok(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking)) ||
-		    !ok(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking)))
+		// high priority: the runtime keeps a separate pool of hardware
+		// queues per priority, so these streams never sit in a hardware
+		// queue behind a caller's long-running kernels (streams of equal
+		// priority share the few hardware queues a process gets), and the
+		// pipeline's short kernels do not wait for a busy device
+		int lo = 0, hi = 0;
+		if (!ok(hipDeviceGetStreamPriorityRange(&lo, &hi)))
+			lo = hi = 0;
+		if (!ok(hipStreamCreateWithPriority(&s_up, hipStreamNonBlocking, hi)) ||
+		    !ok(hipStreamCreateWithPriority(&s_run, hipStreamNonBlocking, hi)) ||
+		    !ok(hipStreamCreateWithPriority(&s_down, hipStreamNonBlocking, hi)))
 			return false;
 		for (Slot &s : slot)
 			if (!ok(hipEventCreateWithFlags(&s.up, hipEventDisableTiming)) ||

@@ -134,7 +134,6 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 
 	typedef const __attribute__((address_space(3))) u32x4 lds_entry;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-	typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 	typedef const __attribute__((address_space(3))) u32x2 lds_bucket;
 	// LDS is addressed by byte offset from 0: no static LDS in this kernel
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
@@ -242,10 +241,18 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 						en[v][at] = t4[0]; en[v][at + 1] = t4[1];
 						en[v][at + 2] = t4[2]; en[v][at + 3] = t4[3];
 					} else if (W - at == 3) {
-						const u32x3 t3 = *(const __attribute__((address_space(3)))
+						// three dwords left: ds_read_b96 (8 lane groups of 8)
+						// or a b128 whose fourth dword is padding
+#ifndef CORDIC_DX_B128	/* same-box A/B (profiles/r04/ab_b96.txt): a b128 here is
+			 * -0.8 % on ramps, +0.5 % on unrelated phases: b96 kept */
+						typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+						const u32x3 t4 = *(const __attribute__((address_space(3)))
 							u32x3 *)(uintptr_t)(ea[v] + 4u * at);
-						en[v][at] = t3[0]; en[v][at + 1] = t3[1];
-						en[v][at + 2] = t3[2];
+#else
+						const u32x4 t4 = *(lds_entry *)(uintptr_t)(ea[v] + 4u * at);
+#endif
+						en[v][at] = t4[0]; en[v][at + 1] = t4[1];
+						en[v][at + 2] = t4[2];
 					} else if (W - at == 2) {
 						const u32x2 t2 = *(lds_bucket *)(uintptr_t)(ea[v] + 4u * at);
 						en[v][at] = t2[0]; en[v][at + 1] = t2[1];

@@ -253,7 +253,7 @@ def test_every_line_says_which_ceiling_binds(workload):
     # (the seeded kernel builds its table in every block: at 2^24 samples that
     # prologue adds ~20 % to cfg4's 85 instructions per sample with the
     # direction tails)
-    want = {"cfg4": (85, 115), "cfg3": (150, 175), "p2rxy": (125, 150)}[workload]
+    want = {"cfg4": (85, 115), "cfg3": (150, 175), "p2rxy": (98, 115)}[workload]
     assert want[0] < v["instr_per_sample"] < want[1], v
     assert roof["valu_fraction"] == pytest.approx(
         v["achieved_Tinstr_per_s"] / v["peak_Tinstr_per_s"])

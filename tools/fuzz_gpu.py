@@ -64,6 +64,27 @@ for t in range(ncfg):
                                            int(ph[bad[0]]), a[0][bad[0]],
                                            a[1][bad[0]], b[0][bad[0]],
                                            b[1][bad[0]], bad.size))
+        # per-sample vectors through the plan: directions looked up where the
+        # core has the tables (cordic_xydir.h), cordic_p2r's kernel elsewhere
+        import torch  # noqa: E402
+        dx_, dy_, dp_ = (torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).cuda()
+                         for v in (x, y, ph))
+        oa = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ob = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.p2r(dx_, dy_, dp_, oa, ob)
+        torch.cuda.synchronize()
+        if plan.dir_groups:
+            paths["dirs%d" % len(plan.dir_groups)] = paths.get(
+                "dirs%d" % len(plan.dir_groups), 0) + 1
+        b = O.rotate(ocfg, x, y, ph)
+        if not (np.array_equal(oa.cpu().numpy(), b[0])
+                and np.array_equal(ob.cpu().numpy(), b[1])):
+            bad = np.nonzero((oa.cpu().numpy() != b[0]) | (ob.cpu().numpy() != b[1]))[0]
+            raise SystemExit("plan.p2r mismatch: cli=%r ww=%d nlive=%d groups=%r n=%d "
+                             "first bad %d x=%d y=%d phase=%#x (%d bad)"
+                             % ((mode, iw, ow, xtra, pw, ns), cfg.ww, cfg.nlive,
+                                plan.dir_groups, n, bad[0], x[bad[0]], y[bad[0]],
+                                int(ph[bad[0]]), bad.size))
         fcw, p0, i0 = int(rng.randint(1 << 32)), int(rng.randint(1 << 32)), int(rng.randint(1 << 40))
         if rng.randint(2):
             fcw = int(rng.choice([1, 2, 5, (1 << pw) - 3])) & 0xffffffff   # slow NCO: tails
