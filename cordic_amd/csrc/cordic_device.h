@@ -1168,7 +1168,6 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	// VALU instruction per read).  Checked once per wave.
 	typedef const __attribute__((address_space(3))) u32x4 lds_entry;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-	typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 	typedef const __attribute__((address_space(3))) u32x2 lds_bucket;
 	if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds != 0u)
 		__builtin_trap();

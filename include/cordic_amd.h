@@ -803,7 +803,7 @@ int	cordic_fill_circle(int32_t *d_x, int32_t *d_y, size_t n, uint64_t index0,
  *     DMA'd in place: the call runs at the PCIe rate of the busier direction
  *     (p2r with constant vectors: 4 B up, 8 B down per sample);
  *   - pageable arrays (malloc / new) are staged through pinned buffers by a
- *     pool of host threads (CORDIC_HOST_THREADS, default 6): bounded by the
+ *     pool of host threads (CORDIC_HOST_THREADS, default 8): bounded by the
  *     host's memcpy rate.
  * Inputs and outputs may mix the two kinds.  The pipeline (streams, 3 x 5
  * device arrays, staging, threads, plan) is created on first use per device,

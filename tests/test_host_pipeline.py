@@ -124,3 +124,25 @@ def test_release_and_reuse():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     r = O.rotate(ocfg, 5, 6, ph)
     assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
+
+
+def test_pageable_arrays_at_odd_offsets():
+    """Caller arrays that start 4, 12 or 20 bytes past a 64-byte line (views
+    into larger buffers): the staging copies' aligned non-temporal body has
+    unaligned heads and tails on both sides."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n = 2 * CHUNK + 1237
+    _, _, ph = _inputs(n + 8, 32, 9)
+    for k_in, k_out in ((1, 3), (5, 1), (3, 5)):
+        phv = ph[k_in:k_in + n]
+        oxb = np.full(n + 8, -7, dtype=np.int32)
+        oyb = np.full(n + 8, -7, dtype=np.int32)
+        out = (oxb[k_out:k_out + n], oyb[k_out:k_out + n])
+        assert phv.ctypes.data % 16 != 0 and out[0].ctypes.data % 16 != 0
+        a = ca.p2r_host(cfg, 2**31 - 1, 0, phv, out=out)
+        assert ca.host_last_stats()["staged_outputs"] == 2
+        b = O.rotate(ocfg, 2**31 - 1, 0, phv)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # nothing written outside the views
+        assert (oxb[:k_out] == -7).all() and (oxb[k_out + n:] == -7).all()
+        assert (oyb[:k_out] == -7).all() and (oyb[k_out + n:] == -7).all()
