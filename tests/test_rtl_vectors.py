@@ -260,3 +260,71 @@ def test_worst_case_samples_of_the_acceptance_sweeps(tmp_path):
     q = Q.r2p_quality(c, x[2:3], y[2:3], int(mg), mag[2:3], p[2:3])
     assert q["mxperr"] == pytest.approx(12.36, abs=0.01)
     assert q["mxperr"] > q["phase_limit"]
+
+
+# ---------------------------------------- where a rotation direction flips
+#
+# tests/golden/rtl_breakpoint_vectors.json (make_rtl_breakpoint_vectors.py):
+# BASELINE's rotators and gencordic's own 24- / 16-bit cores, their emitted RTL
+# EXECUTED by vsim on phases +/- 1 around the partial sums of the arctan table
+# (the break points of the seed / direction tables), every quadrant, random
+# per-sample vectors.
+
+@pytest.fixture(scope="module")
+def break_vectors():
+    with open(os.path.join(ROOT, "tests", "golden",
+                           "rtl_breakpoint_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_reproduces_the_rtl_at_every_direction_break_point(break_vectors):
+    total = 0
+    for name, e in break_vectors.items():
+        c = oracle_cfg(e["args"])
+        assert (c.iw, c.ow, c.ww, c.pw) == (e["IW"], e["OW"], e["WW"], e["PW"])
+        ox, oy = O.rotate(c, np.array(e["x"], dtype=np.int32),
+                          np.array(e["y"], dtype=np.int32),
+                          np.array(e["phase"], dtype=np.uint32))
+        assert ox.tolist() == e["o_xval"], name
+        assert oy.tolist() == e["o_yval"], name
+        total += len(e["x"])
+    assert total >= 10000
+
+
+@pytest.mark.gpu
+def test_table_driven_kernels_reproduce_the_rtl_at_every_break_point(break_vectors):
+    """The engine against the executed RTL directly: per-sample vectors through
+    the plan (directions looked up, cordic_xydir.h) and through cordic_p2r
+    (phase recurrence); and, for the samples that share one vector, the
+    table-seeded constant-vector kernel with its direction tails."""
+    import torch
+    import cordic_amd as ca
+    from gpu_util import DEV, dev_i32, gpu_p2r, gpu_plan_p2r, to_np
+    for name, e in break_vectors.items():
+        d = parse_args(e["args"])
+        cfg = ca.Config.from_cli(d["mode"], d["iw"], d["ow"], d["xtra"],
+                                 d["pw"], d["n"])
+        x = np.array(e["x"], dtype=np.int32)
+        y = np.array(e["y"], dtype=np.int32)
+        ph = np.array(e["phase"], dtype=np.uint32)
+        gx, gy = gpu_p2r(cfg, x, y, ph)
+        assert gx.tolist() == e["o_xval"] and gy.tolist() == e["o_yval"], name
+        plan = ca.Plan(cfg)
+        assert plan.dir_groups, name
+        ox = torch.zeros(x.size, dtype=torch.int32, device=DEV)
+        oy = torch.zeros(x.size, dtype=torch.int32, device=DEV)
+        plan.p2r(dev_i32(x), dev_i32(y), dev_i32(ph), ox, oy)
+        torch.cuda.synchronize()
+        assert ca.last_kernel() == ca.KERNEL_DIRECTIONS
+        assert to_np(ox).tolist() == e["o_xval"], name
+        assert to_np(oy).tolist() == e["o_yval"], name
+        # constant vector: the RTL's outputs for x[0], y[0] at EVERY phase of the
+        # set come from the oracle (pinned to the RTL above); the seeded kernel
+        # must agree, and at sample 0 with the RTL itself
+        c = oracle_cfg(e["args"])
+        rx, ry = O.rotate(c, int(x[0]), int(y[0]), ph)
+        sx, sy = gpu_plan_p2r(plan, int(x[0]), int(y[0]), ph)
+        assert ca.last_kernel() == ca.KERNEL_SEEDED
+        assert np.array_equal(sx, rx) and np.array_equal(sy, ry), name
+        assert int(sx[0]) == e["o_xval"][0] and int(sy[0]) == e["o_yval"][0]
+        plan.close()
