@@ -1253,3 +1253,42 @@ def test_direction_tails_on_every_group_boundary(args):
         wa, wb = O.rotate(ocfg, x0, 0, pn)
         assert np.array_equal(a, wa) and np.array_equal(b, wb), fcw
     plan.close(); plain.close()
+
+
+@pytest.mark.gpu
+def test_plan_p2r_on_two_streams_and_in_a_hip_graph():
+    """cordic_plan_p2r only enqueues: launches of one plan on two streams at
+    once, and a launch captured into a HIP graph and replayed on new data."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    plan = ca.Plan(cfg)
+    n = 1 << 20
+    rng = np.random.RandomState(31)
+    sets = [rand_inputs(rng, 32, 32, n) for _ in range(2)]
+    dev = [[dev_i32(a) for a in s] for s in sets]
+    outs = [[torch.zeros(n, dtype=torch.int32, device=DEV) for _ in range(2)]
+            for _ in range(2)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for k in range(2):
+            plan.p2r(dev[k][0], dev[k][1], dev[k][2], outs[k][0], outs[k][1],
+                     stream=streams[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        rx, ry = O.rotate(ocfg, *sets[k])
+        assert np.array_equal(to_np(outs[k][0]), rx)
+        assert np.array_equal(to_np(outs[k][1]), ry)
+    # capture once, replay on other inputs
+    gx, gy, gp = (torch.zeros(n, dtype=torch.int32, device=DEV) for _ in range(3))
+    ox = torch.zeros(n, dtype=torch.int32, device=DEV)
+    oy = torch.zeros(n, dtype=torch.int32, device=DEV)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.p2r(gx, gy, gp, ox, oy)
+    for k in range(2):
+        gx.copy_(dev[k][0]); gy.copy_(dev[k][1]); gp.copy_(dev[k][2])
+        g.replay()
+        torch.cuda.synchronize()
+        rx, ry = O.rotate(ocfg, *sets[k])
+        assert np.array_equal(to_np(ox), rx) and np.array_equal(to_np(oy), ry)
+    plan.close()

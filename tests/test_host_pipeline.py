@@ -146,3 +146,37 @@ def test_pageable_arrays_at_odd_offsets():
         # nothing written outside the views
         assert (oxb[:k_out] == -7).all() and (oxb[k_out + n:] == -7).all()
         assert (oyb[:k_out] == -7).all() and (oyb[k_out + n:] == -7).all()
+
+
+def test_concurrent_callers_queue_up_behind_each_other():
+    """The pipeline of a device serialises host-array calls (a mutex): four
+    host threads with different cores and sizes, every result its own."""
+    import threading
+    jobs = [((ca.P2R, 32, 32, 2, 32, 16), CHUNK + 11, 2**31 - 1, 0),
+            ((ca.P2R, 32, 32, 2, 32, 24), 2 * CHUNK + 5, 12345, -9),
+            ((ca.P2R, 16, 16, 2, -1, -1), 70001, 32767, 1),
+            ((ca.P2R, 32, 32, 2, 32, 16), 3, -5, 77)]
+    out, err = [None] * len(jobs), []
+
+    def work(k):
+        try:
+            args, n, x0, y0 = jobs[k]
+            cfg = ca.Config.from_cli(*args)
+            _, _, ph = _inputs(n, 32, 40 + k)
+            for _ in range(3):
+                out[k] = (ca.p2r_host(cfg, x0, y0, ph), ph)
+        except Exception as e:              # pragma: no cover
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for k, (args, n, x0, y0) in enumerate(jobs):
+        ocfg = O.config_cli(*args)
+        (a, b), ph = out[k]
+        pw = ocfg.pw
+        rx, ry = O.rotate(ocfg, x0, y0, ph & np.uint32((1 << pw) - 1 if pw < 32
+                                                       else 0xffffffff))
+        assert np.array_equal(a, rx) and np.array_equal(b, ry), k
