@@ -7,7 +7,7 @@
 // operands, so this path is a COPY PIPELINE with a
 // kernel in the middle, and it is built to keep both PCIe directions busy:
 //
-//   * the job is cut into chunks of kChunk samples (16 MiB per array); three
+//   * the job is cut into chunks of 2^22 samples (16 MiB per array); three
 //     slots of device arrays rotate through three private non-blocking
 //     streams -- upload, run, download -- chained by events on the device, so
 //     chunk k+1 uploads and chunk k-1 downloads while chunk k computes;
@@ -15,8 +15,11 @@
 //     hipHostRegister) are DMA'd in place: no CPU copy at all, the host only
 //     enqueues and waits once at the end;
 //   * pageable arrays (malloc / new, the reference's own) go through pinned
-//     staging buffers, copied by a small pool of host threads while the DMA of
-//     the neighbouring chunks runs;
+//     staging buffers, copied by a small pool of host threads (8) while the
+//     DMA of the neighbouring chunks runs; the host paces itself so that at
+//     most three chunks are queued (copy engines serve queued copies in
+//     submission order: unpaced, downloads waiting for their kernels hold up
+//     the uploads behind them);
 //   * constant vectors (xy_is_scalar) run the table-seeded plan, cached with
 //     the pipeline, like cordic_plan_p2r_const;
 //   * only the pipeline's own streams are synchronised -- never the device.
@@ -28,12 +31,10 @@
 // anyway).
 #include <hip/hip_runtime_api.h>
 
-#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -60,7 +61,7 @@ size_t chunk_samples()
 	}();
 	return v;
 }
-#define kChunk (chunk_samples())
+#define kChunk (chunk_samples())	/* (a run-time constant of the process) */
 constexpr size_t kDirectBytes = (size_t)1 << 20;	// small jobs: no staging
 
 bool ok(hipError_t e) { return e == hipSuccess; }

@@ -46,6 +46,10 @@ KERNELS = [
     ("rotator_unrolled_lj29_16_xy", "cordic_inst_rot_lj29.o",
      r"rotator_unrolled<cordic_amd::dev::WideLJ<29>, 16, 2, \(cordic_amd::Feed\)1, false, cordic_amd::dev::Io32, false>",
      "p2rxy: per-sample x, y and phase"),
+    ("rotator_xydir_lj29_16", "cordic_inst_xydir_lj29.o",
+     r"rotator_xydir<29, 16>",
+     "p2rxy through a plan (round 4): per-sample x, y and phase, directions of "
+     "stages 2-16 looked up in three groups of five"),
     ("topolar_unrolled_narrow_20", "cordic_inst_pol_narrow.o",
      r"topolar_unrolled<cordic_amd::dev::Narrow32, 20, 0, false, cordic_amd::dev::Io32, false>",
      "cfg3 r2p, round-1 form (8 instructions per micro-rotation)"),
