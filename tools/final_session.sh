@@ -1,0 +1,23 @@
+#!/bin/bash
+# final_session.sh -- the ONE gpurun call whose outputs fill profiles/bench_rNN/
+# and profiles/rNN/ (one box, one code state): the driver's order first
+# (pytest -m gpu, smoke(), the default bench line), the rocprofv3 kernel-trace
+# summary of the default command, the sweep (one stamped line per workload x
+# {ramp, random}), the per-workload profiles (stats + separate PMC passes, ramp
+# and random phases), the host-array rates.  Afterwards, here:
+#   cp gpurun_out/bench_sweep/*.json profiles/bench_rNN/   (+ the prof summaries)
+#   python tools/design_table.py --write
+#   gpurun --timeout 5400 -- 'bash tools/final_session.sh'
+OUT=gpurun_out/final
+mkdir -p $OUT
+(time timeout 1800 python -m pytest tests -m gpu -x -q) > $OUT/gputests.log 2>&1; echo rc=$? >> $OUT/gputests.log
+(time timeout 600 python -c "import __graft_entry__ as g; g.smoke()") > $OUT/smoke.log 2>&1; echo rc=$? >> $OUT/smoke.log
+(time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5) > $OUT/default_driver_order.json 2> $OUT/default_driver_order.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/default_stats -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-other-paths --no-pmc --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/default_stats.log 2>&1
+cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/bench_sweep gpurun_out/prof
+bash tools/gpu_session.sh env sweep > $OUT/session.log 2>&1
+for w in cfg2 cfg3 cfg4 cfg5 p2rxy cfg1 nat24 nat32; do timeout 900 bash tools/profile_workload.sh $w > $OUT/prof_$w.log 2>&1; done
+for w in cfg2 cfg4 nat24 p2rxy; do timeout 900 bash tools/profile_workload.sh $w --input random > $OUT/prof_${w}_random.log 2>&1; done
+python bench.py --host-paths-only > $OUT/host_paths.json 2>/dev/null
