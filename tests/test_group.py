@@ -512,9 +512,11 @@ def test_group_over_the_shim_from_python_two_ranks(tmp_path, delay_ms):
     assert "gathered arrays equal the oracle for 3 jobs" in outs[1][0]
     if delay_ms >= 20:
         # the calls only enqueue: the host is done long before the transfers
+        # (at least four of the nine exchanges are still outstanding when the
+        # host has finished enqueuing -- whatever the first launches cost)
         for so, _ in outs:
             assert _ms(so, "total_ms") >= 9 * delay_ms
-            assert _ms(so, "enqueue_ms") < 0.5 * _ms(so, "total_ms"), so
+            assert _ms(so, "total_ms") - _ms(so, "enqueue_ms") >= 4 * delay_ms, so
 
 
 def test_async_shim_catches_a_missing_job_order(tmp_path):
