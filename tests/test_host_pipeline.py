@@ -99,12 +99,13 @@ def test_other_streams_of_the_caller_are_not_waited_for():
     n_big = 1 << 28
     phs = torch.zeros(n_big, dtype=torch.int32, device=dev)
     oa = torch.empty_like(phs); ob = torch.empty_like(phs)
+    _, _, ph = _inputs(1000, 32, 3)
+    ca.p2r_host(cfg, 2**31 - 1, 0, ph)      # pipeline and plan exist from here on
     torch.cuda.synchronize()
     done = torch.cuda.Event()
-    for _ in range(40):                     # ~40 x 1.5 ms of queued kernels
+    for _ in range(80):                     # ~80 x 1.4 ms of queued kernels
         ca.p2r_const(big_cfg, 1, 0, phs, oa, ob, stream=side)
     done.record(side)
-    _, _, ph = _inputs(1000, 32, 3)
     t0 = time.perf_counter()
     a = ca.p2r_host(cfg, 2**31 - 1, 0, ph)
     dt = time.perf_counter() - t0
