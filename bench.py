@@ -202,7 +202,15 @@ def _usable_cpus():
     return n
 
 
-def oracle_digest_leg(args, w, ocfg, start, n, x0, y0):
+def ranks_on_this_node(world):
+    """processes that share this node's host cores with us"""
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    except ValueError:
+        return max(1, world)
+
+
+def oracle_digest_leg(args, w, ocfg, start, n, x0, y0, threads=None):
     """The oracle's digest of ALL n samples this rank computed (threaded
     orc_digest: every sample through the scalar restatement, condensed by the
     device's position-aware digest).  This CPU work is also the cpu_baseline
@@ -214,10 +222,30 @@ def oracle_digest_leg(args, w, ocfg, start, n, x0, y0):
             or getattr(args, "no_full_digest", False)):
         return None
     fcw = 0x01234567 if kind == "nco" else (1 << w.get("shift", 0))
-    cores = _usable_cpus()
+    cores = threads or _usable_cpus()
     d, secs = O.job_digest(ocfg, kind, start, n, 0, fcw, x0, y0,
                            threads=cores)
     return {"digest": d, "samples": n, "seconds": secs, "cores": cores}
+
+
+def reduce_digest_legs(dist, dev, world, local_ok, leg):
+    """Every rank has compared ITS shards with the oracle: (all equal?, samples
+    compared in all, sum of the oracle's digests mod 2^64, slowest leg)."""
+    if dist is None or world == 1:
+        return local_ok, leg["samples"], leg["digest"], leg["seconds"]
+    od = leg["digest"]
+    t = torch.tensor([1 if local_ok else 0, leg["samples"],
+                      od - (1 << 64) if od >= 1 << 63 else od],
+                     dtype=torch.int64, device=coll_device(dev))
+    mn = t[:1].clone()
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    sm = t[1:].clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    sec = torch.tensor([leg["seconds"]], dtype=torch.float64,
+                       device=coll_device(dev))
+    dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+    return (bool(mn.item()), int(sm[0].item()),
+            int(sm[1].item()) & 0xFFFFFFFFFFFFFFFF, float(sec.item()))
 
 
 def cpu_baseline(workload, seconds=12.0, leg=None):
@@ -1033,9 +1061,21 @@ def run_group(args, w, launch):
         dist.all_reduce(d, op=dist.ReduceOp.SUM)     # digests of shards add
         digest = int(d.item()) & 0xFFFFFFFFFFFFFFFF
 
-    check = digest_check = leg = None
+    check = digest_check = None
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    # EVERY output of EVERY rank against the oracle: each rank pushes its own
+    # shards' samples through the scalar oracle (its share of the node's host
+    # cores) and compares digests; the verdicts are reduced
+    lo = grp.range(n_total, first)[0]
+    cnt_all = sum(grp.range(n_total, first + sh)[1] for sh in range(nlocal))
+    leg = oracle_digest_leg(args, w, ocfg, lo, cnt_all, x0, y0,
+                            threads=max(1, _usable_cpus()
+                                        // ranks_on_this_node(world)))
+    legs = None
+    if leg is not None:
+        legs = reduce_digest_legs(dist, dev, world,
+                                  local_digest == leg["digest"], leg)
     if rank == 0:
-        ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
         start0 = grp.range(n_total, first)[0]
 
         def oracle(off, cnt):
@@ -1071,21 +1111,19 @@ def run_group(args, w, launch):
             got = int(dd.cpu().numpy().view(np.uint64)[0])
         digest_check = {"samples": cnt, "device": "%016x" % got,
                         "oracle": "%016x" % want, "equal": got == want}
-        # ... and EVERY output this process computed (its nlocal shards are
-        # one contiguous global range) against the oracle
-        lo = grp.range(n_total, first)[0]
-        cnt_all = sum(grp.range(n_total, first + sh)[1] for sh in range(nlocal))
-        leg = oracle_digest_leg(args, w, ocfg, lo, cnt_all, x0, y0)
-        if leg is not None:
+        if legs is not None:
+            all_ok, samples_all, oracle_sum, slowest = legs
             digest_check = {
-                "samples": cnt_all, "device": "%016x" % local_digest,
-                "oracle": "%016x" % leg["digest"],
-                "equal": local_digest == leg["digest"],
-                "oracle_seconds": leg["seconds"], "oracle_threads": leg["cores"],
-                "what": "position-aware 64-bit digest of ALL outputs of this "
-                        "process's shards: device digest kernel over what the "
-                        "timed kernels wrote vs oracle/cordic_oracle.c: "
-                        "orc_digest (every sample through the scalar oracle)",
+                "samples": samples_all, "device": "%016x" % digest,
+                "oracle": "%016x" % oracle_sum,
+                "equal": all_ok and digest == oracle_sum,
+                "oracle_seconds": slowest, "oracle_threads": leg["cores"],
+                "ranks": world,
+                "what": "position-aware 64-bit digest of ALL outputs of ALL "
+                        "ranks: each rank's device digest over what its timed "
+                        "kernels wrote vs oracle/cordic_oracle.c: orc_digest of "
+                        "its own shards (every sample through the scalar "
+                        "oracle); verdicts AND digests reduced over the ranks",
                 "leading_2^20_also_equal": got == want}
             check = check and digest_check["equal"]
 
@@ -1541,10 +1579,18 @@ def run_direct(args, w, launch):
     torch.cuda.synchronize()
     digest = int(d.cpu().numpy().view(np.uint64)[0])
 
-    check = digest_check = leg = None
+    check = digest_check = None
+    import oracle_lib as O
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    # EVERY output of EVERY rank against the oracle (see run_group)
+    leg = oracle_digest_leg(args, w, ocfg, index0, n, x0, y0,
+                            threads=max(1, _usable_cpus()
+                                        // ranks_on_this_node(world)))
+    legs = None
+    if leg is not None:
+        legs = reduce_digest_legs(dist, dev, world,
+                                  local_digest == leg["digest"], leg)
     if rank == 0:
-        import oracle_lib as O
-        ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
         idx = np.unique(np.concatenate([
             np.arange(0, min(n, 4096)), np.arange(max(0, n - 4096), n),
             np.arange(0, n, 65521)])).astype(np.int64)
@@ -1570,16 +1616,17 @@ def run_direct(args, w, launch):
                   * np.uint64(0x01234567) & np.uint64(0xffffffff))
             ra, rb = O.rotate(ocfg, x0, y0, ph.astype(np.uint32))
         check = bool(np.array_equal(ga, ra) and np.array_equal(gb, rb))
-        # EVERY output of this rank against the oracle
-        leg = oracle_digest_leg(args, w, ocfg, index0, n, x0, y0)
-        if leg is not None:
+        if legs is not None:
+            all_ok, samples_all, oracle_sum, slowest = legs
             digest_check = {
-                "samples": n, "device": "%016x" % local_digest,
-                "oracle": "%016x" % leg["digest"],
-                "equal": local_digest == leg["digest"],
-                "oracle_seconds": leg["seconds"], "oracle_threads": leg["cores"],
-                "what": "position-aware 64-bit digest of ALL outputs: device "
-                        "digest kernel vs oracle/cordic_oracle.c: orc_digest"}
+                "samples": samples_all, "device": "%016x" % digest,
+                "oracle": "%016x" % oracle_sum,
+                "equal": all_ok and digest == oracle_sum,
+                "oracle_seconds": slowest, "oracle_threads": leg["cores"],
+                "ranks": world,
+                "what": "position-aware 64-bit digest of ALL outputs of ALL "
+                        "ranks: device digest kernel vs oracle/cordic_oracle.c: "
+                        "orc_digest, rank by rank, verdicts and digests reduced"}
             check = check and digest_check["equal"]
 
     # ---- constant-vector feeds: also time the full-recurrence kernel (every

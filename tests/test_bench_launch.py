@@ -336,6 +336,11 @@ def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
             a, b = O.rotate(c, ramp(0x9E3779B1, 32), ramp(0x85EBCA77, 32), ph)
     want = (cpu_digest(a, 0) + cpu_digest(b, 1 << 40)) % 2 ** 64
     assert int(d["digest"], 16) == want, (d["digest"], "%016x" % want)
+    # every rank compared ITS shard with the oracle (threaded orc_digest); the
+    # line carries the reduced verdict over all ranks' samples
+    dc = d["digest_check"]
+    assert dc["equal"] is True and dc["samples"] == n_total and dc["ranks"] == ranks
+    assert int(dc["oracle"], 16) == want
     if "single_process_cordic_group" in d:
         sp = d["single_process_cordic_group"]
         assert "error" not in sp, sp
