@@ -544,6 +544,38 @@ int general_stages_for(int ww)
 	return kAllGeneral;
 }
 
+// Every block of the table-seeded kernel rebuilds the seed table in its
+// prologue (~10 us: nothing is cached between launches), so a SMALL batch is
+// served faster by the full recurrence, which has none: per launch 11.5 us
+// against 23 us at 2^20 samples, equal at 2^23 (16 stages) / 2^22.6 (24
+// stages), then the seeds win (profiles/r04/small_batch.txt).  A plan therefore
+// takes the seeded kernel from this many samples on.  CORDIC_SEED_MIN_SAMPLES
+// overrides it (0: always seeded -- what the test suite sets, so that the
+// seeded kernels stay covered at test sizes).
+long long forced_min_samples()
+{
+	static const long long forced = [] {
+		const char *e = std::getenv("CORDIC_SEED_MIN_SAMPLES");
+		return (e && *e) ? std::atoll(e) : -1ll;
+	}();
+	return forced;
+}
+size_t seed_min_samples(const cordic_config &cfg)
+{
+	if (forced_min_samples() >= 0)
+		return (size_t)forced_min_samples();
+	return cfg.nlive <= 18 ? (size_t)1 << 23 : (size_t)3 << 21;
+}
+// ... and the same for per-sample vectors with looked-up directions: their
+// tables are small, but the plain kernel is still 10 % ahead up to 2^22
+// samples (9.2 against 7.9 us per launch at 2^20; 68.8 against 71.9 at 2^24)
+size_t dir_min_samples()
+{
+	if (forced_min_samples() >= 0)
+		return (size_t)forced_min_samples();
+	return (size_t)1 << 23;
+}
+
 template <Feed FEED>
 int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 {
@@ -577,6 +609,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		// constant-vector feeds with a plan: table-seeded kernel
 		if (FEED != Feed::PhaseArray_XYArray && j.seed_table
 				&& j.seed_m == kSeedStages && j.n >= (size_t)kVec
+				&& j.n >= seed_min_samples(cfg)
 				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)) {
 			static_assert(CORDIC_QUEUE_BYTES
 				== kQueueCounters * kQueueStride * 4, "queue layout");
@@ -622,6 +655,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		// (cordic_xydir.h); cores / counts without an instance fall through
 		if (FEED == Feed::PhaseArray_XYArray && j.dir_table && j.dx.n > 0
 				&& !j.io16 && j.n >= (size_t)kVec && kp.post_mul == 0
+				&& j.n >= dir_min_samples()
 				&& kp.in_shl >= 1 && kp.in_shl <= 30 && cfg.ww <= 35
 				&& !cfg.needs_wrap
 				&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))) {

@@ -247,7 +247,12 @@ int	cordic_last_kernel(void);
  * fills the (x, y) table itself on every launch with the exact recurrence, so
  * results are bit-identical for every phase and nothing is cached across
  * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 11 live
- * stages) simply run the ordinary kernels.
+ * stages) simply run the ordinary kernels -- and so do SMALL batches: building
+ * the table costs every launch ~10 us, so below 2^23 samples (6 Mi for cores
+ * of more than 18 stages) a plan launches the full recurrence, which is then
+ * the faster kernel (11.5 against 23 us per launch at 2^20 samples);
+ * CORDIC_SEED_MIN_SAMPLES in the environment moves that size (0: always the
+ * table).  Same results either way.
  *
  * Tile queues and HIP graphs.  A plan (likewise a table / quad handle) owns a
  * ring of tile-queue counter blocks; every launch takes one and the ring hands
@@ -294,7 +299,8 @@ int	cordic_plan_tail_info(const cordic_plan *plan, int32_t *ngroups,
  * 7 instructions per micro-rotation; the vector state itself cannot be
  * tabulated, every stage still runs).  Same results as cordic_p2r, bit for
  * bit; cores without such a table (WW > 35, reachable overflow, stage counts
- * without an instance) run cordic_p2r's kernel.  cordic_plan_dir_info: the
+ * without an instance) and batches below 2^23 samples (see above:
+ * CORDIC_SEED_MIN_SAMPLES) run cordic_p2r's kernel.  cordic_plan_dir_info: the
  * number of looked-up stage groups (0: none) and their sizes. */
 int	cordic_plan_p2r(const cordic_plan *plan, size_t n,
 		const int32_t *d_xval, const int32_t *d_yval,

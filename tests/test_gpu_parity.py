@@ -1292,3 +1292,56 @@ def test_plan_p2r_on_two_streams_and_in_a_hip_graph():
         rx, ry = O.rotate(ocfg, *sets[k])
         assert np.array_equal(to_np(ox), rx) and np.array_equal(to_np(oy), ry)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_a_plan_serves_small_batches_with_the_plain_kernel():
+    """Below ~2^23 samples the per-launch seed table costs more than it saves
+    (profiles/r04/small_batch.txt): without CORDIC_SEED_MIN_SAMPLES in the
+    environment (the test suite sets it to 0) a plan picks the kernel by the
+    batch size -- same bits either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np, torch
+import cordic_amd as ca, oracle_lib as O
+from gpu_util import gpu_digest
+for args, small, large in (((ca.P2R, 32, 32, 2, 32, 16), 1 << 22, 1 << 23),
+                           ((ca.P2R, 32, 32, 2, 32, 24), 1 << 22, 3 << 21)):
+    cfg, ocfg = ca.Config.from_cli(*args), O.config_cli(*args)
+    plan = ca.Plan(cfg)
+    for n, want in ((small, ca.KERNEL_UNROLLED), (large, ca.KERNEL_SEEDED),
+                    (1 << 16, ca.KERNEL_UNROLLED)):
+        ph = torch.empty(n, dtype=torch.int32, device="cuda")
+        a = torch.empty_like(ph); b = torch.empty_like(ph)
+        ca.fill_phase_ramp(ph, 0, 3)
+        plan.p2r_const(2**31 - 1, 0, ph, a, b)
+        torch.cuda.synchronize()
+        assert ca.last_kernel() == want, (n, ca.last_kernel())
+        d = (gpu_digest(a, 0) + gpu_digest(b, 1 << 40)) %% 2**64
+        assert d == O.job_digest(ocfg, "p2r", 0, n, 0, 8, 2**31 - 1, 0)[0], n
+        plan.nco(n, 5, 7, 0, 2**31 - 1, 0, a, b)
+        torch.cuda.synchronize()
+        assert ca.last_kernel() == want
+    # per-sample vectors: directions looked up from 2^23 samples on
+    for n, want in ((1 << 20, ca.KERNEL_UNROLLED), (1 << 23, ca.KERNEL_DIRECTIONS)):
+        ph = torch.empty(n, dtype=torch.int32, device="cuda")
+        x = torch.empty_like(ph); y = torch.empty_like(ph)
+        a = torch.empty_like(ph); b = torch.empty_like(ph)
+        ca.fill_phase_ramp(ph, 0, 3)
+        ca.fill_iq_ramp(x, y, 0, O.IQ_MULX, O.IQ_MULY, 32)
+        plan.p2r(x, y, ph, a, b)
+        torch.cuda.synchronize()
+        assert ca.last_kernel() == want, (n, ca.last_kernel())
+        d = (gpu_digest(a, 0) + gpu_digest(b, 1 << 40)) %% 2**64
+        assert d == O.job_digest(ocfg, "p2rxy", 0, n, 0, 8)[0], n
+print("ok")
+""" % (root, root)
+    env = {k: v for k, v in os.environ.items() if k != "CORDIC_SEED_MIN_SAMPLES"}
+    r = subprocess.run([sys.executable, "-c", script], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-launch time of the constant-vector rotator against the batch size: the
+table-seeded kernel (every block rebuilds the seed table in its prologue)
+against the full recurrence (no prologue), cfg2's and cfg4's cores.  Where is
+the crossover, i.e. below which n should a plan launch the plain kernel?"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+os.environ["CORDIC_SEED_MIN_SAMPLES"] = "0"     # both kernels at every size
+import cordic_amd as ca
+
+dev = torch.device("cuda:0")
+for ns in (16, 24):
+    cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns)
+    plan = ca.Plan(cfg)
+    plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
+    print("p2r %d stages: n, seeded us, plain us, seeded Gs/s, plain Gs/s" % ns)
+    for lg in range(12, 28):
+        n = 1 << lg
+        ph = torch.empty(n, dtype=torch.int32, device=dev)
+        a = torch.empty_like(ph); b = torch.empty_like(ph)
+        ca.fill_phase_ramp(ph, 0, 2)
+        res = []
+        for p in (plan, plain):
+            reps = 200 if lg < 22 else 40
+            for _ in range(5):
+                p.p2r_const(2**31 - 1, 0, ph, a, b)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                p.p2r_const(2**31 - 1, 0, ph, a, b)
+            e1.record()
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / reps * 1e3)
+        print("  2^%-2d %9.2f %9.2f %8.1f %8.1f" % (lg, res[0], res[1],
+                                                   n / res[0] / 1e3, n / res[1] / 1e3))
+    plan.close(); plain.close()
+# per-sample vectors: directions looked up (small tables) against the recurrence
+cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)
+plan = ca.Plan(cfg)
+print("p2r 16 stages, per-sample vectors: n, directions us, recurrence us")
+for lg in range(12, 26, 2):
+    n = 1 << lg
+    ph = torch.empty(n, dtype=torch.int32, device=dev)
+    x = torch.empty_like(ph); y = torch.empty_like(ph)
+    a = torch.empty_like(ph); b = torch.empty_like(ph)
+    ca.fill_phase_ramp(ph, 0, 2)
+    ca.fill_iq_ramp(x, y, 0, 0x9E3779B1, 0x85EBCA77, 32)
+    res = []
+    for fn in (lambda: plan.p2r(x, y, ph, a, b), lambda: ca.p2r(cfg, x, y, ph, a, b)):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 100 * 1e3)
+    print("  2^%-2d %9.2f %9.2f" % (lg, res[0], res[1]))
+plan.close()
