@@ -1012,6 +1012,12 @@ def run_group(args, w, launch):
     fill(grp)
     step(grp)                   # allocates the outputs; first-launch costs
     grp.sync()
+    if seeded and ca.last_kernel() != ca.KERNEL_SEEDED:
+        # a batch below the size from which a plan takes the table-driven
+        # kernel by itself (cordic_kernels.hip: seed_min_samples; --log2-samples
+        # under 23 without CORDIC_SEED_MIN_SAMPLES=0): the line must name the
+        # kernel that ran
+        seeded, seed_stages, tails = False, 0, []
 
     # ---- same-run copy probes on the very arrays of shard 0 (before)
     _, ptrs, _ = grp.buffers(0)
@@ -1543,9 +1549,10 @@ def run_direct(args, w, launch):
         torch.cuda.synchronize()
 
     sampler = start_power(local, rank == 0 and not args.no_power)
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
     barrier()
+    ran = ca.last_kernel()      # the family that really serves this batch size
 
     # ---- timed region: exactly K steps; HIP events (on the stream the
     # kernels are launched on: torch's current stream) bracket every launch
@@ -1633,7 +1640,7 @@ def run_direct(args, w, launch):
     # sample runs all micro-rotations) so both numbers are on record
     full = None
     if (w["kind"] in ("p2r", "nco") and not args.no_seed and not args.generic
-            and plan.seed_info["stages"] > 0):
+            and plan.seed_info["stages"] > 0 and ran == ca.KERNEL_SEEDED):
         plan2 = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
         a2 = torch.empty_like(a)
         b2 = torch.empty_like(b)
@@ -1688,9 +1695,10 @@ def run_direct(args, w, launch):
                 "nstages": cfg.nstages, "rotations": cfg.nlive,
                 "kernel": "generic" if args.generic else (
                     ("directions(%s)" % "+".join(map(str, plan.dir_groups))
-                     if plan.dir_groups and not args.no_tails else "unrolled")
+                     if ran == ca.KERNEL_DIRECTIONS else "unrolled")
                     if w["kind"] == "p2rxy" else
-                    "unrolled" if (args.no_seed or w["kind"] == "r2p")
+                    "unrolled" if (args.no_seed or w["kind"] == "r2p"
+                                   or ran != ca.KERNEL_SEEDED)
                     else "seeded(%d)+unrolled" % plan.seed_info["stages"]),
                 "input": args.input,
                 "parallelism": "shard%d" % world,
