@@ -271,7 +271,8 @@ def _free_port():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,ranks", [("cfg2", 2), ("cfg4", 3), ("cfg3", 2),
-                                            ("cfg5", 2), ("p2rxy", 2)])
+                                            ("cfg5", 2), ("p2rxy", 2),
+                                            ("cfg4", 8)])      # the node's rank count
 def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
     """The command the driver runs for N > 1 --
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N
