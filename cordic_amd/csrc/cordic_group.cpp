@@ -37,6 +37,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "cordic_amd.h"
@@ -57,9 +58,11 @@ struct Shard {
 	void	*buf[4] = {nullptr, nullptr, nullptr, nullptr};	// in0 in1 out0 out1
 	uint64_t cap = 0;		// words allocated per array
 	int	inputs = 0;
-	// words [0, written[a]) of input array a were supplied by the caller
-	// (cordic_group_write) since the array was last allocated or filled
-	uint64_t written[2] = {0, 0};
+	// the stretches [first, second) of input array a the caller supplied
+	// (cordic_group_write) since the array was last allocated or filled:
+	// disjoint, sorted, merged where they touch -- pieces may arrive in ANY
+	// order, a job needs [0, its share) inside the first one
+	std::vector<std::pair<uint64_t, uint64_t>> written[2];
 	uint64_t *d_digest = nullptr;
 	hipEvent_t marks[kMaxMarks] = {};
 	hipEvent_t piece[kMaxChunks] = {};
@@ -157,6 +160,39 @@ struct cordic_group {
 };
 
 namespace {
+
+// coverage bookkeeping of the caller-written inputs (Shard::written)
+typedef std::vector<std::pair<uint64_t, uint64_t>> Spans;
+
+void add_span(Spans &v, uint64_t lo, uint64_t hi)
+{
+	if (lo >= hi)
+		return;
+	Spans out;
+	bool placed = false;
+	for (const auto &iv : v) {
+		if (iv.second < lo) {
+			out.push_back(iv);		// wholly before, not touching
+		} else if (hi < iv.first) {
+			if (!placed) {
+				out.emplace_back(lo, hi);
+				placed = true;
+			}
+			out.push_back(iv);
+		} else {				// overlaps or touches: absorb
+			lo = iv.first < lo ? iv.first : lo;
+			hi = iv.second > hi ? iv.second : hi;
+		}
+	}
+	if (!placed)
+		out.emplace_back(lo, hi);
+	v.swap(out);
+}
+
+bool covers(const Spans &v, uint64_t cnt)
+{
+	return cnt == 0 || (!v.empty() && v[0].first == 0 && v[0].second >= cnt);
+}
 
 void shard_span(uint64_t n, int s, int total, uint64_t *start, uint64_t *count)
 {
@@ -455,7 +491,8 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			// whatever the inputs held is gone
 			s.cap = 0;
 			s.inputs = 0;
-			s.written[0] = s.written[1] = 0;
+			s.written[0].clear();
+			s.written[1].clear();
 			g->filled_total = 0;
 			g->filled_inputs = 0;
 		}
@@ -553,7 +590,7 @@ int for_each_piece(cordic_group *g, uint64_t n_total, int inputs, F launch)
 		shard_span(n_total, s.index, g->total, &start, &cnt);
 		for (int a = 0; a < inputs; a++) {
 			const bool filled = g->filled_total == n_total && a < g->filled_inputs;
-			if (!filled && s.written[a] < cnt)
+			if (!filled && !covers(s.written[a], cnt))
 				return CORDIC_ERR_ARGS;
 		}
 	}
@@ -799,7 +836,7 @@ int cordic_group_fill_phase_ramp(cordic_group *grp, uint64_t n_total, int shift)
 			return rc;
 	}
 	for (Shard &s : grp->shards)
-		s.written[0] = 0;		// overwritten by the ramp
+		s.written[0].clear();		// overwritten by the ramp
 	grp->filled_total = n_total;
 	grp->filled_inputs = 1;
 	return CORDIC_OK;
@@ -823,8 +860,10 @@ int cordic_group_fill_iq_ramp(cordic_group *grp, uint64_t n_total, uint32_t mulx
 				mulx, muly, bits, s.compute))
 			return rc;
 	}
-	for (Shard &s : grp->shards)
-		s.written[0] = s.written[1] = 0;
+	for (Shard &s : grp->shards) {
+		s.written[0].clear();
+		s.written[1].clear();
+	}
 	grp->filled_total = n_total;
 	grp->filled_inputs = 2;
 	return CORDIC_OK;
@@ -1118,10 +1157,11 @@ int cordic_group_write(cordic_group *grp, int local_shard, int array,
 	    !ok(hipMemcpy(static_cast<uint32_t *>(s.buf[array]) + offset, src,
 			(size_t)count * 4, hipMemcpyDefault)))
 		return CORDIC_ERR_DEVICE;
-	// the caller's own inputs: coverage grows as a prefix (pieces may come
-	// in any order as long as they join up)
-	if (array < 2 && offset <= s.written[array] && offset + count > s.written[array])
-		s.written[array] = offset + count;
+	// the caller's own inputs: any order, as long as the pieces end up
+	// covering the shard's share (a prefix counter rejected a
+	// shard written completely but back to front)
+	if (array < 2)
+		add_span(s.written[array], offset, offset + count);
 	return CORDIC_OK;
 }
 

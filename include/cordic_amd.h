@@ -603,8 +603,8 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
 /* A job that READS input arrays (p2r_const: in0; r2p: in0, in1) requires
  * EACH of them, on EVERY local shard, to hold data for that job: filled by
  * cordic_group_fill_* for the same n_total, or written by the caller
- * (cordic_group_write; pieces in any order that join up from offset 0) over
- * the shard's whole share, since the arrays were last (re)allocated.  Growing
+ * (cordic_group_write; pieces in any order, overlapping or not, that together
+ * cover the shard's whole share) since the arrays were last (re)allocated.  Growing
  * the capacity discards what the inputs held, a fill discards what the caller
  * wrote; a job whose inputs are not all there returns CORDIC_ERR_ARGS instead
  * of computing on uninitialised memory.

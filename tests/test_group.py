@@ -346,13 +346,28 @@ def test_a_job_needs_inputs_filled_for_its_own_size():
     g3.write(1, g3.IN0, 2048, np.arange(2048, dtype=np.uint32))
     with pytest.raises(ca.CordicError):
         g3.p2r_const(8192, AMP, 0)                    # shard 1: hole at 0..2047
+    # (pieces may arrive in ANY order -- back to front here --
+    # as long as they end up covering the shard's share)
     g3.write(1, g3.IN0, 0, np.arange(2048, dtype=np.uint32))
-    with pytest.raises(ca.CordicError):
-        g3.p2r_const(8192, AMP, 0)   # pieces must join up from offset 0 in order
+    g3.p2r_const(8192, AMP, 0)
+    assert np.array_equal(g3.read(1, g3.OUT0, 0, 2048), rx[:2048])
+    assert np.array_equal(g3.read(1, g3.OUT0, 2048, 2048), rx[:2048])
     g3.write(1, g3.IN0, 2048, np.arange(2048, dtype=np.uint32) + 2048)
     g3.p2r_const(8192, AMP, 0)
     assert np.array_equal(g3.read(1, g3.OUT0, 0, 4096), rx[:4096])
     g3.close()
+    # many pieces, shuffled, overlapping, with a hole until the very last one
+    g5 = ca.Group(cfg, devices=[0])
+    g5.reserve(4096, 1)
+    ph = np.arange(4096, dtype=np.uint32)
+    for lo, hi in ((3000, 4096), (100, 900), (800, 2000), (0, 100), (2500, 3200)):
+        g5.write(0, g5.IN0, lo, ph[lo:hi])
+        with pytest.raises(ca.CordicError):
+            g5.p2r_const(4096, AMP, 0)                # [2000, 2500) still missing
+    g5.write(0, g5.IN0, 1990, ph[1990:2510])
+    g5.p2r_const(4096, AMP, 0)
+    assert np.array_equal(g5.read(0, g5.OUT0, 0, 4096), rx[:4096])
+    g5.close()
     r2p_cfg, _ = both(ca.R2P, 24, 24, 2, -1, 20)
     g4 = ca.Group(r2p_cfg, devices=[0])
     g4.reserve(4096, 2)

@@ -1,0 +1,162 @@
+"""bench_paths.py -- the informational lines behind the default run: the other
+BASELINE configurations at their sizes (child runs of bench.py) and the
+host-array entry points beside the raw PCIe rates.  Never `value`."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from bench_common import MODE, ROOT, WORKLOADS
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+# BASELINE.json's other GPU configurations at THEIR sizes (configs[2..4]) plus
+# the per-sample-vector rotator: (workload, log2 samples per launch)
+OTHER_PATHS = (("cfg3", 30), ("cfg4", 30), ("cfg5", 32), ("p2rxy", 30))
+
+
+def other_paths(args, steps=24, warmup=4):
+    """Driver-timed lines of the other configurations (single-GPU default run
+    only; informational, never `value`): each one is this script run on that
+    workload -- same timing discipline, HIP events around every launch, oracle
+    spot checks and digest, hwmon clock, one SQ_INSTS_VALU pass -- as a child
+    process once the main measurement is finished, condensed to its rate,
+    roofline (HBM fraction AND valu_fraction, bound) and checks."""
+    import subprocess
+    res = {}
+    for wl, log2n in OTHER_PATHS:
+        cmd = [sys.executable, BENCH, "--workload", wl,
+               "--steps", str(steps), "--warmup", str(warmup),
+               "--log2-samples", str(log2n), "--input", args.input,
+               "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
+               "--pmc-counters", "SQ_INSTS_VALU"]
+        if args.no_pmc:
+            cmd.append("--no-pmc")
+        if args.no_power:
+            cmd.append("--no-power")
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1])
+        except Exception as e:                # never lose the main line
+            res[wl] = {"error": repr(e)}
+            continue
+        roof = d["roofline"]
+        e = {"Msamples_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+             "steps": d["steps"], "samples_per_launch": 1 << log2n,
+             "bytes_per_sample": roof["bytes_per_sample"],
+             "kernel": d["config"]["kernel"],
+             "bit_exact_vs_oracle": d["bit_exact_vs_oracle"],
+             "digest": d["digest"],
+             "digest_check": {k: (d.get("digest_check") or {}).get(k) for k in (
+                 "samples", "equal", "oracle", "oracle_seconds")},
+             "roofline": {k: roof[k] for k in (
+                 "bound", "achieved", "peak", "unit", "frac", "valu_fraction",
+                 "valu", "kernel_ms_avg", "kernel_ms_min") if k in roof},
+             "wall_s": time.perf_counter() - t0}
+        pw = (roof.get("power") or {}).get("sustained")
+        if pw:
+            e["sustained"] = {k: pw[k] for k in (
+                "socket_w_median", "sclk_mhz_median") if k in pw}
+        if "full_recurrence_kernel" in d:
+            f = d["full_recurrence_kernel"]
+            e["full_recurrence_kernel"] = {
+                "Msamples_per_s": f["value_per_gpu"], "hbm_frac": f["hbm_frac"],
+                "outputs_identical_to_seeded_kernel":
+                    f["outputs_identical_to_seeded_kernel"]}
+        res[wl] = e
+    return res
+
+
+def host_paths(log2n=28, reps=3):
+    """The host-array entry points (cordic_p2r_host / cordic_r2p_host: what a
+    caller holding the reference bench's plain `int` arrays uses,
+    bench/cpp/cordic_tb.cpp:94-178) timed beside the raw PCIe rates of this
+    box: pinned 1 GiB hipMemcpy each way, then BASELINE config 2's core on
+    2^log2n host samples -- pinned arrays (DMA'd in place) and pageable numpy
+    arrays (staged by the library's copy threads) -- and config 3's converter.
+    Informational, never `value`: inputs start in HOST memory here.  Outputs
+    are checked against the oracle's digest of every sample."""
+    import ctypes as C
+    import cordic_amd as ca
+    import oracle_lib as O
+    n = 1 << log2n
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dev = torch.empty(n, dtype=torch.int32, device="cuda")
+    pin = [ca.HostArray(n, "int32") for _ in range(4)]
+    res = {"samples": n, "reps": reps}
+
+    def best(fn):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+    pin[0].array[:] = 1
+    h2d = best(lambda: hip.hipMemcpy(dev.data_ptr(), pin[0].array.ctypes.data,
+                                     n * 4, 1))
+    d2h = best(lambda: hip.hipMemcpy(pin[0].array.ctypes.data, dev.data_ptr(),
+                                     n * 4, 2))
+    res["pcie"] = {"h2d_GBps": n * 4 / h2d / 1e9, "d2h_GBps": n * 4 / d2h / 1e9,
+                   "what": "hipMemcpy of %d MiB, pinned host memory, best of "
+                           "%d" % (n * 4 >> 20, reps)}
+    del dev
+
+    def line(seconds, up, down, want, got):
+        # the direction that takes longer at the raw rates is the bound
+        t_up = up * n / (res["pcie"]["h2d_GBps"] * 1e9)
+        t_down = down * n / (res["pcie"]["d2h_GBps"] * 1e9)
+        return {"Msamples_per_s": n / seconds / 1e6, "seconds": seconds,
+                "up_GBps": up * n / seconds / 1e9,
+                "down_GBps": down * n / seconds / 1e9,
+                "frac_of_slower_pcie_direction": max(t_up, t_down) / seconds,
+                "stats": {k: v for k, v in ca.host_last_stats().items()
+                          if k != "seconds"},
+                "digest_equals_oracle": want == got}
+
+    def dig(a, b):
+        return (O.digest_words(a, 0) + O.digest_words(b, 1 << 40)) % (1 << 64)
+    # config 2: constant vector, phase ramp n << 2
+    m, iw, ow, xtra, pw, ns = WORKLOADS["cfg2"]["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    x0 = (1 << (iw - 1)) - 1
+    ramp = (np.arange(n, dtype=np.uint32) << np.uint32(2))
+    want, _ = O.job_digest(ocfg, "p2r", 0, n, 0, 4, x0, 0)
+    pin[0].array.view(np.uint32)[:] = ramp
+    out = (pin[1].array, pin[2].array)
+    ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32), out=out)   # set-up
+    t = best(lambda: ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32),
+                                 out=out))
+    res["p2r_const_pinned"] = line(t, 4, 8, want, dig(*out))
+    pa, pb = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb))
+    t = best(lambda: ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb)))
+    res["p2r_const_pageable"] = line(t, 4, 8, want, dig(pa, pb))
+    # config 3: converter on the I/Q ramps (8 B up, 8 B down)
+    m, iw, ow, xtra, pw, ns = WORKLOADS["cfg3"]["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    g = np.arange(n, dtype=np.uint32)
+    sh = 32 - iw
+    for k, mul in ((0, O.IQ_MULX), (1, O.IQ_MULY)):
+        with np.errstate(over="ignore"):
+            v = ((g * np.uint32(mul)) >> np.uint32(8)) << np.uint32(sh)
+        pin[k].array[:] = v.view(np.int32) >> sh
+    want, _ = O.job_digest(ocfg, "r2p", 0, n)
+    out = (pin[2].array, pin[3].array.view(np.uint32))
+    ca.r2p_host(cfg, pin[0].array, pin[1].array, out=out)
+    t = best(lambda: ca.r2p_host(cfg, pin[0].array, pin[1].array, out=out))
+    res["r2p_pinned"] = line(t, 8, 8, want, dig(*out))
+    for h in pin:
+        h.close()
+    ca.host_release()
+    return res

@@ -1,0 +1,108 @@
+"""bench_pmc.py -- roofline.traffic / instructions per sample of a bench line:
+separate rocprofv3 --pmc passes over a short run of the same command, and the
+committed counters of earlier sessions (profiles/pmc_latest.json)."""
+import json
+import os
+import sys
+
+from bench_common import KERNEL_OF, ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+def _profile_entry(key):
+    """Counters of a workload from the COMMITTED rocprofv3 passes
+    (profiles/pmc_latest.json; tools/profile_workload.sh produced them in an
+    earlier gpurun session) -- not measured by this run, and labelled so."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            db = json.load(f)
+        return db.get(key), db.get("_source", "profiles/pmc_latest.json")
+    except (OSError, ValueError):
+        return None, None
+
+
+def from_profile(key, samples_per_launch=1 << 30):
+    """{"source": ..., "hbm_bytes_per_launch": ..., "valu_instr_per_sample": ...}
+    for the bench line's `from_profile` block (FETCH_SIZE x 2 +
+    WRITE_SIZE, SQ_INSTS_VALU x 64 lanes / samples), or None."""
+    e, src = _profile_entry(key)
+    if not e:
+        return None
+    out = {"source": src, "note": "rocprofv3 PMC passes of an earlier session "
+           "on this kernel, not re-measured by this run"}
+    if "hbm_bytes_per_launch" in e:
+        out["hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+    if "SQ_INSTS_VALU" in e:
+        out["valu_instr_per_sample"] = (e["SQ_INSTS_VALU"] * 64.0
+                                        / samples_per_launch)
+    # clock the chip sustained under this kernel (GRBM_GUI_ACTIVE / 8 XCDs /
+    # dispatch duration of the PMC pass; the kernels run at the 1400 W socket
+    # limit) and VALU issue interval per SIMD at that clock
+    for k in ("shader_clock_ghz", "valu_cycles_per_inst"):
+        if k in e:
+            out[k] = round(e[k], 3)
+    return out
+
+
+def measure_pmc(args):
+    """HBM bytes per launch and VALU instructions per sample of the workload's
+    kernel, MEASURED now: separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE,
+    SQ_INSTS_VALU -- the first two do not fit one pass, and PMC is never
+    combined with tracing) over a 3-step run of this same script, corrected as MI355X_MICROARCH.md prescribes for gfx950
+    (FETCH_SIZE counts half of a wide coalesced read; both are in KiB)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not found"}
+    kern = KERNEL_OF.get(args.workload)
+    if args.no_seed and kern == "rotator_seeded":
+        kern = "rotator_unrolled"
+    if args.no_tails and kern == "rotator_xydir":
+        kern = "rotator_unrolled"
+    base = [sys.executable, BENCH, "--workload",
+            args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
+            str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
+            "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power",
+            "--no-full-digest"]
+    for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
+                     ("--static-chunks", args.static_chunks),
+                     ("--no-tails", args.no_tails)):
+        if on:
+            base.append(flag)
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    counters = [c for c in args.pmc_counters.split(",") if c]
+    for ctr in counters:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format",
+                                "csv", "-d", td, "--"] + base, cwd="/tmp",
+                               env=env, capture_output=True, text=True,
+                               timeout=600)
+            rows = []
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"),
+                               recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if (row["Counter_Name"] == ctr and kern
+                            and kern in row["Kernel_Name"]):
+                        rows.append(float(row["Counter_Value"]))
+            if not rows:
+                return {"error": "no %s rows for %s (rocprofv3 rc %d)"
+                        % (ctr, kern, r.returncode)}
+            vals[ctr] = (sum(rows) / len(rows), len(rows))
+    out = {"kernel": kern, "passes": counters}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+        out.update({
+            "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+            "launches_averaged": vals["FETCH_SIZE"][1],
+            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM), "
+                          "WRITE_SIZE as reported, KiB -> B"})
+    if "SQ_INSTS_VALU" in vals:
+        out["SQ_INSTS_VALU_per_launch"] = vals["SQ_INSTS_VALU"][0]
+        out["valu_instr_per_sample"] = (vals["SQ_INSTS_VALU"][0] * 64.0
+                                        / float(1 << args.log2_samples))
+    return out
