@@ -16,7 +16,7 @@ from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
     FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_NO_TAILS, FLAG_STATIC_CHUNKS,
     FLAG_UNIT_GAIN,
-    ERR_ARGS, ERR_DEVICE, ERR_CONTAINER,
+    ERR_ARGS, ERR_DEVICE, ERR_CONTAINER, ERR_UNSUPPORTED,
     Config, CordicError, Plan, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, dir_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED, KERNEL_DIRECTIONS,
     lib, lib_path,
     p2r, p2r_const, nco, r2p,

@@ -11,6 +11,7 @@ FLAG_STATIC_CHUNKS = 0x20
 FLAG_UNIT_GAIN = 0x10
 FLAG_NO_TAILS = 0x40
 # enum cordic_status (the codes tests assert on)
+ERR_UNSUPPORTED = -6
 ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -114,6 +115,12 @@ ABI = {
     "cordic_plan_tail_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
     "cordic_plan_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cordic_plan_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_void_p]),
+    "cordic_plan_image_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]),
+    "cordic_plan_set_min_samples": (C.c_int, [C.c_void_p, C.c_longlong]),
     "cordic_plan_p2r": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
@@ -394,6 +401,25 @@ class Plan:
     def queue_info(self):
         """tile-queue ring of the handle (include/cordic_amd.h)"""
         return _queue_info("cordic_plan_queue_info", self._h)
+
+    def prepare(self, x0, y0, stream=None):
+        """build the seed image of the constant vector (x0, y0) now"""
+        _check(lib().cordic_plan_prepare(self._h, x0, y0, _stream(stream)),
+               "cordic_plan_prepare")
+
+    @property
+    def image_info(self):
+        """seed images the plan holds; launches served from one / not"""
+        a, b, c = C.c_int32(), C.c_uint64(), C.c_uint64()
+        _check(lib().cordic_plan_image_info(self._h, C.byref(a), C.byref(b),
+                                            C.byref(c)),
+               "cordic_plan_image_info")
+        return dict(held=a.value, hits=b.value, misses=c.value)
+
+    def set_min_samples(self, n):
+        """batch size from which the table-driven kernels serve (< 0: default)"""
+        _check(lib().cordic_plan_set_min_samples(self._h, n),
+               "cordic_plan_set_min_samples")
 
     @property
     def tail_groups(self):
@@ -1088,25 +1114,22 @@ class HostArray:
     array: what the host-array entry points DMA in place."""
 
     def __init__(self, n, dtype="int32"):
+        import weakref
         import numpy as np
         p = C.c_void_p()
         _check(lib().cordic_host_alloc(C.byref(p), max(1, n) * 4),
                "cordic_host_alloc")
-        self._p = p
         buf = (C.c_uint32 * max(1, n)).from_address(p.value)
+        # the pinned block lives as long as ANY numpy view of it does (views
+        # keep `buf` alive through their .base chain): it is released when the
+        # ctypes buffer is collected, not when close() is called
+        weakref.finalize(buf, lib().cordic_host_free, C.c_void_p(p.value))
         self.array = np.frombuffer(buf, dtype=np.uint32, count=n).view(dtype)
 
     def close(self):
-        if self._p:
-            self.array = None
-            lib().cordic_host_free(self._p)
-            self._p = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """drop this handle's reference (the memory goes once no view of
+        `.array` is left)"""
+        self.array = None
 
 
 def host_last_stats():
@@ -1117,6 +1140,24 @@ def host_last_stats():
 
 def host_release():
     lib().cordic_host_release()
+
+
+def _host_out(out, n, dtypes, what):
+    """caller-provided output arrays of a host-array call: the C pipeline
+    writes n contiguous words through the raw pointer, so anything else than a
+    writable C-contiguous array of exactly n 32-bit words is refused here"""
+    import numpy as np
+    if out is None:
+        return tuple(np.empty(n, dtype=d) for d in dtypes)
+    if len(out) != len(dtypes):
+        raise ValueError("%s: out= wants %d arrays" % (what, len(dtypes)))
+    for a in out:
+        if (not isinstance(a, np.ndarray) or a.dtype.itemsize != 4
+                or a.dtype.kind not in "iu" or a.ndim != 1 or a.size != n
+                or not a.flags.c_contiguous or not a.flags.writeable):
+            raise ValueError("%s: out= arrays must be writable, C-contiguous, "
+                             "one-dimensional, 32-bit, %d elements" % (what, n))
+    return tuple(out)
 
 
 def p2r_host(cfg, x, y, phase, out=None):
@@ -1132,8 +1173,9 @@ def p2r_host(cfg, x, y, phase, out=None):
     else:
         xa = np.ascontiguousarray(x, dtype=np.int32)
         ya = np.ascontiguousarray(y, dtype=np.int32)
-    ox, oy = out if out is not None else (np.empty(n, dtype=np.int32),
-                                          np.empty(n, dtype=np.int32))
+        if xa.size != n or ya.size != n:
+            raise ValueError("cordic_p2r_host: x, y and phase differ in length")
+    ox, oy = _host_out(out, n, (np.int32, np.int32), "cordic_p2r_host")
     _check(lib().cordic_p2r_host(
         cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
         1 if scalar else 0, phase.ctypes.data_as(_u32p),
@@ -1147,8 +1189,9 @@ def r2p_host(cfg, x, y, out=None):
     xa = np.ascontiguousarray(x, dtype=np.int32)
     ya = np.ascontiguousarray(y, dtype=np.int32)
     n = xa.size
-    mag, ph = out if out is not None else (np.empty(n, dtype=np.int32),
-                                           np.empty(n, dtype=np.uint32))
+    if ya.size != n:
+        raise ValueError("cordic_r2p_host: x and y differ in length")
+    mag, ph = _host_out(out, n, (np.int32, np.uint32), "cordic_r2p_host")
     _check(lib().cordic_r2p_host(
         cfg.ref, n, xa.ctypes.data_as(_i32p), ya.ctypes.data_as(_i32p),
         mag.ctypes.data_as(_i32p), ph.ctypes.data_as(_u32p)),

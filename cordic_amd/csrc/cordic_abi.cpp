@@ -174,6 +174,11 @@ struct cordic_plan {
 	uint32_t *d_dir = nullptr;	// direction tables for per-sample vectors
 	DxInfo dx;			// (dx.n == 0: none)
 	QueueRing queues;
+	// prologue images of the seeded kernels, per constant vector (round 5;
+	// cordic_internal.h: SeedImages -- internally locked, write-once slots)
+	SeedImages *images = nullptr;
+	// batch size from which the table-driven kernels serve (< 0: default)
+	std::atomic<long long> min_samples{-1};
 };
 
 int cordic_last_kernel(void) { return g_last_kernel; }
@@ -208,6 +213,10 @@ int cordic_plan_create(const cordic_config *cfg, cordic_plan **plan)
 		p->S = (int)words[1];
 		p->nbuckets = (int)words[2];
 		p->nleaves = (int)words[3];
+		// CORDIC_SEED_IMAGES=0: every block computes its prologue (A/B)
+		const char *e = std::getenv("CORDIC_SEED_IMAGES");
+		if (!(e && e[0] == '0' && e[1] == 0))
+			p->images = seed_images_create();	// (NULL: not fatal)
 	}
 	// direction tables for per-sample vectors (cordic_plan_p2r); independent
 	// of the seed table
@@ -249,6 +258,7 @@ int cordic_plan_p2r(const cordic_plan *plan, size_t n, const int32_t *d_xval,
 	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
 	j.dir_table = plan->d_dir;
 	j.dx = plan->dx;
+	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
 	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
@@ -268,6 +278,7 @@ void cordic_plan_destroy(cordic_plan *plan)
 		(void)hipFree(plan->d_table);
 	if (plan->d_dir)
 		(void)hipFree(plan->d_dir);
+	seed_images_destroy(plan->images);
 	plan->queues.release();
 	delete plan;
 }
@@ -308,6 +319,55 @@ static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 	j.seed_nbuckets = plan->nbuckets;
 	j.seed_nleaves = plan->nleaves;
 	j.dt = plan->dt;
+	j.images = plan->images;
+	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
+}
+
+int cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
+		void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	if (!plan->d_table || !plan->images)
+		return CORDIC_ERR_UNSUPPORTED;
+	int rc = CORDIC_OK;
+	// one image per container the plan's entry points may run in: the 32-bit
+	// arrays' and, for cores whose ports fit, the int16 arrays'
+	for (int io16 = 0; io16 < 2; io16++) {
+		if (io16 && (plan->cfg.iw > 16 || plan->cfg.ow > 16))
+			break;
+		RotatorJob j;
+		j.x0 = xval; j.y0 = yval;
+		j.io16 = io16 != 0;
+		j.prepare_only = true;
+		attach_seed(plan, j);
+		const int r = launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
+		if (!io16)
+			rc = r;
+	}
+	// a set-up call: it returns with the image COMPLETE (one block, ~15 us),
+	// so that a capture begun right behind it may use it
+	if (rc == CORDIC_OK && !seed_images_settle(plan->images))
+		rc = CORDIC_ERR_DEVICE;
+	return rc;
+}
+
+int cordic_plan_set_min_samples(cordic_plan *plan, long long min_samples)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	plan->min_samples.store(min_samples < 0 ? -1 : min_samples,
+			std::memory_order_relaxed);
+	return CORDIC_OK;
+}
+
+int cordic_plan_image_info(const cordic_plan *plan, int32_t *held, uint64_t *hits,
+		uint64_t *misses)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	seed_images_info(plan->images, held, hits, misses);
+	return CORDIC_OK;
 }
 
 // launch with a tile queue no other launch in flight is using

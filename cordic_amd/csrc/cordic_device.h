@@ -863,6 +863,16 @@ struct SeedArgs {
 	// direction tails behind the seeds (cordic_internal.h: DtInfo; the words
 	// they refer to follow the seed table in `table`)
 	DtInfo	dt;
+	// Round 5: the block's LDS as the prologue leaves it -- buckets, seeds of
+	// every (octant, leaf), tail tables -- kept by the plan per constant vector
+	// (cordic_kernels.hip: SeedImages).  `image` != NULL: the prologue is a
+	// copy of image_words words (136 KiB from L2 instead of ~10 us of exact
+	// recurrences per block).  `image_out` != NULL: BUILD mode -- one block runs
+	// the ordinary prologue, writes its LDS there and returns; the image is
+	// made by the very code whose result it replaces.
+	const uint32_t *image = nullptr;
+	uint32_t *image_out = nullptr;
+	uint32_t image_words = 0;
 };
 
 // LDS of the direction tails of a seeded kernel: per group its buckets
@@ -1034,11 +1044,76 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	static_assert(M <= NLIVE, "seed deeper than the core");
 
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	// ---- tile geometry of the queued sweep (see "Work distribution" below),
+	// ahead of the prologue: round 5 hands every block its first two tiles
+	// WITHOUT an atomic -- ticket numbers 0 .. 2 R_j - 1 of range j belong to
+	// the R_j blocks whose home is j (home = blockIdx mod 8, rank = blockIdx
+	// div 8: ranks r and r + R_j), the counters hand out 2 R_j + k -- so the
+	// first tile is known from blockIdx alone and its phases are requested
+	// BEFORE the prologue stages the table: a small batch no longer pays two
+	// serial atomic round trips and a load latency behind the prologue.
+	constexpr uint32_t kTileVecs = (uint32_t)kSeedBlock * kSeedSub;
+	const uint32_t ntiles = (uint32_t)((nvec + kTileVecs - 1) / kTileVecs);
+	const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
+	const uint32_t lane = threadIdx.x;
+	// vectors of the tile that exist (only the batch's last tile is partial)
+	const uint32_t last_live = ntiles
+		? (uint32_t)(nvec - (size_t)(ntiles - 1) * kTileVecs) : 0u;
+	auto live = [&](uint32_t tile) -> uint32_t {
+		return tile == ntiles - 1 ? last_live : kTileVecs;
+	};
+	// a lane's vector in row s of a tile, clamped into the tile's live
+	// part (only the batch's last tile is partial): the loads need no
+	// predicate, so nothing has to be preserved around them
+	auto row_vec = [&](uint32_t tile, int s) -> size_t {
+		uint32_t l = lane + (uint32_t)s * kSeedBlock;
+		const uint32_t top = live(tile) - 1u;	// block-uniform
+		// (spelled out: left to itself the compiler selects with
+		// v_cndmask_b32, ~23 cycles per wave-instruction here, §4.1)
+		asm("v_min_u32 %0, %1, %2" : "=v"(l) : "v"(l), "s"(top));
+		return (size_t)tile * kTileVecs + l;
+	};
+	const uint32_t q_home = blockIdx.x % kQueueCounters;
+	const uint32_t q_rank = blockIdx.x / kQueueCounters;
+	// blocks whose home is j
+	auto q_blocks = [&](uint32_t j) -> uint32_t {
+		return gridDim.x > j ? (gridDim.x - j + kQueueCounters - 1) / kQueueCounters : 0u;
+	};
+	typename IO::uvec pa[kSeedSub] = {};
+	bool early = false;
+	if (sa.queue != nullptr && sa.image_out == nullptr) {
+		const uint32_t lo = q_home * per;
+		const uint32_t cnt = lo >= ntiles ? 0u : (ntiles - lo < per ? ntiles - lo : per);
+		early = q_rank < cnt;		// else: fewer tiles than blocks here
+		if constexpr (FEED != Feed::Nco_ConstXY) {
+			if (early) {
+#pragma unroll
+				for (int s = 0; s < kSeedSub; s++)
+					pa[s] = __builtin_nontemporal_load(&phin[row_vec(lo + q_rank, s)]);
+			}
+		}
+	}
 	uint32_t *lds_buckets = lds;				// nbuckets x 2
 	uint32_t *lds_seeds = lds + (size_t)sa.nbuckets * 2;	// 4L x 4 words
 	const int L = sa.nleaves;
 	const uint32_t seed_base = (uint32_t)sa.nbuckets * 8u;
 
+	constexpr int kDtR = NLIVE - M;
+	constexpr int kDtN = DT ? dt_levels(kDtR) : 0;
+	uint32_t dt_bk[kDtMaxLevels] = {}, dt_lf[kDtMaxLevels] = {};
+	if constexpr (DT) {
+		static_assert((C::lj != 0 || !C::wide) && !DYN && !UG,
+			"direction tails: static left-justified or 32-bit instances");
+		static_assert(kDtN >= 1 && kDtN <= kDtMaxLevels, "no group to look up");
+		dt_lds_layout(sa.dt, seed_base + 4u * (uint32_t)L * 16u + 16u, dt_bk, dt_lf);
+	}
+	if (sa.image != nullptr) {
+		// the plan holds this prologue's result for (x0, y0): copy it
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(sa.image);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+		for (uint32_t i = threadIdx.x; i < sa.image_words / 4u; i += kSeedBlock)
+			dst[i] = src[i];
+	} else {
 	// bucket entries as the lookup wants them: {bound - 1, byte address of
 	// the bucket's first leaf in quadrant 0}.  A bucket without a boundary
 	// gets its own last phase as the bound (the compare below looks at bit
@@ -1103,14 +1178,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	// residual u and leaf entries {ns_0, s_0, ns_1, s_1, ... (the multipliers
 	// -/+ s_j 2^LJ of the group's stages), off'} with u_next = u - off'
 	// (cordic_internal.h: dt_pairs, dt_entry_dwords).
-	constexpr int kDtR = NLIVE - M;
-	constexpr int kDtN = DT ? dt_levels(kDtR) : 0;
-	uint32_t dt_bk[kDtMaxLevels] = {}, dt_lf[kDtMaxLevels] = {};
 	if constexpr (DT) {
-		static_assert((C::lj != 0 || !C::wide) && !DYN && !UG,
-			"direction tails: static left-justified or 32-bit instances");
-		static_assert(kDtN >= 1 && kDtN <= kDtMaxLevels, "no group to look up");
-		dt_lds_layout(sa.dt, seed_base + 4u * (uint32_t)L * 16u + 16u, dt_bk, dt_lf);
 #pragma unroll
 		for (int g = 0; g < kDtN; g++) {
 			const DtLevel lv = sa.dt.lv[g];
@@ -1144,7 +1212,16 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			}
 		}
 	}
+	}	// (sa.image == nullptr)
 	__syncthreads();
+	if (sa.image_out != nullptr) {
+		// build mode (one block, no samples): the LDS as it stands IS the image
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(lds);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(sa.image_out);
+		for (uint32_t i = threadIdx.x; i < sa.image_words / 4u; i += kSeedBlock)
+			dst[i] = src[i];
+		return;
+	}
 
 	LjRegs ljc{};
 	if constexpr (C::lj != 0) {
@@ -1476,9 +1553,6 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// contiguous 16 KiB stretch per array): with two rows a lane rotates
 		// 8 samples per rendezvous, which halves the barriers, the tickets and
 		// the per-pass scalar work per sample.
-		constexpr uint32_t kTileVecs = (uint32_t)kSeedBlock * kSeedSub;
-		const uint32_t ntiles = (uint32_t)((nvec + kTileVecs - 1) / kTileVecs);
-		const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
 		// three tile-id slots behind the seeds, addressed like them by byte
 		// offset (ds_read / ds_write: a generic `volatile` pointer would
 		// become flat loads with a vmcnt(0) wait each)
@@ -1494,11 +1568,15 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		};
 		// the ticket is drawn first and looked at later (resolve), so that
 		// the atomic's round trip is not waited for where it is issued
+		// (tickets 0 .. 2 R_j - 1 of range j are the static head: above)
+		auto q_base = [&]() -> uint32_t {
+			return 2u * q_blocks((home + tried) % kQueueCounters);
+		};
 		auto draw = [&]() -> uint32_t {
 			uint32_t lo, cnt;
 			uint32_t *c = range_of(lo, cnt);
 			return (tried < (uint32_t)kQueueCounters && cnt != 0)
-				? atomicAdd(c, 1u) : kEnd;
+				? atomicAdd(c, 1u) + q_base() : kEnd;
 		};
 		auto resolve = [&](uint32_t ticket) -> uint32_t {
 			for (;;) {
@@ -1512,7 +1590,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 				if (tried >= (uint32_t)kQueueCounters)
 					return kEnd;
 				c = range_of(lo, cnt);
-				ticket = cnt != 0 ? atomicAdd(c, 1u) : kEnd;
+				ticket = cnt != 0 ? atomicAdd(c, 1u) + q_base() : kEnd;
 			}
 		};
 		// Block-wide rendezvous on LDS contents only.  __syncthreads() also
@@ -1525,9 +1603,11 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// LDS), so that the phases of the next tile can be prefetched while
 		// this one is being rotated
 		if (threadIdx.x == 0) {
-			home = xcc_id() % kQueueCounters;
-			slot[0] = resolve(draw());
-			slot[1] = resolve(draw());
+			// home = blockIdx mod 8: the XCD the dispatcher's round robin
+			// puts the block on (affinity only; nothing depends on it)
+			home = q_home;
+			slot[0] = resolve(q_rank);
+			slot[1] = resolve(q_rank + q_blocks(q_home));
 		}
 		lds_barrier();
 		// Tile ids are block-uniform: kept in SGPRs (readfirstlane), so the
@@ -1537,29 +1617,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// address arithmetic in the pass.
 		uint32_t cur = __builtin_amdgcn_readfirstlane(slot[0]);
 		int ring = 0;
-		const uint32_t lane = threadIdx.x;
-		// vectors of the tile that exist (only the batch's last tile is partial)
-		const uint32_t last_live = (uint32_t)(nvec - (size_t)(ntiles - 1) * kTileVecs);
-		auto live = [&](uint32_t tile) -> uint32_t {
-			return tile == ntiles - 1 ? last_live : kTileVecs;
-		};
 		// One pass over tile `cur` with its phases in `in`; the phases of the
 		// next tile are prefetched into `pre` (which may be `in` itself: the
 		// phases are widened into registers first).
 		// (Storing the results one pass late, so that the compiler's
 		// vmcnt(0) wait for the prefetch never meets a young store, measured
 		// no gain: same-box A/B in profiles/r02/ab_delayed_stores.txt.)
-		// a lane's vector in row s of a tile, clamped into the tile's live
-		// part (only the batch's last tile is partial): the loads need no
-		// predicate, so nothing has to be preserved around them
-		auto row_vec = [&](uint32_t tile, int s) -> size_t {
-			uint32_t l = lane + (uint32_t)s * kSeedBlock;
-			const uint32_t top = live(tile) - 1u;	// block-uniform
-			// (spelled out: left to itself the compiler selects with
-			// v_cndmask_b32, ~23 cycles per wave-instruction here, §4.1)
-			asm("v_min_u32 %0, %1, %2" : "=v"(l) : "v"(l), "s"(top));
-			return (size_t)tile * kTileVecs + l;
-		};
 		auto tile_pass = [&](typename IO::uvec (&ph)[kSeedSub]) {
 			const uint32_t nxt = __builtin_amdgcn_readfirstlane(slot[(ring + 1) % 3]);
 			// the phases of this tile are consumed first ...
@@ -1609,9 +1672,10 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			cur = nxt;
 			ring = (ring + 1) % 3;
 		};
-		typename IO::uvec pa[kSeedSub] = {};
 		if constexpr (FEED != Feed::Nco_ConstXY) {
-			if (cur != kEnd) {
+			// (the first tile's phases are on their way since before the
+			// prologue, unless this block's home range had no tile for it)
+			if (!early && cur != kEnd) {
 #pragma unroll
 				for (int s = 0; s < kSeedSub; s++)
 					pa[s] = __builtin_nontemporal_load(&phin[row_vec(cur, s)]);

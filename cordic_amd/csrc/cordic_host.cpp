@@ -343,6 +343,7 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 	const bool host_retires = stage_out[0] || stage_out[1];
 	int rc = CORDIC_OK;
 	size_t retired = 0;
+	bool any_seeded = false;	// what really ran (cordic_last_kernel per chunk)
 	for (size_t c = 0; c < nc && rc == CORDIC_OK; c++) {
 		Slot &s = hp.slot[c % kSlots];
 		size_t off, cnt;
@@ -395,6 +396,8 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 					static_cast<int32_t *>(s.dout[1]), hp.s_run);
 		if (rc != CORDIC_OK)
 			break;
+		any_seeded |= !j.r2p && j.scalar
+			&& cordic_last_kernel() == CORDIC_KERNEL_SEEDED;
 		fine = ok(hipEventRecord(s.done, hp.s_run))
 			&& ok(hipStreamWaitEvent(hp.s_down, s.done, 0));
 		for (int a = 0; a < 2 && fine; a++) {
@@ -445,7 +448,7 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 	for (int a = 0; a < j.nin; a++) st.staged_inputs += stage_in[a] ? 1 : 0;
 	st.staged_outputs = (stage_out[0] ? 1 : 0) + (stage_out[1] ? 1 : 0);
 	st.copy_threads = any_stage && hp.pool ? hp.pool->threads() : 0;
-	st.seeded_plan = (j.scalar && hp.plan) ? 1 : 0;	// (vectors: its direction tables)
+	st.seeded_plan = any_seeded ? 1 : 0;	// a chunk ran the table-seeded kernel
 	st.seconds = std::chrono::duration<double>(
 			std::chrono::steady_clock::now() - t_begin).count();
 	return rc;

@@ -231,6 +231,25 @@ enum class Feed : int {
 	Nco_ConstXY	   = 2	// phase from the sample index (cordic_nco)
 };
 
+// Round 5: what the seeded kernels' prologue computes -- the seeds of every
+// (octant, leaf) for ONE constant vector, the buckets, the tail tables: the
+// block's LDS image -- kept on the device by the plan, per (container, x0, y0).
+// Write-once slots: an image is built by the kernel itself in build mode
+// (cordic_device.h: SeedArgs::image_out) on the stream of the first launch that
+// wants it, other streams wait for that launch's event until the host has seen
+// it complete, and a slot is never rewritten -- so nothing a launch in flight
+// (or a captured graph) reads can change under it.  More than kSeedImageSlots
+// different vectors on one plan: the later ones run the in-kernel prologue, as
+// every launch did before round 5.  Implemented in cordic_kernels.hip.
+constexpr int kSeedImageSlots = 8;
+struct SeedImages;
+SeedImages *seed_images_create();
+void	seed_images_destroy(SeedImages *c);
+bool	seed_images_settle(SeedImages *c);	// host wait; false: an event failed
+// images held, launches served from one, launches that ran the prologue
+void	seed_images_info(const SeedImages *c, int32_t *held, uint64_t *hits,
+		uint64_t *misses);
+
 struct RotatorJob {
 	const int32_t  *x = nullptr, *y = nullptr;	// Feed::PhaseArray_XYArray
 	const uint32_t *phase = nullptr;
@@ -254,6 +273,13 @@ struct RotatorJob {
 	// memory that no other launch in flight uses (the kernel leaves it zeroed
 	// again: cordic_device.h queue_leave); NULL = static chunk-per-block sweep
 	uint32_t *queue = nullptr;
+	// the plan's cache of prologue images (NULL: every block computes its own)
+	SeedImages *images = nullptr;
+	// build the image for (x0, y0) and return: no samples (cordic_plan_prepare)
+	bool	prepare_only = false;
+	// batch size from which the plan takes its table-driven kernels
+	// (cordic_plan_set_min_samples); < 0: the library's default
+	long long min_samples = -1;
 };
 #define CORDIC_QUEUE_BYTES 2048	/* 8 counters, one 256-byte line each */
 

@@ -7,6 +7,8 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
+#include <new>
 #include <type_traits>
 
 #include "cordic_device.h"
@@ -19,8 +21,150 @@ namespace cordic_amd {
 // rotator / converter launch (diagnostic; lets a test assert that the fast
 // path really ran instead of a quietly slower one)
 thread_local int g_last_kernel = CORDIC_KERNEL_NONE;
+
+// ---- prologue images of the seeded kernels (cordic_internal.h: SeedImages)
+struct SeedImages {
+	struct Slot {
+		uint32_t *d = nullptr;
+		size_t	bytes = 0;
+		int	container = 0;
+		int32_t	x0 = 0, y0 = 0;
+		hipEvent_t ready = nullptr;	// behind the build kernel
+		bool	settled = false;	// `ready` has been seen complete
+	};
+	std::mutex mu;
+	Slot	slot[kSeedImageSlots];
+	int	used = 0;
+	unsigned long long hits = 0, misses = 0;
+};
+
+SeedImages *seed_images_create() { return new (std::nothrow) SeedImages; }
+
+void seed_images_destroy(SeedImages *c)
+{
+	if (!c)
+		return;
+	for (SeedImages::Slot &s : c->slot) {
+		if (s.ready) (void)hipEventDestroy(s.ready);
+		if (s.d) (void)hipFree(s.d);
+	}
+	delete c;
+}
+
+// wait (on the host) until every image built so far is complete and mark it
+// so: what cordic_plan_prepare promises, so that a stream capture started
+// right behind it may use the image
+bool seed_images_settle(SeedImages *c)
+{
+	if (!c)
+		return true;
+	std::lock_guard<std::mutex> lock(c->mu);
+	bool fine = true;
+	for (int k = 0; k < c->used; k++) {
+		SeedImages::Slot &s = c->slot[k];
+		if (s.settled)
+			continue;
+		if (hipEventSynchronize(s.ready) == hipSuccess)
+			s.settled = true;
+		else {
+			(void)hipGetLastError();
+			fine = false;
+		}
+	}
+	return fine;
+}
+
+void seed_images_info(const SeedImages *c, int32_t *held, uint64_t *hits,
+		uint64_t *misses)
+{
+	SeedImages *m = const_cast<SeedImages *>(c);
+	if (held) *held = 0;
+	if (hits) *hits = 0;
+	if (misses) *misses = 0;
+	if (!m)
+		return;
+	std::lock_guard<std::mutex> lock(m->mu);
+	if (held) *held = m->used;
+	if (hits) *hits = m->hits;
+	if (misses) *misses = m->misses;
+}
+
 namespace {
 using namespace dev;
+
+// The image of (container, x0, y0) for a launch on `st`, or NULL (the kernel
+// then computes its prologue itself, as before).  `build(dst)` enqueues the
+// build-mode kernel on `st`.
+template <typename F>
+const uint32_t *seed_image_for(SeedImages &c, int container, int32_t x0, int32_t y0,
+		size_t bytes, hipStream_t st, F build)
+{
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (st && hipStreamIsCapturing(st, &cs) != hipSuccess) {
+		(void)hipGetLastError();
+		cs = hipStreamCaptureStatusNone;
+	}
+	const bool capturing = cs != hipStreamCaptureStatusNone;
+	std::lock_guard<std::mutex> lock(c.mu);
+	for (int k = 0; k < c.used; k++) {
+		SeedImages::Slot &s = c.slot[k];
+		if (s.container != container || s.x0 != x0 || s.y0 != y0 || s.bytes != bytes)
+			continue;
+		if (!s.settled) {
+			// (while a stream is being captured nothing may be asked of the
+			// runtime -- hipEventQuery invalidates a global-mode capture --
+			// and a graph must not depend on an event outside it: a captured
+			// launch takes an image only once the host KNOWS it is complete,
+			// which cordic_plan_prepare and any later eager launch establish)
+			if (capturing) {
+				c.misses++;
+				return nullptr;
+			}
+			if (hipEventQuery(s.ready) == hipSuccess) {
+				s.settled = true;
+			} else {
+				(void)hipGetLastError();	// hipErrorNotReady
+				if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) {
+					(void)hipGetLastError();
+					c.misses++;
+					return nullptr;
+				}
+			}
+		}
+		c.hits++;
+		return s.d;
+	}
+	c.misses++;
+	if (capturing || c.used >= kSeedImageSlots)
+		return nullptr;
+	SeedImages::Slot &s = c.slot[c.used];
+	if (!s.ready && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) {
+		(void)hipGetLastError();
+		s.ready = nullptr;
+		return nullptr;
+	}
+	if (s.d && s.bytes != bytes) {
+		(void)hipFree(s.d);
+		s.d = nullptr;
+	}
+	if (!s.d && hipMalloc((void **)&s.d, bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		s.d = nullptr;
+		return nullptr;
+	}
+	s.bytes = bytes;
+	if (!build(s.d) || hipGetLastError() != hipSuccess
+			|| hipEventRecord(s.ready, st) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;		// (the slot's memory is kept for the next try)
+	}
+	s.container = container;
+	s.x0 = x0;
+	s.y0 = y0;
+	s.settled = false;
+	c.used++;
+	return s.d;			// same stream: ordered behind the build
+}
 
 // ------------------------------------------------------------ generic path
 //
@@ -552,6 +696,10 @@ int general_stages_for(int ww)
 // takes the seeded kernel from this many samples on.  CORDIC_SEED_MIN_SAMPLES
 // overrides it (0: always seeded -- what the test suite sets, so that the
 // seeded kernels stay covered at test sizes).
+#ifndef CORDIC_SEED_MIN_LOG2_WITH_IMAGE
+#define CORDIC_SEED_MIN_LOG2_WITH_IMAGE 22
+#endif
+constexpr int kSeedMinLog2WithImage = CORDIC_SEED_MIN_LOG2_WITH_IMAGE;
 long long forced_min_samples()
 {
 	static const long long forced = [] {
@@ -560,17 +708,29 @@ long long forced_min_samples()
 	}();
 	return forced;
 }
-size_t seed_min_samples(const cordic_config &cfg)
+size_t seed_min_samples(const cordic_config &cfg, long long plan_value, bool image)
 {
+	if (plan_value >= 0)
+		return (size_t)plan_value;	// cordic_plan_set_min_samples
 	if (forced_min_samples() >= 0)
 		return (size_t)forced_min_samples();
+	// with the prologue served from the plan's image (round 5) the table
+	// kernels win from 2^22 samples on (16 stages: 18.7 against 20.7 us per
+	// launch there, 16.1 against 13.3 at 2^21; 24 stages: 22.6 / 26.1 and
+	// 19.3 / 16.3); where every block has to compute it (no plan image: more
+	// than kSeedImageSlots vectors, stream capture before cordic_plan_prepare)
+	// from 2^23 / 6 Mi (profiles/r05/small_batch.txt)
+	if (image)
+		return (size_t)1 << kSeedMinLog2WithImage;
 	return cfg.nlive <= 18 ? (size_t)1 << 23 : (size_t)3 << 21;
 }
 // ... and the same for per-sample vectors with looked-up directions: their
 // tables are small, but the plain kernel is still 10 % ahead up to 2^22
 // samples (9.2 against 7.9 us per launch at 2^20; 68.8 against 71.9 at 2^24)
-size_t dir_min_samples()
+size_t dir_min_samples(long long plan_value)
 {
+	if (plan_value >= 0)
+		return (size_t)plan_value;
 	if (forced_min_samples() >= 0)
 		return (size_t)forced_min_samples();
 	return (size_t)1 << 23;
@@ -608,8 +768,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 		bool done = false;
 		// constant-vector feeds with a plan: table-seeded kernel
 		if (FEED != Feed::PhaseArray_XYArray && j.seed_table
-				&& j.seed_m == kSeedStages && j.n >= (size_t)kVec
-				&& j.n >= seed_min_samples(cfg)
+				&& j.seed_m == kSeedStages
+				&& (j.prepare_only || (j.n >= (size_t)kVec
+					&& j.n >= seed_min_samples(cfg, j.min_samples,
+						j.images != nullptr)))
 				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)) {
 			static_assert(CORDIC_QUEUE_BYTES
 				== kQueueCounters * kQueueStride * 4, "queue layout");
@@ -621,9 +783,10 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 				sa.dt.n = 0;	// A/B: phase recurrence behind the seeds
 			// buckets, seeds, the three tile-id slots of the queue and the
 			// direction tails
-			const size_t lds = dt_lds_layout(sa.dt,
+			const size_t lds = (dt_lds_layout(sa.dt,
 					(uint32_t)((size_t)j.seed_nbuckets * 8
-					+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr);
+					+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr)
+					+ 15u) & ~(size_t)15;
 			// blocks per CU: 32 waves and 160 KiB of LDS to share
 			int per_cu = 32 / (kSeedBlock / 64);
 			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
@@ -633,35 +796,65 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
 			if (per_cu >= 1 && lds <= 160 * 1024) {
-				if (j.io16)
-					done = launch_seed_narrow16(FEED, cfg.nlive, g2, st,
-							kp, sa, j, lds);
-				else if (cfg.ww <= 32 && (cfg.needs_wrap
-						|| (cfg.flags & CORDIC_FLAG_NO_LJ)))
-					done = launch_seed_narrow(FEED, cfg.nlive, g2, st,
-							kp, sa, j, lds);
-				// (every other WW <= 34 core: left-justified by 30)
-				else if (cfg.ww == 35)
-					done = launch_seed_lj29(FEED, cfg.nlive, g2, st, kp,
-							sa, j, lds);
-				else if (cfg.ww < 35)
-					done = launch_seed_lj30(FEED, cfg.nlive, g2, st, kp,
-							sa, j, lds);
+				// which container's instance serves the core: 3 int16 arrays,
+				// 0 32-bit registers, 1 / 2 left-justified by 29 / 30
+				const int container = j.io16 ? 3
+					: (cfg.ww <= 32 && (cfg.needs_wrap
+						|| (cfg.flags & CORDIC_FLAG_NO_LJ))) ? 0
+					: cfg.ww == 35 ? 1 : 2;
+				auto run = [&](Feed feed, const SeedArgs &a, const RotatorJob &jj,
+						int grid_) -> bool {
+					switch (container) {
+					case 3: return launch_seed_narrow16(feed, cfg.nlive, grid_,
+							st, kp, a, jj, lds);
+					case 0: return launch_seed_narrow(feed, cfg.nlive, grid_,
+							st, kp, a, jj, lds);
+					case 1: return launch_seed_lj29(feed, cfg.nlive, grid_, st,
+							kp, a, jj, lds);
+					// (every other WW <= 34 core: left-justified by 30)
+					default: return cfg.ww < 35 && launch_seed_lj30(feed,
+							cfg.nlive, grid_, st, kp, a, jj, lds);
+					}
+				};
+				if (j.images && cfg.ww <= 35) {
+					// the prologue's result for this vector, from the plan
+					sa.image = seed_image_for(*j.images, container, kp.x0,
+						kp.y0, lds, st, [&](uint32_t *dst) {
+							SeedArgs b = sa;
+							b.queue = nullptr;
+							b.image = nullptr;
+							b.image_out = dst;
+							b.image_words = (uint32_t)(lds / 4);
+							RotatorJob bj = j;
+							bj.n = 0;
+							// (the phase-array instance: the one that
+							// carries the direction tails where there are any)
+							return run(Feed::PhaseArray_ConstXY, b, bj, 1);
+						});
+					sa.image_words = (uint32_t)(lds / 4);
+				}
+				if (j.prepare_only)
+					return sa.image ? check_launch() : CORDIC_ERR_UNSUPPORTED;
+				done = run(FEED, sa, j, g2);
 			}
 		}
+		if (j.prepare_only)
+			return CORDIC_ERR_UNSUPPORTED;	// no table kernel for this core
 		if (done)
 			g_last_kernel = CORDIC_KERNEL_SEEDED;
 		// per-sample vectors with a plan: directions looked up
 		// (cordic_xydir.h); cores / counts without an instance fall through
 		if (FEED == Feed::PhaseArray_XYArray && j.dir_table && j.dx.n > 0
 				&& !j.io16 && j.n >= (size_t)kVec && kp.post_mul == 0
-				&& j.n >= dir_min_samples()
+				&& j.n >= dir_min_samples(j.min_samples)
 				&& kp.in_shl >= 1 && kp.in_shl <= 30 && cfg.ww <= 35
 				&& !cfg.needs_wrap
 				&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))) {
 			dev::DirArgs da{j.dir_table, j.dx};
 			const size_t lds = dev::dx_lds_layout(j.dx, nullptr, nullptr);
-			done = cfg.ww == 35
+			// (no opt-in to more dynamic LDS than a launch gets by default:
+			// a table that large runs the plain kernel instead of failing)
+			done = lds > 64 * 1024 ? false : cfg.ww == 35
 				? launch_xydir_lj29(cfg.nlive, grid, st, kp, da, j, lds)
 				: launch_xydir_lj30(cfg.nlive, grid, st, kp, da, j, lds);
 			if (done)
@@ -728,6 +921,8 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			return check_launch();
 		}
 	}
+	if (j.prepare_only)
+		return CORDIC_ERR_UNSUPPORTED;
 	const int grid = grid_for(kBlock, j.n);
 	if (grid < 0)
 		return CORDIC_ERR_DEVICE;
@@ -748,6 +943,8 @@ int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		return CORDIC_ERR_MODE;
 	if (!config_sane(cfg))
 		return CORDIC_ERR_ARGS;
+	if (job.prepare_only)
+		return launch_rot_feed<Feed::PhaseArray_ConstXY>(cfg, job, stream);
 	if (job.n == 0)
 		return CORDIC_OK;
 	if (!job.ox || !job.oy)

@@ -306,7 +306,11 @@ size_t build_dir_table(const cordic_config &c, uint32_t *buf, size_t cap,
 	std::vector<uint32_t> tail(4, 0u);
 	DxInfo info;
 	info.bias0 = (uint32_t)bias;
-	size_t lds_at = 0;
+	// LDS of rotator_xydir (cordic_xydir.h: dx_lds_layout): the fold's eight
+	// 16-byte rows first, then per group its buckets (aligned to their total
+	// size) and leaf entries -- the same arithmetic, so that the bound checked
+	// below is the figure the launch asks for
+	size_t lds_at = 8 * 16;
 	for (int g = 0; g < ngroups; g++) {
 		const int t = dx_size(c.nlive, g), s0 = dx_first(c.nlive, g);
 		uint32_t a2[8];
@@ -386,7 +390,7 @@ size_t build_dir_table(const cordic_config &c, uint32_t *buf, size_t cap,
 	// signed number scaled by 2^31 (cordic_device.h: RotChainLJ)
 	if (dx_rest(c.nlive) > 0 && (rmin < -((int64_t)1 << 28) || rmax >= ((int64_t)1 << 28)))
 		return 0;
-	if (lds_at + 256 > 60 * 1024)		// (with the fold's rows; two blocks per CU at least)
+	if (lds_at > 60 * 1024)		// (the 64 KiB a launch gets without opting in)
 		return 0;
 	info.n = ngroups;
 	info.bias_last = (uint32_t)bias;

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 			}
 			constexpr int W = 2 * T + (more ? 1 : 0);	// dwords used
 			constexpr int kStride = dt_entry_dwords(T) * 4;
+			// the prologue writes 2 T + 1 dwords per entry whatever
+			// CORDIC_DT_SINGLES says about the seeded kernel's entries
+			static_assert(dt_entry_dwords(T) >= 2 * T + 1, "entry stride");
 			uint32_t ea[kVec];
 #pragma unroll
 			for (int v = 0; v < kVec; v++) {

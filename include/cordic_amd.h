@@ -243,16 +243,33 @@ int	cordic_last_kernel(void);
  * fixed as in bench/cpp/cordic_tb.cpp:68-69 -- replace the first 11
  * micro-rotations by an exact table lookup: the (x, y) state after 11 stages
  * depends only on the octant and on the 11 rotation directions, which are a
- * monotone step function of the phase with integer break points.  The kernel
- * fills the (x, y) table itself on every launch with the exact recurrence, so
- * results are bit-identical for every phase and nothing is cached across
- * calls.  Cores that are not eligible (r2p, WW > 35, fewer than 11 live
- * stages) simply run the ordinary kernels -- and so do SMALL batches: building
- * the table costs every launch ~10 us, so below 2^23 samples (6 Mi for cores
- * of more than 18 stages) a plan launches the full recurrence, which is then
- * the faster kernel (11.5 against 23 us per launch at 2^20 samples);
- * CORDIC_SEED_MIN_SAMPLES in the environment moves that size (0: always the
- * table).  Same results either way.
+ * monotone step function of the phase with integer break points.  The (x, y)
+ * table itself is computed ON THE DEVICE with the exact recurrence, by the
+ * kernel's own prologue, so results are bit-identical for every phase.
+ *
+ * Since round 5 the plan KEEPS that prologue's result -- the block's LDS image:
+ * seeds of every (octant, leaf), buckets, tail tables; 136 KiB -- per constant
+ * vector (xval, yval): the first launch with a new vector runs the kernel once
+ * in build mode (one block, ~15 us) on the caller's stream, every later launch
+ * with that vector copies the image instead of recomputing it (~10 us of every
+ * launch before).  Image slots are write-once (cordic_plan_image_info: up to 8
+ * vectors per plan; later ones compute in the kernel as before), launches on
+ * other streams are ordered behind the build on the device, and a launch that
+ * is being CAPTURED into a HIP graph only uses an image the host already
+ * knows to be complete -- call cordic_plan_prepare(plan, xval, yval, stream)
+ * before capturing to get it (a captured launch without one computes its own
+ * prologue, same bits).  CORDIC_SEED_IMAGES=0 in the
+ * environment of cordic_plan_create turns the cache off (A/B).
+ *
+ * Cores that are not eligible (r2p, WW > 35, fewer than 11 live stages) simply
+ * run the ordinary kernels -- and so do SMALL batches: below 2^22 samples (2^23
+ * / 6 Mi where no image serves the launch) a plan launches the full recurrence,
+ * which has no table to stage and is then the faster kernel
+ * (profiles/r05/small_batch.txt).  cordic_plan_set_min_samples moves that size
+ * for one plan (0: always the tables; < 0: back to the default);
+ * CORDIC_SEED_MIN_SAMPLES in the environment is the process-wide default for
+ * plans that have not been told (the test suite sets 0).  Same results either
+ * way.  Many small jobs in ONE launch: cordic_jobset below.
  *
  * Tile queues and HIP graphs.  A plan (likewise a table / quad handle) owns a
  * ring of tile-queue counter blocks; every launch takes one and the ring hands
@@ -279,6 +296,19 @@ typedef struct cordic_queue_info {
 } cordic_queue_info;
 
 int	cordic_plan_create(const cordic_config *cfg, cordic_plan **plan);
+/* Build the seed image of (xval, yval) now, on `stream` (see above), and
+ * return when it is complete (a set-up call: it waits ~15 us for one block);
+ * not inside a stream capture.  CORDIC_ERR_UNSUPPORTED for cores without a
+ * seed table or when all image slots are taken. */
+int	cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
+		void *stream);
+/* images held, launches served from one, launches that computed their own
+ * prologue (any pointer may be NULL) */
+int	cordic_plan_image_info(const cordic_plan *plan, int32_t *held,
+		uint64_t *hits, uint64_t *misses);
+/* batch size (samples) from which this plan's table-driven kernels serve a
+ * call; < 0: the library's default */
+int	cordic_plan_set_min_samples(cordic_plan *plan, long long min_samples);
 int	cordic_plan_queue_info(const cordic_plan *plan, cordic_queue_info *info);
 void	cordic_plan_destroy(cordic_plan *plan);
 const cordic_config *cordic_plan_config(const cordic_plan *plan);
@@ -833,7 +863,8 @@ typedef struct cordic_host_stats {
 	int32_t	staged_inputs;		/* input arrays that were pageable   */
 	int32_t	staged_outputs;		/* output arrays that were pageable  */
 	int32_t	copy_threads;		/* host threads that staged (0: none) */
-	int32_t	seeded_plan;		/* 1: constant vectors, plan kernel  */
+	int32_t	seeded_plan;		/* 1: a chunk ran the table-seeded
+					   kernel (cordic_last_kernel)      */
 	double	seconds;		/* wall time inside the call         */
 } cordic_host_stats;
 int	cordic_host_last_stats(cordic_host_stats *out);

@@ -44,7 +44,7 @@ def test_pageable_arrays_every_size(n):
     b = O.rotate(ocfg, x, y, ph)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     a = ca.p2r_host(cfg, 2**31 - 1, 0, ph)
-    assert ca.host_last_stats()["seeded_plan"] == 1
+    assert ca.host_last_stats()["seeded_plan"] == (1 if n >= 4 else 0)
     b = O.rotate(ocfg, 2**31 - 1, 0, ph)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     cfg, ocfg = both(ca.R2P, 24, 24, 2, -1, 20)

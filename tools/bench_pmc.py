@@ -87,6 +87,13 @@ def measure_pmc(args):
                 for row in csv.DictReader(open(f)):
                     if (row["Counter_Name"] == ctr and kern
                             and kern in row["Kernel_Name"]):
+                        # (not the one-block launch that builds a plan's seed
+                        # image: same kernel, build mode, no samples)
+                        try:
+                            if int(row["Grid_Size"]) <= int(row["Workgroup_Size"]):
+                                continue
+                        except (KeyError, ValueError):
+                            pass
                         rows.append(float(row["Counter_Value"]))
             if not rows:
                 return {"error": "no %s rows for %s (rocprofv3 rc %d)"

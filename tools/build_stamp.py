@@ -80,6 +80,8 @@ def stamp():
 
 def write_build_info():
     head, dirty = git_head()
+    if head is None:
+        return      # no .git and no earlier record: nothing to add, nothing lost
     with open(os.path.join(ROOT, "cordic_amd", "BUILD_INFO.json"), "w") as f:
         json.dump({"git_head": head, "git_dirty": dirty,
                    "kernel_sources_sha256": kernel_sources_sha256()}, f)

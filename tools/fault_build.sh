@@ -8,7 +8,12 @@
 # round-3 one (exchange complete inside ncclGroupEnd) could not.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}	# as cordic_amd/csrc/Makefile
+ARCH=${ARCH:-gfx950}
 cd "$ROOT/cordic_amd/csrc"
+# the product build's objects are reused: make them if a snapshot (or `make
+# clean`) left only the library behind
+ls build/*.o > /dev/null 2>&1 || make -j"$(nproc)" HIPCC="$HIPCC" ARCH="$ARCH"
 mkdir -p build_fault
 find build_fault -type l -delete	# objects of an earlier source layout
 # every other object is identical: reuse the product build's
@@ -19,6 +24,6 @@ done
 g++ -O3 -std=c++17 -fPIC -fwrapv -Wall -Wno-unused-function -I"$ROOT/include" -I. \
 	-ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include \
 	-DCORDIC_FAULT_SKIP_JOB_ORDER -c cordic_group.cpp -o build_fault/cordic_group.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/cordic_amd/lib_fault.so" \
+"$HIPCC" --offload-arch="$ARCH" -shared -fPIC -o "$ROOT/cordic_amd/lib_fault.so" \
 	build_fault/*.o -ldl
 echo "built cordic_amd/lib_fault.so"

@@ -29,9 +29,20 @@ def counters(sub):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"),
                        recursive=True):
         for row in csv.DictReader(open(f)):
+            if one_block(row):
+                continue
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(
                 float(row["Counter_Value"]))
     return acc
+
+
+def one_block(row):
+    """the launch that builds a plan's seed image: the seeded kernel in build
+    mode, one block, no samples -- not a sample of the workload"""
+    try:
+        return int(row["Grid_Size"]) <= int(row["Workgroup_Size"])
+    except (KeyError, ValueError):
+        return False
 
 
 def short(name):
@@ -71,7 +82,7 @@ for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"),
                    recursive=True):
     last = {}
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+        if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and not one_block(row):
             last[row["Kernel_Name"]] = (float(row["Counter_Value"]),
                                         int(row["End_Timestamp"])
                                         - int(row["Start_Timestamp"]))

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Per-launch time of the constant-vector rotator against the batch size: the
-table-seeded kernel (every block rebuilds the seed table in its prologue)
-against the full recurrence (no prologue), cfg2's and cfg4's cores.  Where is
-the crossover, i.e. below which n should a plan launch the plain kernel?"""
+table-seeded kernel with its prologue served from the plan's image (round 5)
+and with every block rebuilding the seed table (round 4), against the full
+recurrence (no prologue), cfg2's and cfg4's cores.  Where is the crossover,
+i.e. below which n should a plan launch the plain kernel?"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,15 +16,19 @@ dev = torch.device("cuda:0")
 for ns in (16, 24):
     cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns)
     plan = ca.Plan(cfg)
+    os.environ["CORDIC_SEED_IMAGES"] = "0"      # round 4: every block computes
+    noimg = ca.Plan(cfg)                        # its own prologue
+    del os.environ["CORDIC_SEED_IMAGES"]
     plain = ca.Plan(cfg.with_flags(ca.FLAG_NO_SEED))
-    print("p2r %d stages: n, seeded us, plain us, seeded Gs/s, plain Gs/s" % ns)
+    print("p2r %d stages: n, seeded (plan image) us, seeded (prologue per block) us, "
+          "plain us, the three in Gs/s" % ns)
     for lg in range(12, 28):
         n = 1 << lg
         ph = torch.empty(n, dtype=torch.int32, device=dev)
         a = torch.empty_like(ph); b = torch.empty_like(ph)
         ca.fill_phase_ramp(ph, 0, 2)
         res = []
-        for p in (plan, plain):
+        for p in (plan, noimg, plain):
             reps = 200 if lg < 22 else 40
             for _ in range(5):
                 p.p2r_const(2**31 - 1, 0, ph, a, b)
@@ -35,9 +40,10 @@ for ns in (16, 24):
             e1.record()
             torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) / reps * 1e3)
-        print("  2^%-2d %9.2f %9.2f %8.1f %8.1f" % (lg, res[0], res[1],
-                                                   n / res[0] / 1e3, n / res[1] / 1e3))
-    plan.close(); plain.close()
+        print("  2^%-2d %9.2f %9.2f %9.2f %8.1f %8.1f %8.1f" % (
+            lg, res[0], res[1], res[2], n / res[0] / 1e3, n / res[1] / 1e3,
+            n / res[2] / 1e3))
+    plan.close(); noimg.close(); plain.close()
 # per-sample vectors: directions looked up (small tables) against the recurrence
 cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)
 plan = ca.Plan(cfg)
