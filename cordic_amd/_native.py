@@ -117,6 +117,27 @@ ABI = {
     "cordic_plan_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_plan_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p]),
+    "cordic_mix": (C.c_int, [_cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
+                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
+    "cordic_plan_mix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32,
+                                  C.c_uint32, C.c_uint64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "cordic_jobset_create": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t,
+                                       C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cordic_jobset_destroy": (None, [C.c_void_p]),
+    "cordic_jobset_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32)]),
+    "cordic_plan_run_jobs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p]),
+    "cordic_plan_p2r_const_batch": (C.c_int, [C.c_void_p, C.c_size_t,
+                                              C.c_void_p, C.c_int32, C.c_int32,
+                                              C.c_void_p]),
+    "cordic_plan_nco_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_int32, C.c_int32, C.c_void_p]),
+    "cordic_jobset_reap": (None, []),
     "cordic_plan_image_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),
@@ -397,6 +418,14 @@ class Plan:
                                      _ptr(ox), _ptr(oy), _stream(stream)),
                "cordic_plan_p2r")
 
+    def mix(self, phase0, fcw, index0, x, y, ox, oy, n=None, stream=None):
+        """fused NCO mixer through the plan (directions looked up)"""
+        n = x.numel() if n is None else n
+        _check(lib().cordic_plan_mix(self._h, n, phase0 & 0xffffffff,
+                                     fcw & 0xffffffff, index0, _ptr(x), _ptr(y),
+                                     _ptr(ox), _ptr(oy), _stream(stream)),
+               "cordic_plan_mix")
+
     @property
     def queue_info(self):
         """tile-queue ring of the handle (include/cordic_amd.h)"""
@@ -415,6 +444,17 @@ class Plan:
                                             C.byref(c)),
                "cordic_plan_image_info")
         return dict(held=a.value, hits=b.value, misses=c.value)
+
+    def p2r_const_batch(self, jobs, x0, y0, stream=None):
+        """one-shot batch of phase-array jobs (cordic_plan_p2r_const_batch)"""
+        _check(lib().cordic_plan_p2r_const_batch(
+            self._h, len(jobs), _job_array(jobs), x0, y0, _stream(stream)),
+            "cordic_plan_p2r_const_batch")
+
+    def nco_batch(self, jobs, x0, y0, stream=None):
+        _check(lib().cordic_plan_nco_batch(
+            self._h, len(jobs), _job_array(jobs), x0, y0, _stream(stream)),
+            "cordic_plan_nco_batch")
 
     def set_min_samples(self, n):
         """batch size from which the table-driven kernels serve (< 0: default)"""
@@ -455,6 +495,72 @@ class Plan:
                                      fcw & 0xffffffff, index0, x0, y0,
                                      _ptr(ox), _ptr(oy), _stream(stream)),
                "cordic_plan_nco")
+
+
+class _CJob(C.Structure):
+    _fields_ = [("d_phase", C.c_void_p), ("phase0", C.c_uint32),
+                ("fcw", C.c_uint32), ("index0", C.c_uint64),
+                ("d_oxval", C.c_void_p), ("d_oyval", C.c_void_p),
+                ("n", C.c_uint64)]
+
+
+JOBS_PHASE_ARRAYS, JOBS_NCO = 0, 1
+
+
+def _job_array(jobs):
+    """jobs: dicts / tuples with phase (tensor or None), ox, oy, n and, for
+    NCO jobs, phase0, fcw, index0 -> a C array of cordic_job"""
+    arr = (_CJob * max(1, len(jobs)))()
+    for k, jb in enumerate(jobs):
+        ph = jb.get("phase")
+        arr[k].d_phase = _ptr(ph) if ph is not None else None
+        arr[k].phase0 = jb.get("phase0", 0) & 0xffffffff
+        arr[k].fcw = jb.get("fcw", 0) & 0xffffffff
+        arr[k].index0 = jb.get("index0", 0)
+        arr[k].d_oxval = _ptr(jb["ox"])
+        arr[k].d_oyval = _ptr(jb["oy"])
+        arr[k].n = jb["n"]
+    return arr
+
+
+class Jobset:
+    """cordic_jobset: many small jobs cut into tiles once, run in one launch."""
+
+    def __init__(self, plan, kind, jobs):
+        self.plan = plan
+        self._keep = jobs          # the tensors behind the addresses
+        arr = _job_array(jobs)
+        h = C.c_void_p()
+        _check(lib().cordic_jobset_create(plan._h, kind, len(jobs), arr,
+                                          C.byref(h)), "cordic_jobset_create")
+        self._h = h
+
+    @property
+    def info(self):
+        a, b, c = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _check(lib().cordic_jobset_info(self._h, C.byref(a), C.byref(b),
+                                        C.byref(c)), "cordic_jobset_info")
+        return dict(samples=a.value, tiles=b.value, tail_samples=c.value)
+
+    def run(self, x0, y0, stream=None, plan=None):
+        _check(lib().cordic_plan_run_jobs((plan or self.plan)._h, self._h, x0,
+                                          y0, _stream(stream)),
+               "cordic_plan_run_jobs")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cordic_jobset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def jobset_reap():
+    lib().cordic_jobset_reap()
 
 
 class Group:
@@ -1088,6 +1194,14 @@ def nco(cfg, n, phase0, fcw, index0, x0, y0, ox, oy, stream=None):
     _check(lib().cordic_nco(cfg.ref, n, phase0 & 0xffffffff, fcw & 0xffffffff,
                             index0, x0, y0, _ptr(ox), _ptr(oy),
                             _stream(stream)), "cordic_nco")
+
+
+def mix(cfg, phase0, fcw, index0, x, y, ox, oy, n=None, stream=None):
+    """cordic_mix: per-sample x / y rotated by phase0 + (index0 + i) * fcw"""
+    n = x.numel() if n is None else n
+    _check(lib().cordic_mix(cfg.ref, n, phase0 & 0xffffffff, fcw & 0xffffffff,
+                            index0, _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
+                            _stream(stream)), "cordic_mix")
 
 
 def r2p(cfg, x, y, mag, ophase, n=None, stream=None):

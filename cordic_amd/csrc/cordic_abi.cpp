@@ -262,6 +262,22 @@ int cordic_plan_p2r(const cordic_plan *plan, size_t n, const int32_t *d_xval,
 	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
+int cordic_plan_mix(const cordic_plan *plan, size_t n, uint32_t phase0,
+		uint32_t fcw, uint64_t index0, const int32_t *d_xval,
+		const int32_t *d_yval, int32_t *d_oxval, int32_t *d_oyval, void *stream)
+{
+	if (!plan)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x = d_xval; j.y = d_yval;
+	j.phase0 = phase0; j.fcw = fcw; j.index0 = index0; j.xy_nco = true;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	j.dir_table = plan->d_dir;
+	j.dx = plan->dx;
+	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
+	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
+}
+
 int cordic_plan_queue_info(const cordic_plan *plan, cordic_queue_info *info)
 {
 	if (!plan || !info)
@@ -311,6 +327,15 @@ int cordic_plan_tail_info(const cordic_plan *plan, int32_t *ngroups,
 	return CORDIC_OK;
 }
 
+// launch with a tile queue no other launch in flight is using
+template <typename F> static int with_queue(const QueueRing &ring, void *stream, F launch)
+{
+	const int slot = ring.claim(stream);
+	const int rc = launch(ring.ptr(slot));
+	ring.launched(slot, stream, rc);
+	return rc;
+}
+
 static void attach_seed(const cordic_plan *plan, RotatorJob &j)
 {
 	j.seed_table = plan->d_table;
@@ -352,6 +377,224 @@ int cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
 	return rc;
 }
 
+// ------------------------------------------------------------- job sets
+// Many small jobs in one launch (include/cordic_amd.h, "job sets").  The host
+// cuts the batch into the seeded kernel's tiles once and keeps the table on
+// the device; running the set is then ONE launch of the dynamic-exit instance
+// (+ one small launch for trailing samples), whatever the number of jobs.
+struct cordic_jobset {
+	int	kind = 0;		// CORDIC_JOBS_PHASE_ARRAYS / CORDIC_JOBS_NCO
+	int	device = 0;
+	std::vector<cordic_job> jobs;	// host copy: the one-by-one fallback
+	uint32_t *d_tiles = nullptr, *d_tails = nullptr;
+	JobTables tabs;
+	cordic_config cfg;		// of the plan it was cut for (PW decides NCO words)
+};
+
+namespace {
+// one-shot batches (cordic_plan_*_batch): the set has to outlive the launch
+// that reads it; it is parked here with an event and freed by a later call
+// once that event has completed (or by cordic_jobset_reap / process exit)
+struct Parked { cordic_jobset *set; hipEvent_t done; };
+std::mutex g_parked_mu;
+std::vector<Parked> g_parked;
+
+void reap_parked(bool wait)
+{
+	std::vector<Parked> dead;
+	{
+		std::lock_guard<std::mutex> lock(g_parked_mu);
+		for (size_t k = 0; k < g_parked.size();) {
+			Parked &p = g_parked[k];
+			const hipError_t e = wait ? hipEventSynchronize(p.done)
+						  : hipEventQuery(p.done);
+			if (e == hipSuccess || (wait && e != hipErrorNotReady)) {
+				dead.push_back(p);
+				g_parked.erase(g_parked.begin() + (long)k);
+			} else {
+				(void)hipGetLastError();
+				k++;
+			}
+		}
+	}
+	for (Parked &p : dead) {
+		(void)hipEventDestroy(p.done);
+		cordic_jobset_destroy(p.set);
+	}
+}
+} // namespace
+
+int cordic_jobset_create(const cordic_plan *plan, int kind, size_t njobs,
+		const cordic_job *jobs, cordic_jobset **out)
+{
+	if (!plan || !out || (njobs && !jobs)
+			|| (kind != CORDIC_JOBS_PHASE_ARRAYS && kind != CORDIC_JOBS_NCO))
+		return CORDIC_ERR_ARGS;
+	if (plan->cfg.mode != CORDIC_P2R && plan->cfg.mode != CORDIC_SP2R)
+		return CORDIC_ERR_MODE;
+	std::vector<TileDesc> tiles;
+	std::vector<TailDesc> tails;
+	uint64_t samples = 0;
+	const int sh = 32 - plan->cfg.pw;
+	for (size_t k = 0; k < njobs; k++) {
+		const cordic_job &jb = jobs[k];
+		if (jb.n == 0)
+			continue;
+		if (!jb.d_oxval || !jb.d_oyval
+				|| (kind == CORDIC_JOBS_PHASE_ARRAYS && !jb.d_phase)
+				|| ((uintptr_t)jb.d_oxval & 3) || ((uintptr_t)jb.d_oyval & 3)
+				|| (kind == CORDIC_JOBS_PHASE_ARRAYS && ((uintptr_t)jb.d_phase & 3)))
+			return CORDIC_ERR_ARGS;
+		samples += jb.n;
+		const uint64_t nvec = jb.n / 4;
+		// the phase of sample s of the job, left-justified (NCO jobs)
+		auto nco_word = [&](uint64_t s) -> uint64_t {
+			const uint32_t f = jb.fcw << sh;
+			const uint32_t p = (jb.phase0 << sh) + (uint32_t)(jb.index0 + s) * f;
+			return ((uint64_t)f << 32) | p;
+		};
+		for (uint64_t v0 = 0; v0 < nvec; v0 += kJobTileVecs) {
+			TileDesc d{};
+			d.in = kind == CORDIC_JOBS_NCO ? nco_word(v0 * 4)
+				: (uint64_t)(uintptr_t)(jb.d_phase + v0 * 4);
+			d.ox = (uint64_t)(uintptr_t)(jb.d_oxval + v0 * 4);
+			d.oy = (uint64_t)(uintptr_t)(jb.d_oyval + v0 * 4);
+			d.live = (uint32_t)(nvec - v0 < kJobTileVecs ? nvec - v0 : kJobTileVecs);
+			tiles.push_back(d);
+		}
+		for (uint64_t s = nvec * 4; s < jb.n; s++) {
+			TailDesc d{};
+			d.in = kind == CORDIC_JOBS_NCO ? nco_word(s)
+				: (uint64_t)(uintptr_t)(jb.d_phase + s);
+			d.ox = (uint64_t)(uintptr_t)(jb.d_oxval + s);
+			d.oy = (uint64_t)(uintptr_t)(jb.d_oyval + s);
+			tails.push_back(d);
+		}
+		if (tiles.size() > 0x7fffffffu || tails.size() > 0x7fffffffu)
+			return CORDIC_ERR_ARGS;
+	}
+	cordic_jobset *set = new (std::nothrow) cordic_jobset;
+	if (!set)
+		return CORDIC_ERR_NOMEM;
+	set->kind = kind;
+	set->cfg = plan->cfg;
+	set->jobs.assign(jobs, jobs + njobs);
+	if (hipGetDevice(&set->device) != hipSuccess)
+		set->device = 0;
+	auto upload = [](const void *src, size_t bytes, uint32_t **dst) {
+		if (!bytes)
+			return true;
+		return hipMalloc((void **)dst, bytes) == hipSuccess
+			&& hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+	};
+	if (!upload(tiles.data(), tiles.size() * sizeof(TileDesc), &set->d_tiles)
+			|| !upload(tails.data(), tails.size() * sizeof(TailDesc), &set->d_tails)) {
+		(void)hipGetLastError();
+		cordic_jobset_destroy(set);
+		return CORDIC_ERR_DEVICE;
+	}
+	set->tabs.tiles = set->d_tiles;
+	set->tabs.ntiles = (uint32_t)tiles.size();
+	set->tabs.tails = set->d_tails;
+	set->tabs.ntails = (uint32_t)tails.size();
+	set->tabs.samples = samples;
+	*out = set;
+	return CORDIC_OK;
+}
+
+void cordic_jobset_destroy(cordic_jobset *set)
+{
+	if (!set)
+		return;
+	if (set->d_tiles) (void)hipFree(set->d_tiles);
+	if (set->d_tails) (void)hipFree(set->d_tails);
+	delete set;
+}
+
+int cordic_jobset_info(const cordic_jobset *set, uint64_t *samples,
+		uint32_t *tiles, uint32_t *tail_samples)
+{
+	if (!set)
+		return CORDIC_ERR_ARGS;
+	if (samples) *samples = set->tabs.samples;
+	if (tiles) *tiles = set->tabs.ntiles;
+	if (tail_samples) *tail_samples = set->tabs.ntails;
+	return CORDIC_OK;
+}
+
+int cordic_plan_run_jobs(const cordic_plan *plan, const cordic_jobset *set,
+		int32_t xval, int32_t yval, void *stream)
+{
+	if (!plan || !set)
+		return CORDIC_ERR_ARGS;
+	// cut for this core?  (the tile table holds PW-scaled phase words)
+	if (std::memcmp(&set->cfg, &plan->cfg, sizeof plan->cfg) != 0)
+		return CORDIC_ERR_ARGS;
+	const Feed feed = set->kind == CORDIC_JOBS_NCO ? Feed::Nco_ConstXY
+						     : Feed::PhaseArray_ConstXY;
+	RotatorJob j;
+	j.x0 = xval; j.y0 = yval;
+	attach_seed(plan, j);
+	int rc = with_queue(plan->queues, stream, [&](uint32_t *q) {
+		j.queue = q;
+		return launch_rotator_jobs(plan->cfg, feed, j, set->tabs, stream);
+	});
+	if (rc != CORDIC_ERR_UNSUPPORTED)
+		return rc;
+	// no seeded kernel for this core (or no tile queue to be had right now):
+	// the jobs one by one through the ordinary entry points -- same results
+	for (const cordic_job &jb : set->jobs) {
+		if (jb.n == 0)
+			continue;
+		rc = feed == Feed::Nco_ConstXY
+			? cordic_plan_nco(plan, (size_t)jb.n, jb.phase0, jb.fcw, jb.index0,
+				xval, yval, jb.d_oxval, jb.d_oyval, stream)
+			: cordic_plan_p2r_const(plan, (size_t)jb.n, xval, yval, jb.d_phase,
+				jb.d_oxval, jb.d_oyval, stream);
+		if (rc != CORDIC_OK)
+			return rc;
+	}
+	return CORDIC_OK;
+}
+
+static int run_batch_once(const cordic_plan *plan, int kind, size_t njobs,
+		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream)
+{
+	reap_parked(false);
+	cordic_jobset *set = nullptr;
+	if (int rc = cordic_jobset_create(plan, kind, njobs, jobs, &set))
+		return rc;
+	const int rc = cordic_plan_run_jobs(plan, set, xval, yval, stream);
+	// the tables have to stay until the launch has read them
+	hipEvent_t done = nullptr;
+	if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess
+			&& hipEventRecord(done, static_cast<hipStream_t>(stream)) == hipSuccess) {
+		std::lock_guard<std::mutex> lock(g_parked_mu);
+		g_parked.push_back(Parked{set, done});
+	} else {
+		(void)hipGetLastError();
+		if (done) (void)hipEventDestroy(done);
+		(void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+		cordic_jobset_destroy(set);
+	}
+	return rc;
+}
+
+int cordic_plan_p2r_const_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream)
+{
+	return run_batch_once(plan, CORDIC_JOBS_PHASE_ARRAYS, njobs, jobs, xval, yval,
+			stream);
+}
+
+int cordic_plan_nco_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream)
+{
+	return run_batch_once(plan, CORDIC_JOBS_NCO, njobs, jobs, xval, yval, stream);
+}
+
+void cordic_jobset_reap(void) { reap_parked(true); }
+
 int cordic_plan_set_min_samples(cordic_plan *plan, long long min_samples)
 {
 	if (!plan)
@@ -368,15 +611,6 @@ int cordic_plan_image_info(const cordic_plan *plan, int32_t *held, uint64_t *hit
 		return CORDIC_ERR_ARGS;
 	seed_images_info(plan->images, held, hits, misses);
 	return CORDIC_OK;
-}
-
-// launch with a tile queue no other launch in flight is using
-template <typename F> static int with_queue(const QueueRing &ring, void *stream, F launch)
-{
-	const int slot = ring.claim(stream);
-	const int rc = launch(ring.ptr(slot));
-	ring.launched(slot, stream, rc);
-	return rc;
 }
 
 int cordic_plan_p2r_const(const cordic_plan *plan, size_t n, int32_t xval,
@@ -1129,6 +1363,19 @@ int cordic_nco(const cordic_config *cfg, size_t n, uint32_t phase0, uint32_t fcw
 	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
 	j.index0 = index0; j.ox = d_oxval; j.oy = d_oyval; j.n = n;
 	return launch_rotator(*cfg, Feed::Nco_ConstXY, j, stream);
+}
+
+int cordic_mix(const cordic_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, const int32_t *d_xval, const int32_t *d_yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream)
+{
+	if (!cfg)
+		return CORDIC_ERR_ARGS;
+	RotatorJob j;
+	j.x = d_xval; j.y = d_yval;
+	j.phase0 = phase0; j.fcw = fcw; j.index0 = index0; j.xy_nco = true;
+	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
+	return launch_rotator(*cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
 int cordic_r2p(const cordic_config *cfg, size_t n, const int32_t *d_xval,

@@ -72,6 +72,9 @@ struct CoreParams {
 	uint64_t index0;	// NCO: global index of sample 0
 	uint32_t post_mul;	// 0, or the gain-annihilation multiplier
 				// (CORDIC_FLAG_UNIT_GAIN): o = (o * post_mul) >> 32
+	uint32_t xy_nco;	// per-sample vector feeds: 1 = the phase is not read
+				// from an array but generated, phase0 + (index0 + i)
+				// * fcw (the fused NCO MIXER, cordic_mix: round 5)
 };
 
 // ---------------------------------------------------------------- utilities
@@ -714,11 +717,16 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	// software prefetch: the loads of pass i+1 are issued before the ~750
 	// VALU instructions of pass i, so no wave ever parks on HBM latency
+	// the mixer (cordic_mix): per-sample vectors, generated phases -- a
+	// wave-uniform choice in the instances of the per-sample feed
+	const bool gen_phase = FEED == Feed::Nco_ConstXY
+		|| (FEED == Feed::PhaseArray_XYArray && kp.xy_nco != 0);
 	typename IO::uvec nph{};
 	typename IO::ivec nx{}, ny{};
 	if (g < nvec) {
 		if constexpr (FEED != Feed::Nco_ConstXY)
-			nph = CORDIC_LOAD_IN(&phin[g]);
+			if (!gen_phase)
+				nph = CORDIC_LOAD_IN(&phin[g]);
 		if constexpr (!kConstXY) {
 			nx = CORDIC_LOAD_IN(&xin[g]);
 			ny = CORDIC_LOAD_IN(&yin[g]);
@@ -730,7 +738,8 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		const size_t gn = g + stride;
 		if (gn < nvec) {
 			if constexpr (FEED != Feed::Nco_ConstXY)
-				nph = CORDIC_LOAD_IN(&phin[gn]);
+				if (!gen_phase)
+					nph = CORDIC_LOAD_IN(&phin[gn]);
 			if constexpr (!kConstXY) {
 				nx = CORDIC_LOAD_IN(&xin[gn]);
 				ny = CORDIC_LOAD_IN(&yin[gn]);
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void rotator_unrolled(CoreParams kp,
 		}
 
 		uint32_t P[kVec];
-		if constexpr (FEED == Feed::Nco_ConstXY) {
+		if (gen_phase) {
 			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
 			P[0] = kp.phase0 + s0 * kp.fcw;
 #pragma unroll
@@ -873,6 +882,11 @@ struct SeedArgs {
 	const uint32_t *image = nullptr;
 	uint32_t *image_out = nullptr;
 	uint32_t image_words = 0;
+	// Round 5, many small jobs in one launch (cordic_jobset): `tiles` != NULL
+	// = ntiles descriptors of 32 bytes, one per tile of the whole batch in
+	// queue order (cordic_internal.h: TileDesc); dynamic-exit instances only.
+	const uint32_t *tiles = nullptr;
+	uint32_t ntiles = 0;
 };
 
 // LDS of the direction tails of a seeded kernel: per group its buckets
@@ -1053,6 +1067,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	// BEFORE the prologue stages the table: a small batch no longer pays two
 	// serial atomic round trips and a load latency behind the prologue.
 	constexpr uint32_t kTileVecs = (uint32_t)kSeedBlock * kSeedSub;
+	static_assert(kTileVecs == kJobTileVecs, "cordic_jobset cuts its tiles on the host");
 	const uint32_t ntiles = (uint32_t)((nvec + kTileVecs - 1) / kTileVecs);
 	const uint32_t per = (ntiles + kQueueCounters - 1) / kQueueCounters;
 	const uint32_t lane = threadIdx.x;
@@ -1081,7 +1096,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	};
 	typename IO::uvec pa[kSeedSub] = {};
 	bool early = false;
-	if (sa.queue != nullptr && sa.image_out == nullptr) {
+	if (!DYN && sa.queue != nullptr && sa.image_out == nullptr) {
 		const uint32_t lo = q_home * per;
 		const uint32_t cnt = lo >= ntiles ? 0u : (ntiles - lo < per ? ntiles - lo : per);
 		early = q_rank < cnt;		// else: fewer tiles than blocks here
@@ -1537,7 +1552,186 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		apply_unit_gain<UG>(ry, kp);
 	};
 
+	if constexpr (DYN) {
 	if (sa.queue != nullptr) {
+		// Dynamic-exit instances: the queue of the static instances (below:
+		// read that comment first) one slot deeper and over TILE DESCRIPTORS
+		// -- where the tile's phases come from, where its results go, how
+		// many of its vectors exist.  For one job they are arithmetic on the
+		// kernel's arguments; for a BATCH (cordic_jobset: round 5, many small
+		// jobs in one launch, the fixed cost of a launch paid once) they are
+		// read from the job set's table, one 32-byte entry per tile in queue
+		// order.  The entry of the tile AFTER next is requested at the top of a
+		// pass and first looked at a pass later, so its latency is never
+		// waited for: hence the fourth slot and the third static ticket.
+		struct Desc { uint64_t in, ox, oy; uint32_t live; };
+		constexpr int kRing = 4;
+		typedef volatile __attribute__((address_space(3))) uint32_t lds_word;
+		lds_word *slot = (lds_word *)(uintptr_t)(seed_base + 4u * qstride);
+		constexpr uint32_t kEnd = 0xffffffffu;
+		const bool batch = sa.tiles != nullptr;
+		const uint32_t nt = batch ? sa.ntiles : ntiles;
+		const uint32_t per_d = (nt + kQueueCounters - 1) / kQueueCounters;
+		uint32_t home = 0, tried = 0;		// lane 0 of the block only
+		auto range_of = [&](uint32_t &lo, uint32_t &cnt) {
+			const uint32_t j = (home + tried) % kQueueCounters;
+			lo = j * per_d;
+			cnt = lo >= nt ? 0u : (nt - lo < per_d ? nt - lo : per_d);
+			return &sa.queue[j * kQueueStride];
+		};
+		auto q_base = [&]() -> uint32_t {	// three static tickets per block
+			return (uint32_t)(kRing - 1) * q_blocks((home + tried) % kQueueCounters);
+		};
+		auto draw = [&]() -> uint32_t {
+			uint32_t lo, cnt;
+			uint32_t *c = range_of(lo, cnt);
+			return (tried < (uint32_t)kQueueCounters && cnt != 0)
+				? atomicAdd(c, 1u) + q_base() : kEnd;
+		};
+		auto resolve = [&](uint32_t ticket) -> uint32_t {
+			for (;;) {
+				if (tried >= (uint32_t)kQueueCounters)
+					return kEnd;
+				uint32_t lo, cnt;
+				uint32_t *c = range_of(lo, cnt);
+				if (ticket < cnt)
+					return lo + ticket;
+				tried++;
+				if (tried >= (uint32_t)kQueueCounters)
+					return kEnd;
+				c = range_of(lo, cnt);
+				ticket = cnt != 0 ? atomicAdd(c, 1u) + q_base() : kEnd;
+			}
+		};
+		auto lds_barrier = [] {
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		};
+		if (threadIdx.x == 0) {
+			home = q_home;
+			auto head = [&](uint32_t t) -> uint32_t {
+				uint32_t lo, cnt;
+				range_of(lo, cnt);
+				return (tried == 0 && t < cnt) ? lo + t : resolve(draw());
+			};
+			const uint32_t R = q_blocks(q_home);
+			slot[0] = head(q_rank);
+			slot[1] = head(q_rank + R);
+			slot[2] = head(q_rank + 2u * R);
+		}
+		lds_barrier();
+		// the descriptor of a tile: block-uniform, kept in SGPRs
+		auto uni64 = [](uint64_t v) -> uint64_t {
+			// (the builtin returns a signed int: no sign extension into the
+			// high word)
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+			return ((uint64_t)hi << 32) | lo;
+		};
+		auto fetch = [&](uint32_t tile) -> Desc {
+			Desc d{0, 0, 0, 0};
+			if (tile == kEnd)
+				return d;
+			if (batch) {
+				const u32x4 *t = reinterpret_cast<const u32x4 *>(sa.tiles) + 2u * (size_t)tile;
+				const u32x4 a = t[0], b = t[1];
+				d.in = ((uint64_t)a[1] << 32) | a[0];
+				d.ox = ((uint64_t)a[3] << 32) | a[2];
+				d.oy = ((uint64_t)b[1] << 32) | b[0];
+				d.live = b[2];
+			} else {
+				const size_t v0 = (size_t)tile * kTileVecs;
+				if constexpr (FEED == Feed::Nco_ConstXY)
+					d.in = ((uint64_t)kp.fcw << 32)
+						| (uint32_t)(kp.phase0 + (uint32_t)(kp.index0 + v0 * kVec) * kp.fcw);
+				else
+					d.in = (uint64_t)(uintptr_t)(phin + v0);
+				d.ox = (uint64_t)(uintptr_t)(ox + v0);
+				d.oy = (uint64_t)(uintptr_t)(oy + v0);
+				d.live = live(tile);
+			}
+			return d;
+		};
+		auto settle = [&](const Desc &d) -> Desc {	// vector registers -> scalars
+			return Desc{uni64(d.in), uni64(d.ox), uni64(d.oy),
+				(uint32_t)__builtin_amdgcn_readfirstlane(d.live)};
+		};
+		auto load_rows = [&](const Desc &d, typename IO::uvec (&ph)[kSeedSub]) {
+			if constexpr (FEED != Feed::Nco_ConstXY) {
+				const typename IO::uvec *p =
+					reinterpret_cast<const typename IO::uvec *>((uintptr_t)d.in);
+#pragma unroll
+				for (int s = 0; s < kSeedSub; s++) {
+					uint32_t l = lane + (uint32_t)s * kSeedBlock;
+					asm("v_min_u32 %0, %1, %2" : "=v"(l) : "v"(l), "s"(d.live - 1u));
+					ph[s] = __builtin_nontemporal_load(&p[l]);
+				}
+			}
+		};
+		uint32_t cur = __builtin_amdgcn_readfirstlane(slot[0]);
+		uint32_t nxt = __builtin_amdgcn_readfirstlane(slot[1]);
+		int ring = 0;
+		Desc dcur = settle(fetch(cur)), dnxt = settle(fetch(nxt));
+		typename IO::uvec pd[kSeedSub] = {};
+		if (cur != kEnd)
+			load_rows(dcur, pd);
+		while (cur != kEnd) {
+			// the tile after next: its descriptor is asked for now ...
+			const uint32_t nn = __builtin_amdgcn_readfirstlane(slot[(ring + 2) % kRing]);
+			const Desc dnn = fetch(nn);
+			// ... this tile's phases are consumed ...
+			uint32_t pb[kSeedSub][kVec];
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++) {
+				if constexpr (FEED == Feed::Nco_ConstXY) {
+					const uint32_t f = (uint32_t)(dcur.in >> 32);
+					const uint32_t p0 = (uint32_t)dcur.in + 0x20000000u
+						+ (uint32_t)s * (uint32_t)(kSeedBlock * kVec) * f;
+					pb[s][0] = p0 + lane * (uint32_t)kVec * f;
+#pragma unroll
+					for (int v = 1; v < kVec; v++)
+						pb[s][v] = pb[s][v - 1] + f;
+				} else {
+					const u32x4 tph = IO::widen(pd[s]);
+#pragma unroll
+					for (int v = 0; v < kVec; v++)
+						asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(pb[s][v])
+							: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
+				}
+			}
+			// ... and the next tile's are prefetched into the same registers
+			if (nxt != kEnd)
+				load_rows(dnxt, pd);
+			uint32_t ahead = 0;
+			if (threadIdx.x == 0)
+				ahead = draw();
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++) {
+				if (lane + (uint32_t)s * kSeedBlock < dcur.live) {
+					i32x4 rx, ry;
+					pass_pb(std::false_type{}, pb[s], rx, ry);
+					typename IO::ivec *o0 = reinterpret_cast<typename IO::ivec *>(
+						(uintptr_t)dcur.ox) + (size_t)s * kSeedBlock;
+					typename IO::ivec *o1 = reinterpret_cast<typename IO::ivec *>(
+						(uintptr_t)dcur.oy) + (size_t)s * kSeedBlock;
+					CORDIC_STORE_OUT(true, &o0[lane], IO::narrow(rx));
+					CORDIC_STORE_OUT(true, &o1[lane], IO::narrow(ry));
+				}
+			}
+			if (threadIdx.x == 0)
+				slot[(ring + 3) % kRing] = resolve(ahead);
+			lds_barrier();
+			cur = nxt;
+			nxt = nn;
+			dcur = dnxt;
+			dnxt = settle(dnn);
+			ring = (ring + 1) % kRing;
+		}
+		if (threadIdx.x == 0)
+			queue_leave(sa.queue);
+		return;
+	}
+	}
+	if (!DYN && sa.queue != nullptr) {
 		// Work distribution, dynamic: the persistent blocks (they keep the
 		// table in LDS) pull 4096-sample tiles from a counter IN ADDRESS
 		// ORDER, the way the hardware dispatcher hands out the blocks of a
@@ -1606,8 +1800,15 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			// home = blockIdx mod 8: the XCD the dispatcher's round robin
 			// puts the block on (affinity only; nothing depends on it)
 			home = q_home;
-			slot[0] = resolve(q_rank);
-			slot[1] = resolve(q_rank + q_blocks(q_home));
+			// a static ticket is a number of the HOME range: once that range
+			// has nothing left for this block the next one is drawn
+			auto head = [&](uint32_t t) -> uint32_t {
+				uint32_t lo, cnt;
+				range_of(lo, cnt);
+				return (tried == 0 && t < cnt) ? lo + t : resolve(draw());
+			};
+			slot[0] = head(q_rank);
+			slot[1] = head(q_rank + q_blocks(q_home));
 		}
 		lds_barrier();
 		// Tile ids are block-uniform: kept in SGPRs (readfirstlane), so the

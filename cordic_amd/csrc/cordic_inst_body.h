@@ -152,7 +152,9 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 		tails_pay = kDtCoherentLog2 >= 31	// (A/B builds: every row)
 			|| (f < 0 ? -(int64_t)f : (int64_t)f) < ((int64_t)1 << (kDtCoherentLog2 - 8));
 	}
-	switch (nlive) {
+	// a batch (cordic_jobset: tile descriptors) runs the dynamic-exit instance,
+	// the one whose tile loop reads them
+	switch (sa.tiles ? -1 : nlive) {
 	// static instances; where the plan carries direction tails for the
 	// stages behind the seeds (left-justified cores with kDtMinStages or more of them),
 	// the instance that looks their multipliers up

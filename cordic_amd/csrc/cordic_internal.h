@@ -250,12 +250,41 @@ bool	seed_images_settle(SeedImages *c);	// host wait; false: an event failed
 void	seed_images_info(const SeedImages *c, int32_t *held, uint64_t *hits,
 		uint64_t *misses);
 
+// ---- many small jobs in one launch (cordic_jobset, round 5).  The batch is
+// cut into the seeded kernel's tiles on the host, once: one TileDesc per tile
+// in queue order, and one TailDesc per sample behind a job's last whole vector
+// (jobs need not be multiples of four samples).
+struct TileDesc {		// 32 bytes, read by rotator_seeded's dynamic-exit loop
+	uint64_t in;		// phase arrays: address of the tile's first i_phase
+				// word; NCO: {high: fcw, low: phase of the tile's
+				// first sample}, both left-justified
+	uint64_t ox, oy;	// addresses of the tile's first o_xval / o_yval words
+	uint32_t live;		// vectors (4 samples) of the tile that exist
+	uint32_t pad;
+};
+struct TailDesc {		// 32 bytes, one SAMPLE (rotator_job_tails)
+	uint64_t in;		// as TileDesc::in, for this one sample
+	uint64_t ox, oy;
+	uint64_t pad;
+};
+constexpr uint32_t kJobTileVecs = CORDIC_SEED_BLOCK * 2;	// = dev::kSeedBlock * kSeedSub
+struct JobTables {
+	const uint32_t *tiles = nullptr;	// device: ntiles x TileDesc
+	uint32_t ntiles = 0;
+	const uint32_t *tails = nullptr;	// device: ntails x TailDesc
+	uint32_t ntails = 0;
+	uint64_t samples = 0;			// of all jobs
+};
+
 struct RotatorJob {
 	const int32_t  *x = nullptr, *y = nullptr;	// Feed::PhaseArray_XYArray
 	const uint32_t *phase = nullptr;
 	int32_t  x0 = 0, y0 = 0;			// const feeds
 	uint32_t phase0 = 0, fcw = 0;			// NCO
 	uint64_t index0 = 0;				// NCO
+	// Feed::PhaseArray_XYArray with generated phases (the fused NCO mixer:
+	// per-sample i_xval / i_yval, i_phase = phase0 + (index0 + i) * fcw)
+	bool	 xy_nco = false;
 	int32_t  *ox = nullptr, *oy = nullptr;
 	size_t   n = 0;
 	// sample arrays hold int16 / uint16 values (the pointers above are then
@@ -285,6 +314,12 @@ struct RotatorJob {
 
 int	launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		void *stream);
+// a whole job set through the seeded kernel in ONE launch (+ one small launch
+// for the jobs' trailing samples); `job` carries the plan's tables, the
+// constant vector and the queue.  CORDIC_ERR_UNSUPPORTED: this core has no
+// seeded kernel -- the caller then runs the jobs one by one.
+int	launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &job,
+		const JobTables &tabs, void *stream);
 int	launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream,
 		bool io16 = false);

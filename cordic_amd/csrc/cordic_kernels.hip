@@ -188,6 +188,55 @@ __device__ __forceinline__ int32_t round_generic(int64_t v, const CoreParams &kp
 	return kp.post_mul ? unit_gain(o, kp.post_mul) : o;
 }
 
+// one sample of rtl/cordic.v:131-188, 231-283, 288-314, literally: fold,
+// kp.nlive micro-rotations with the explicit WW-bit wrap, rounding
+__device__ __forceinline__ void generic_rotate(const CoreParams &kp, uint32_t P,
+		int32_t ix, int32_t iy, int32_t &rx, int32_t &ry)
+{
+	const int64_t ex = (int64_t)((uint64_t)(int64_t)ix << kp.in_shl);
+	const int64_t ey = (int64_t)((uint64_t)(int64_t)iy << kp.in_shl);
+	int64_t x, y;
+	uint32_t p;
+	fold_octant<int64_t>(ex, ey, P, x, y, p);
+	x = wrap_ww(x, kp);
+	y = wrap_ww(y, kp);
+	for (int s = 0; s < kp.nlive; s++) {
+		const int k = (s + 1 > 63) ? 63 : s + 1;
+		const uint32_t a = kp.angle[s];
+		const int64_t sy = y >> k, sx = x >> k;
+		if ((int32_t)p < 0) {
+			x = x + sy; y = y - sx; p += a;
+		} else {
+			x = x - sy; y = y + sx; p -= a;
+		}
+		x = wrap_ww(x, kp);
+		y = wrap_ww(y, kp);
+	}
+	rx = round_generic(x, kp);
+	ry = round_generic(y, kp);
+}
+
+// The samples behind a job's last whole vector, for every job of a batch in
+// one launch (cordic_jobset): one lane per sample, addresses from the table.
+template <Feed FEED>
+__global__ __launch_bounds__(kBlock) void rotator_job_tails(CoreParams kp,
+		const TailDesc *__restrict__ t, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const TailDesc d = t[i];
+	uint32_t P;
+	if constexpr (FEED == Feed::Nco_ConstXY)
+		P = (uint32_t)d.in;
+	else
+		P = *reinterpret_cast<const uint32_t *>((uintptr_t)d.in) << kp.pw_shl;
+	int32_t rx, ry;
+	generic_rotate(kp, P, kp.x0, kp.y0, rx, ry);
+	*reinterpret_cast<int32_t *>((uintptr_t)d.ox) = rx;
+	*reinterpret_cast<int32_t *>((uintptr_t)d.oy) = ry;
+}
+
 template <Feed FEED, typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 		const typename IO::ielem *__restrict__ xin,
@@ -201,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 			i += stride) {
 		uint32_t P;
 		int32_t ix, iy;
-		if constexpr (FEED == Feed::Nco_ConstXY)
+		if (FEED == Feed::Nco_ConstXY
+				|| (FEED == Feed::PhaseArray_XYArray && kp.xy_nco))
 			P = kp.phase0 + (uint32_t)(kp.index0 + i) * kp.fcw;
 		else
 			P = (uint32_t)phin[i] << kp.pw_shl;
@@ -212,27 +262,10 @@ __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 			ix = kp.x0;
 			iy = kp.y0;
 		}
-		const int64_t ex = (int64_t)((uint64_t)(int64_t)ix << kp.in_shl);
-		const int64_t ey = (int64_t)((uint64_t)(int64_t)iy << kp.in_shl);
-		int64_t x, y;
-		uint32_t p;
-		fold_octant<int64_t>(ex, ey, P, x, y, p);
-		x = wrap_ww(x, kp);
-		y = wrap_ww(y, kp);
-		for (int s = 0; s < kp.nlive; s++) {
-			const int k = (s + 1 > 63) ? 63 : s + 1;
-			const uint32_t a = kp.angle[s];
-			const int64_t sy = y >> k, sx = x >> k;
-			if ((int32_t)p < 0) {
-				x = x + sy; y = y - sx; p += a;
-			} else {
-				x = x - sy; y = y + sx; p -= a;
-			}
-			x = wrap_ww(x, kp);
-			y = wrap_ww(y, kp);
-		}
-		ox[i] = (typename IO::ielem)round_generic(x, kp);
-		oy[i] = (typename IO::ielem)round_generic(y, kp);
+		int32_t rx, ry;
+		generic_rotate(kp, P, ix, iy, rx, ry);
+		ox[i] = (typename IO::ielem)rx;
+		oy[i] = (typename IO::ielem)ry;
 	}
 }
 
@@ -746,11 +779,12 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 	kp.phase0 = j.phase0 << kp.pw_shl;
 	kp.fcw = j.fcw << kp.pw_shl;
 	kp.index0 = j.index0;
+	kp.xy_nco = (FEED == Feed::PhaseArray_XYArray && j.xy_nco) ? 1u : 0u;
 
 	// the vector kernels need element alignment only (cordic_device.h: Io32)
 	bool (*const vec_aligned)(const void *) = j.io16 ? aligned2 : aligned4;
 	bool vec_ok = vec_aligned(j.ox) && vec_aligned(j.oy);
-	if (FEED != Feed::Nco_ConstXY)
+	if (FEED != Feed::Nco_ConstXY && !kp.xy_nco)
 		vec_ok = vec_ok && vec_aligned(j.phase);
 	if (FEED == Feed::PhaseArray_XYArray)
 		vec_ok = vec_ok && vec_aligned(j.x) && vec_aligned(j.y);
@@ -913,7 +947,7 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			t.n = j.n - head;
 			t.ox = advance(t.ox, head, j.io16);
 			t.oy = advance(t.oy, head, j.io16);
-			t.phase = advance(t.phase, head, j.io16);
+			t.phase = advance(t.phase, head, j.io16);	// (NULL stays NULL: mixer)
 			t.x = advance(t.x, head, j.io16);
 			t.y = advance(t.y, head, j.io16);
 			kp.index0 += head;
@@ -954,11 +988,97 @@ int launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 		if (!job.phase) return CORDIC_ERR_ARGS;
 		return launch_rot_feed<Feed::PhaseArray_ConstXY>(cfg, job, stream);
 	case Feed::PhaseArray_XYArray:
-		if (!job.phase || !job.x || !job.y) return CORDIC_ERR_ARGS;
+		// (the mixer generates its phases: no array)
+		if ((!job.phase && !job.xy_nco) || !job.x || !job.y) return CORDIC_ERR_ARGS;
 		return launch_rot_feed<Feed::PhaseArray_XYArray>(cfg, job, stream);
 	default:
 		return launch_rot_feed<Feed::Nco_ConstXY>(cfg, job, stream);
 	}
+}
+
+int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j,
+		const JobTables &tabs, void *stream)
+{
+	clear_stale_error();
+	if (cfg.mode != CORDIC_P2R && cfg.mode != CORDIC_SP2R)
+		return CORDIC_ERR_MODE;
+	if (!config_sane(cfg) || feed == Feed::PhaseArray_XYArray)
+		return CORDIC_ERR_ARGS;
+	// the seeded kernel's dynamic-exit instance is the one that reads tile
+	// descriptors: cores it serves (cordic_plan.cpp: seed_eligible), 32-bit
+	// sample arrays, a tile queue
+	if (!j.seed_table || j.seed_m != kSeedStages || !j.queue || j.io16
+			|| (cfg.flags & (CORDIC_FLAG_FORCE_GENERIC | CORDIC_FLAG_NO_SEED
+				| CORDIC_FLAG_STATIC_CHUNKS))
+			|| (cfg.needs_wrap && cfg.ww != 32 && cfg.ww != 64)
+			|| cfg.ww > 35 || cfg.nlive > kDynStages)
+		return CORDIC_ERR_UNSUPPORTED;
+	if (tabs.samples == 0)
+		return CORDIC_OK;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	CoreParams kp = make_params(cfg);
+	kp.x0 = host_sext(j.x0, cfg.iw);
+	kp.y0 = host_sext(j.y0, cfg.iw);
+	if (tabs.ntiles) {
+		SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets, j.seed_nleaves,
+				j.queue, j.dt};
+		sa.dt.n = 0;		// (dynamic-exit instances run the recurrence behind the seeds)
+		sa.tiles = tabs.tiles;
+		sa.ntiles = tabs.ntiles;
+		const size_t lds = (dt_lds_layout(sa.dt,
+				(uint32_t)((size_t)j.seed_nbuckets * 8
+				+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr)
+				+ 15u) & ~(size_t)15;
+		if (lds > 160 * 1024)
+			return CORDIC_ERR_UNSUPPORTED;
+		const int cus = cus_of_current_device();
+		if (cus < 0)
+			return CORDIC_ERR_DEVICE;
+		const int grid = (int)(tabs.ntiles < (uint32_t)cus ? tabs.ntiles : (uint32_t)cus);
+		const int container = (cfg.ww <= 32 && (cfg.needs_wrap
+				|| (cfg.flags & CORDIC_FLAG_NO_LJ))) ? 0 : cfg.ww == 35 ? 1 : 2;
+		auto run = [&](const SeedArgs &a, int grid_) -> bool {
+			RotatorJob bj = j;
+			bj.n = 0;
+			switch (container) {
+			case 0: return launch_seed_narrow(feed, cfg.nlive, grid_, st, kp, a, bj, lds);
+			case 1: return launch_seed_lj29(feed, cfg.nlive, grid_, st, kp, a, bj, lds);
+			default: return launch_seed_lj30(feed, cfg.nlive, grid_, st, kp, a, bj, lds);
+			}
+		};
+		if (j.images) {
+			// (its own image slot: no tail tables in it -- container ids 4..6)
+			sa.image = seed_image_for(*j.images, 4 + container, kp.x0, kp.y0,
+				lds, st, [&](uint32_t *dst) {
+					// one block of the same (dynamic-exit) instance in build
+					// mode: it returns behind the prologue, the tile table is
+					// never looked at
+					SeedArgs b = sa;
+					b.queue = nullptr;
+					b.image_out = dst;
+					b.image_words = (uint32_t)(lds / 4);
+					return run(b, 1);
+				});
+			sa.image_words = (uint32_t)(lds / 4);
+		}
+		if (!run(sa, grid))
+			return CORDIC_ERR_UNSUPPORTED;
+		g_last_kernel = CORDIC_KERNEL_SEEDED;
+		if (int rc = check_launch())
+			return rc;
+	}
+	if (tabs.ntails) {
+		const unsigned blocks = (tabs.ntails + kBlock - 1) / kBlock;
+		const TailDesc *t = reinterpret_cast<const TailDesc *>(tabs.tails);
+		if (feed == Feed::Nco_ConstXY)
+			hipLaunchKernelGGL(rotator_job_tails<Feed::Nco_ConstXY>, dim3(blocks),
+				dim3(kBlock), 0, st, kp, t, tabs.ntails);
+		else
+			hipLaunchKernelGGL(rotator_job_tails<Feed::PhaseArray_ConstXY>,
+				dim3(blocks), dim3(kBlock), 0, st, kp, t, tabs.ntails);
+		return check_launch();
+	}
+	return CORDIC_OK;
 }
 
 int launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,

@@ -153,10 +153,14 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	// software prefetch, as in rotator_unrolled
+	// the mixer (cordic_plan_mix, round 5): the phases are not read but
+	// generated, phase0 + (index0 + i) * fcw -- wave-uniform choice
+	const bool gen_phase = kp.xy_nco != 0;
 	u32x4 nph{};
 	i32x4 nx{}, ny{};
 	if (g < nvec) {
-		nph = CORDIC_LOAD_IN(&phin[g]);
+		if (!gen_phase)
+			nph = CORDIC_LOAD_IN(&phin[g]);
 		nx = CORDIC_LOAD_IN(&xin[g]);
 		ny = CORDIC_LOAD_IN(&yin[g]);
 	}
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 		i32x4 tx = nx, ty = ny;
 		const size_t gn = g + stride;
 		if (gn < nvec) {
-			nph = CORDIC_LOAD_IN(&phin[gn]);
+			if (!gen_phase)
+				nph = CORDIC_LOAD_IN(&phin[gn]);
 			nx = CORDIC_LOAD_IN(&xin[gn]);
 			ny = CORDIC_LOAD_IN(&yin[gn]);
 		}
@@ -177,10 +182,18 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 			}
 		}
 		uint32_t pb[kVec];
+		if (gen_phase) {
+			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
+			pb[0] = (kp.phase0 + 0x20000000u) + s0 * kp.fcw;
 #pragma unroll
-		for (int v = 0; v < kVec; v++)
-			asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(pb[v])
-				: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
+			for (int v = 1; v < kVec; v++)
+				pb[v] = pb[v - 1] + kp.fcw;
+		} else {
+#pragma unroll
+			for (int v = 0; v < kVec; v++)
+				asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(pb[v])
+					: "v"(tph[v]), "s"(kp.pw_shl), "v"(k45));
+		}
 
 		int64_t x[kVec], y[kVec];
 		uint32_t u[kVec];

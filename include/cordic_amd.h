@@ -211,6 +211,18 @@ int	cordic_nco(const cordic_config *cfg, size_t n,
 		int32_t xval, int32_t yval,
 		int32_t *d_oxval, int32_t *d_oyval, void *stream);
 
+/* Fused NCO MIXER (down-converter): the core with all three ports live
+ * (rtl/cordic.v:58-63) -- per-sample i_xval / i_yval from memory, i_phase from
+ * the accumulator phase[i] = phase0 + (index0 + i) * fcw (mod 2^PW, the ramp of
+ * bench/cpp/cordic_tb.cpp:128-138 with an arbitrary increment) generated in the
+ * kernel: 8 B in + 8 B out per sample instead of the 12 + 8 of cordic_p2r on
+ * a materialised phase array.  cordic_plan_mix: the same through a plan, whose
+ * direction tables serve it exactly as they serve cordic_plan_p2r. */
+int	cordic_mix(const cordic_config *cfg, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		const int32_t *d_xval, const int32_t *d_yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
 /* Rectangular to polar (magnitude + atan2); cfg->mode R2P or SR2P.
  * d_ophase receives the raw PW-bit phase (rtl/topolar.v:269).  Replaces one
  * Vtopolar tick() per sample (bench/cpp/topolar_tb.cpp:143-187). */
@@ -338,6 +350,10 @@ int	cordic_plan_p2r(const cordic_plan *plan, size_t n,
 		void *stream);
 int	cordic_plan_dir_info(const cordic_plan *plan, int32_t *ngroups,
 		int32_t stages[5]);
+int	cordic_plan_mix(const cordic_plan *plan, size_t n,
+		uint32_t phase0, uint32_t fcw, uint64_t index0,
+		const int32_t *d_xval, const int32_t *d_yval,
+		int32_t *d_oxval, int32_t *d_oyval, void *stream);
 
 int	cordic_plan_p2r_const(const cordic_plan *plan, size_t n,
 		int32_t xval, int32_t yval, const uint32_t *d_phase,
@@ -346,6 +362,56 @@ int	cordic_plan_nco(const cordic_plan *plan, size_t n,
 		uint32_t phase0, uint32_t fcw, uint64_t index0,
 		int32_t xval, int32_t yval,
 		int32_t *d_oxval, int32_t *d_oyval, void *stream);
+
+/* ------------------------------------------------------------ job sets
+ *
+ * Many SMALL jobs in one launch (round 5).  A launch costs ~10-20 us whatever
+ * it computes -- the runtime's dispatch, staging the seed table, filling and
+ * draining 256 CUs -- which is the whole run time of a 2^16-sample job: an NCO
+ * bank or a channeliser that hands the engine a thousand short blocks gets a
+ * few per cent of the rate of one long one (profiles/r05/small_batch.txt).  A
+ * job set is those blocks described once: the host cuts them into the seeded
+ * kernel's tiles (8192 samples, never across a job's end), keeps the table on
+ * the device, and cordic_plan_run_jobs then runs the WHOLE set as one launch of
+ * the same kernel walking the same address-ordered tile queue (+ one small
+ * launch for the up to three samples behind each job's last whole vector).
+ * Jobs may have any length (ragged, zero included) and any 4-byte aligned
+ * addresses; they must not overlap each other's outputs.  The set can be run
+ * any number of times (new data in the same arrays: a channeliser's steady
+ * state), on any stream, with any constant vector, and inside a HIP graph
+ * capture; cordic_plan_*_batch are the one-shot forms (table built, uploaded
+ * with a blocking copy, run, freed once the launch has passed: they cost a
+ * host-side ~50 us per call more).  kind: the jobs' phases are ARRAYS
+ * (cordic_plan_p2r_const per job: d_phase) or generated (cordic_plan_nco per
+ * job: phase0, fcw, index0).  Results: bit for bit those of the per-job calls.
+ * Cores without a table-seeded kernel (WW > 35, fewer than 11 live stages,
+ * CORDIC_FLAG_NO_SEED) run the jobs one by one behind the same call.
+ */
+typedef struct cordic_job {
+	const uint32_t *d_phase;	/* CORDIC_JOBS_PHASE_ARRAYS: n words    */
+	uint32_t phase0, fcw;		/* CORDIC_JOBS_NCO: phase0 +            */
+	uint64_t index0;		/*   (index0 + i) * fcw  (mod 2^PW)     */
+	int32_t	*d_oxval, *d_oyval;	/* n words each                         */
+	uint64_t n;			/* samples                              */
+} cordic_job;
+enum cordic_jobs_kind { CORDIC_JOBS_PHASE_ARRAYS = 0, CORDIC_JOBS_NCO = 1 };
+typedef struct cordic_jobset cordic_jobset;
+int	cordic_jobset_create(const cordic_plan *plan, int kind, size_t njobs,
+		const cordic_job *jobs, cordic_jobset **set);
+void	cordic_jobset_destroy(cordic_jobset *set);
+/* samples of all jobs, tiles the kernel walks, samples served by the
+ * trailing-sample launch (any pointer may be NULL) */
+int	cordic_jobset_info(const cordic_jobset *set, uint64_t *samples,
+		uint32_t *tiles, uint32_t *tail_samples);
+int	cordic_plan_run_jobs(const cordic_plan *plan, const cordic_jobset *set,
+		int32_t xval, int32_t yval, void *stream);
+int	cordic_plan_p2r_const_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream);
+int	cordic_plan_nco_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream);
+/* waits for and frees what the one-shot forms still hold (they free it
+ * themselves, lazily, on later calls) */
+void	cordic_jobset_reap(void);
 
 /* ---------------------------------------------- 16-bit sample containers
  *

@@ -746,6 +746,22 @@ void orc_nco(const orc_config *c, size_t n, uint32_t phase0, uint32_t fcw,
 	}
 }
 
+/* The fused NCO MIXER (down-converter): the phase accumulator of orc_nco
+ * (bench/cpp/cordic_tb.cpp:128-138) on the core's i_phase port while i_xval /
+ * i_yval carry a sample stream (rtl/cordic.v:58-63 with all three ports
+ * live).  Per sample it is orc_rotate, unchanged. */
+void orc_mixer(const orc_config *c, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, const int32_t *x, const int32_t *y,
+		int32_t *ox, int32_t *oy)
+{
+	const uint32_t pm = pmask(c->pw);
+	for (size_t s = 0; s < n; s++) {
+		uint32_t ph = (uint32_t)(phase0
+				+ (uint32_t)(index0 + s) * fcw) & pm;
+		orc_rotate(c, 1, &x[s], &y[s], 1, &ph, &ox[s], &oy[s]);
+	}
+}
+
 /* ------------------------------------------------------------ quadtbl core
  *
  * sw/quadtbl.cpp builds three tables in double precision; the statements

@@ -118,6 +118,10 @@ void	orc_topolar(const orc_config *cfg, size_t n, const int32_t *x,
 void	orc_nco(const orc_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
 		uint64_t index0, int32_t x0, int32_t y0,
 		int32_t *ox, int32_t *oy);
+/* the same accumulator on i_phase with per-sample i_xval / i_yval (mixer) */
+void	orc_mixer(const orc_config *cfg, size_t n, uint32_t phase0, uint32_t fcw,
+		uint64_t index0, const int32_t *x, const int32_t *y,
+		int32_t *ox, int32_t *oy);
 
 /* table cores (sw/sintable.cpp; kind 4 = -t tbl, 5 = -t qtr) */
 int	orc_table_config(int kind, int iw, int ow, int phase_bits, int *pw_out,

@@ -67,6 +67,9 @@ def lib():
         L.orc_nco.argtypes = [cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
                               C.c_uint64, C.c_int32, C.c_int32, i32p, i32p]
         L.orc_nco.restype = None
+        L.orc_mixer.argtypes = [cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
+                              C.c_uint64, i32p, i32p, i32p, i32p]
+        L.orc_mixer.restype = None
         L.orc_cordic_gain.restype = C.c_double
         L.orc_cordic_gain.argtypes = [C.c_int]
         L.orc_phase_variance.restype = C.c_double
@@ -161,6 +164,20 @@ def nco(cfg, n, phase0, fcw, index0, x0, y0):
     return ox, oy
 
 
+def mix(cfg, phase0, fcw, index0, x, y):
+    """fused NCO mixer: phase[i] = phase0 + (index0 + i) * fcw on i_phase,
+    per-sample x / y on i_xval / i_yval"""
+    xa = np.ascontiguousarray(x, dtype=np.int32)
+    ya = np.ascontiguousarray(y, dtype=np.int32)
+    n = xa.size
+    assert ya.size == n
+    ox = np.empty(n, dtype=np.int32)
+    oy = np.empty(n, dtype=np.int32)
+    lib().orc_mixer(C.byref(cfg), n, phase0 & 0xffffffff, fcw & 0xffffffff,
+                  index0, _i32(xa), _i32(ya), _i32(ox), _i32(oy))
+    return ox, oy
+
+
 IQ_MULX, IQ_MULY = 0x9E3779B1, 0x85EBCA77      # SURVEY.md 8(d) config 3 ramps
 
 
@@ -187,8 +204,9 @@ def job_digest(cfg, kind, start, n, phase0=0, fcw=1, x0=0, y0=0,
     job as the device's position-aware digest -- sum of mix(g, out0[g]) +
     mix(g + 2^40, out1[g]) over g in [start, start+n).  kind "p2r" / "nco":
     constant (x0, y0), phase[g] = phase0 + g*fcw; "r2p": the I/Q ramps;
-    "p2rxy": the I/Q ramps rotated by phase[g]."""
-    k = {"p2r": 0, "nco": 0, "r2p": 1, "p2rxy": 2}[kind]
+    "p2rxy" / "mix": the I/Q ramps rotated by phase[g] (read from an array,
+    resp. generated by the fused accumulator: the same job)."""
+    k = {"p2r": 0, "nco": 0, "r2p": 1, "p2rxy": 2, "mix": 2}[kind]
     sec = C.c_double(0.0)
     d = lib().orc_digest(C.byref(cfg), k, threads or usable_cpus(), start, n,
                          phase0 & 0xffffffff, fcw & 0xffffffff, x0, y0,

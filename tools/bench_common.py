@@ -49,6 +49,10 @@ WORKLOADS = {
     "p2rxy": dict(kind="p2rxy", cli=("p2r", 32, 32, 2, 32, 16), bytes=20,
                   shift=2, desc="basiccordic 16-stage, 32-bit, per-sample x, y "
                   "and phase vectors (cordic_p2r)"),
+    "ddc": dict(kind="ddc", cli=("p2r", 32, 32, 2, 32, 16), bytes=16,
+                desc="fused NCO mixer (down-converter): per-sample x, y "
+                "vectors rotated by the in-kernel accumulator phase = "
+                "n*0x01234567, 16-stage 32-bit core (cordic_plan_mix)"),
     "sintbl": dict(kind="tbl", table=(4, -1, 13, 17), bytes=8, shift=0,
                    desc="sintable PW=17 OW=13 (rtl/sintable.v), phase ramp n"),
     "qtrtbl": dict(kind="tbl", table=(5, -1, 24, 18), bytes=8, shift=0,
@@ -139,7 +143,8 @@ KERNEL_OF = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
              "cfg1": "rotator_seeded", "cfg3": "topolar_lj",
              "nat32": "rotator_seeded", "nat24": "rotator_seeded",
              "nat16": "rotator_seeded", "natr2p24": "topolar_lj",
-             "p2rxy": "rotator_xydir", "quadtbl": "quad_lookup",
+             "p2rxy": "rotator_xydir", "ddc": "rotator_xydir",
+             "quadtbl": "quad_lookup",
              "quadtbl24": "quad_lookup", "sintbl": "table_lookup",
              "qtrtbl": "table_lookup", "qtrtbl16": "table_lookup",
              "qtrtbl24": "table_lookup"}

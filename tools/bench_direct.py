@@ -148,7 +148,7 @@ def run_direct(args, w, launch):
     sdt = torch.int16 if io16 else torch.int32
     # the arrays of the job, placed by measurement (cordic_arrays_alloc: up to
     # two read + two written arrays; a third input is taken as it comes)
-    nread = {"p2r": 1, "p2rxy": 2, "r2p": 2}[w["kind"]]
+    nread = {"p2r": 1, "p2rxy": 2, "r2p": 2, "ddc": 2}[w["kind"]]
     arrays = ca.Arrays((2 if io16 else 4) * n, nread, 2)
     a = arrays.tensor(nread, sdt)
     b = arrays.tensor(nread + 1, sdt)
@@ -183,6 +183,20 @@ def run_direct(args, w, launch):
 
         def step():
             plan.p2r(xin, yin, phase, a, b)
+    elif w["kind"] == "ddc":
+        # the fused NCO mixer: the per-sample vectors of p2rxy, the phase from
+        # the in-kernel accumulator (no phase array: 16 B per sample)
+        xin = arrays.tensor(0, torch.int32)
+        yin = arrays.tensor(1, torch.int32)
+        ca.fill_iq_ramp(xin, yin, index0, 0x9E3779B1, 0x85EBCA77, iw)
+        if args.input == "random":
+            gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+            xin.random_(-2**31, 2**31 - 1, generator=gen)
+            yin.random_(-2**31, 2**31 - 1, generator=gen)
+        plan = ca.Plan(cfg.with_flags(ca.FLAG_NO_TAILS) if args.no_tails else cfg)
+
+        def step():
+            plan.mix(0, 0x01234567, index0, xin, yin, a, b)
     elif w["kind"] == "r2p":
         xin = arrays.tensor(0, torch.int32)
         yin = arrays.tensor(1, torch.int32)
@@ -268,6 +282,11 @@ def run_direct(args, w, launch):
             ra, rb = O.rotate(ocfg, xin[ti].cpu().numpy(),
                               yin[ti].cpu().numpy(),
                               phase[ti].cpu().numpy().view(np.uint32))
+        elif w["kind"] == "ddc":
+            ph = ((idx.astype(np.uint64) + np.uint64(index0))
+                  * np.uint64(0x01234567) & np.uint64(0xffffffff))
+            ra, rb = O.rotate(ocfg, xin[ti].cpu().numpy(),
+                              yin[ti].cpu().numpy(), ph.astype(np.uint32))
         elif w["kind"] == "p2r" and io16:
             ra, rb = O.rotate(ocfg, x0, y0, phase[ti].cpu().numpy()
                               .view(np.uint16).astype(np.uint32))
@@ -353,7 +372,7 @@ def run_direct(args, w, launch):
                 "kernel": "generic" if args.generic else (
                     ("directions(%s)" % "+".join(map(str, plan.dir_groups))
                      if ran == ca.KERNEL_DIRECTIONS else "unrolled")
-                    if w["kind"] == "p2rxy" else
+                    if w["kind"] in ("p2rxy", "ddc") else
                     "unrolled" if (args.no_seed or w["kind"] == "r2p"
                                    or ran != ca.KERNEL_SEEDED)
                     else "seeded(%d)+unrolled" % plan.seed_info["stages"]),

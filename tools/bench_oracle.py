@@ -20,10 +20,10 @@ def oracle_digest_leg(args, w, ocfg, start, n, x0, y0, threads=None):
     if (args.input != "ramp" or w.get("io16") or kind == "tbl"
             or getattr(args, "no_full_digest", False)):
         return None
-    fcw = 0x01234567 if kind == "nco" else (1 << w.get("shift", 0))
+    fcw = 0x01234567 if kind in ("nco", "ddc") else (1 << w.get("shift", 0))
     cores = threads or usable_cpus()
-    d, secs = O.job_digest(ocfg, kind, start, n, 0, fcw, x0, y0,
-                           threads=cores)
+    d, secs = O.job_digest(ocfg, "mix" if kind == "ddc" else kind, start, n, 0,
+                           fcw, x0, y0, threads=cores)
     return {"digest": d, "samples": n, "seconds": secs, "cores": cores}
 
 
@@ -64,7 +64,7 @@ def cpu_baseline(workload, seconds=12.0, leg=None):
     L = O.lib()
     cores = usable_cpus()
     kind = 1 if w["kind"] == "r2p" else 0
-    mul = 0x01234567 if w["kind"] == "nco" else (1 << w.get("shift", 0))
+    mul = 0x01234567 if w["kind"] in ("nco", "ddc") else (1 << w.get("shift", 0))
     x0 = (1 << (iw - 1)) - 1
     t0 = time.perf_counter()
     n1 = L.orc_throughput(C.byref(ocfg), kind, 1, 1.0, mul, x0, 0)

@@ -15,7 +15,8 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 # BASELINE.json's other GPU configurations at THEIR sizes (configs[2..4]) plus
 # the per-sample-vector rotator: (workload, log2 samples per launch)
-OTHER_PATHS = (("cfg3", 30), ("cfg4", 30), ("cfg5", 32), ("p2rxy", 30))
+OTHER_PATHS = (("cfg3", 30), ("cfg4", 30), ("cfg5", 32), ("p2rxy", 30),
+               ("ddc", 30))
 
 
 def other_paths(args, steps=24, warmup=4):
@@ -159,4 +160,67 @@ def host_paths(log2n=28, reps=3):
     for h in pin:
         h.close()
     ca.host_release()
+    return res
+
+
+def small_batches():
+    """What a caller with SMALL batches gets: BASELINE
+    config 2's core on 2^26 resident samples handed over (a) as one plan call
+    per job of 2^16 / 2^20 / 2^24 samples, back to back on one stream, and (b)
+    as ONE job set (cordic_jobset: a single launch walks every job's tiles).
+    Rates are aggregate over the 2^26 samples; the job sets' outputs are
+    checked against the oracle's digest of the whole ramp.  Informational,
+    never `value`."""
+    import cordic_amd as ca
+    import oracle_lib as O
+    from gpu_util import gpu_digest
+    m, iw, ow, xtra, pw, ns = WORKLOADS["cfg2"]["cli"]
+    cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+    ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+    plan = ca.Plan(cfg)
+    plan.set_min_samples(-1)            # the library's own choice of kernel
+    total = 1 << 26
+    x0 = (1 << (iw - 1)) - 1
+    ph = torch.empty(total, dtype=torch.int32, device="cuda")
+    a = torch.empty_like(ph)
+    b = torch.empty_like(ph)
+    ca.fill_phase_ramp(ph, 0, 2)
+    want, _ = O.job_digest(ocfg, "p2r", 0, total, 0, 4, x0, 0)
+    res = {"samples": total, "core": "cfg2", "rows": {}}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    for lg in (16, 20, 24):
+        n = 1 << lg
+        nj = total // n
+        jobs = [dict(phase=ph[k * n:(k + 1) * n], ox=a[k * n:(k + 1) * n],
+                     oy=b[k * n:(k + 1) * n], n=n) for k in range(nj)]
+
+        def one_by_one():
+            for jb in jobs:
+                plan.p2r_const(x0, 0, jb["phase"], jb["ox"], jb["oy"])
+        ms_calls = timed(one_by_one, 3)
+        js = ca.Jobset(plan, ca.JOBS_PHASE_ARRAYS, jobs)
+        a.zero_()
+        b.zero_()
+        ms_set = timed(lambda: js.run(x0, 0), 10)
+        got = (gpu_digest(a, 0) + gpu_digest(b, 1 << 40)) % (1 << 64)
+        js.close()
+        res["rows"]["2^%d" % lg] = {
+            "jobs": nj, "samples_per_job": n,
+            "one_call_per_job_Msamples_per_s": total / ms_calls / 1e3,
+            "one_call_per_job_us_per_call": ms_calls * 1e3 / nj,
+            "job_set_Msamples_per_s": total / ms_set / 1e3,
+            "job_set_ms": ms_set,
+            "job_set_digest_equals_oracle": got == want}
+    plan.close()
     return res

@@ -44,6 +44,46 @@ for ns in (16, 24):
             lg, res[0], res[1], res[2], n / res[0] / 1e3, n / res[1] / 1e3,
             n / res[2] / 1e3))
     plan.close(); noimg.close(); plain.close()
+# many small jobs in ONE launch (cordic_jobset): 2^26 samples as 2^(26-lg) jobs
+# of 2^lg samples, against the same jobs as one plan call each
+for ns in (16, 24):
+    cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, ns)
+    plan = ca.Plan(cfg)
+    plan.set_min_samples(-1)
+    os.environ.pop("CORDIC_SEED_MIN_SAMPLES", None)
+    total = 1 << 26
+    ph = torch.empty(total, dtype=torch.int32, device=dev)
+    a = torch.empty_like(ph); b = torch.empty_like(ph)
+    ca.fill_phase_ramp(ph, 0, 2)
+    print("p2r %d stages, 2^26 samples as jobs of 2^lg: lg, jobs, job set us "
+          "(Gs/s), one call per job us (Gs/s)" % ns)
+    for lg in (12, 14, 16, 18, 20, 22, 24, 26):
+        n = 1 << lg
+        nj = total // n
+        jobs = [dict(phase=ph[k * n:(k + 1) * n], ox=a[k * n:(k + 1) * n],
+                     oy=b[k * n:(k + 1) * n], n=n) for k in range(nj)]
+        js = ca.Jobset(plan, ca.JOBS_PHASE_ARRAYS, jobs)
+        res = []
+
+        def one_by_one():
+            for jb in jobs:
+                plan.p2r_const(2**31 - 1, 0, jb["phase"], jb["ox"], jb["oy"])
+        for fn, reps in ((lambda: js.run(2**31 - 1, 0), 20),
+                         (one_by_one, 2 if nj > 1024 else 5)):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / reps * 1e3)
+        print("  2^%-2d %6d %10.1f (%6.1f) %12.1f (%6.1f)" % (
+            lg, nj, res[0], total / res[0] / 1e3, res[1], total / res[1] / 1e3))
+        js.close()
+    plan.close()
+os.environ["CORDIC_SEED_MIN_SAMPLES"] = "0"
 # per-sample vectors: directions looked up (small tables) against the recurrence
 cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)
 plan = ca.Plan(cfg)
