@@ -381,13 +381,15 @@ def run_group(args, w, launch):
     m, iw, ow, xtra, pw, ns = w["cli"]
     cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
     if args.generic:
-        cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_FORCE_GENERIC)
     if args.no_seed:
-        cfg = cfg.with_flags(ca.FLAG_NO_SEED)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_NO_SEED)
     if args.static_chunks:
-        cfg = cfg.with_flags(ca.FLAG_STATIC_CHUNKS)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_STATIC_CHUNKS)
     if args.no_tails:
-        cfg = cfg.with_flags(ca.FLAG_NO_TAILS)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_NO_TAILS)
+    if args.no_lj:
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_NO_LJ)
 
     dist = host_pg = None
     rank, world, local = 0, 1, 0
@@ -588,7 +590,7 @@ def run_group(args, w, launch):
     # sample runs all micro-rotations) so both numbers are on record
     full = None
     if seeded:
-        grp2 = ca.Group(cfg.with_flags(ca.FLAG_NO_SEED), devices=devices,
+        grp2 = ca.Group(cfg.with_flags(cfg.flags | ca.FLAG_NO_SEED), devices=devices,
                         first_shard=first, total_shards=total)
         for sh in range(nlocal):        # same inputs, bit for bit
             grp2.reserve(n_total, 1 if kind == "p2r" else 0)
@@ -895,8 +897,9 @@ def main():
                     help="skip the hwmon power / clock samples and the two "
                          "seconds of sustained running behind the timed region")
     ap.add_argument("--pmc-counters",
-                    default="FETCH_SIZE,WRITE_SIZE,SQ_INSTS_VALU",
-                    help="comma-separated rocprofv3 counters, one pass each")
+                    default="FETCH_SIZE,WRITE_SIZE,SQ_INSTS_VALU+SQ_INSTS_VALU_INT64",
+                    help="comma-separated rocprofv3 counters, one pass each "
+                    "(A+B: both in one pass)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip measuring roofline.traffic (two rocprofv3 --pmc "
                     "passes, FETCH_SIZE and WRITE_SIZE, over a 3-step run of "
@@ -927,6 +930,9 @@ def main():
                     "instead of the direction-tail lookups (A/B)")
     ap.add_argument("--generic", action="store_true",
                     help="force the generic (not unrolled) kernel")
+    ap.add_argument("--no-lj", action="store_true",
+                    help="A/B: the right-justified kernels (32-bit container "
+                    "for WW <= 32) instead of the left-justified ones")
     ap.add_argument("--nstages", type=int, default=0,
                     help="experiments: the workload's core with this many stages "
                     "(gencordic -n); the line's config says so")

@@ -21,6 +21,7 @@ from ._native import (  # noqa: F401
     lib, lib_path,
     p2r, p2r_const, nco, mix, r2p,
     p2r_host, r2p_host, HostArray, host_last_stats, host_release,
+    host_set_devices, host_lane_stats,
     fill_phase_ramp, fill_iq_ramp, digest_u32,
 )
 

@@ -117,6 +117,8 @@ ABI = {
     "cordic_plan_queue_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cordic_plan_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p]),
+    "cordic_host_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "cordic_host_lane_stats": (C.c_int, [C.c_int, C.c_void_p]),
     "cordic_mix": (C.c_int, [_cfgp, C.c_size_t, C.c_uint32, C.c_uint32,
                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
@@ -1220,7 +1222,8 @@ class _CHostStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("chunks", C.c_int32),
                 ("chunk_samples", C.c_int32), ("staged_inputs", C.c_int32),
                 ("staged_outputs", C.c_int32), ("copy_threads", C.c_int32),
-                ("seeded_plan", C.c_int32), ("seconds", C.c_double)]
+                ("seeded_plan", C.c_int32), ("lanes", C.c_int32),
+                ("seconds", C.c_double)]
 
 
 class HostArray:
@@ -1254,6 +1257,22 @@ def host_last_stats():
 
 def host_release():
     lib().cordic_host_release()
+
+
+def host_set_devices(devices):
+    """device ordinals the host-array calls spread over ([] / None: the
+    current device only)"""
+    devices = list(devices or [])
+    arr = (C.c_int * max(1, len(devices)))(*devices)
+    _check(lib().cordic_host_set_devices(arr, len(devices)),
+           "cordic_host_set_devices")
+
+
+def host_lane_stats(lane):
+    st = _CHostStats()
+    _check(lib().cordic_host_lane_stats(lane, C.byref(st)),
+           "cordic_host_lane_stats")
+    return {k: getattr(st, k) for k, _ in _CHostStats._fields_}
 
 
 def _host_out(out, n, dtypes, what):

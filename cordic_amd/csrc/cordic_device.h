@@ -211,6 +211,27 @@ __device__ __forceinline__ void pol_stage(int64_t &x, int64_t &y, int64_t &p,
 {
 	const int32_t d = C::wide ? (int32_t)((uint64_t)y >> 32) >> 31
 				  : (int32_t)(uint32_t)y >> 31;
+#ifdef CORDIC_POL_VOP2
+	// Round-5 experiment (profiles/r05/ab_pol_vop2.txt):
+	// the 32-bit container WITHOUT the half-rate multiply-adds -- sign-mask
+	// arithmetic on full-rate VOP2 only: 12 instructions per stage (1 mask,
+	// 2 shifts, 3 x {xor, sub, add}) against 8 with v_mad_i64_i32 (7 in
+	// topolar_lj).  -DCORDIC_POL_VOP2 builds it for the A/B; not the product.
+	if constexpr (!C::wide) {
+		const int32_t lx = (int32_t)(uint32_t)x, ly = (int32_t)(uint32_t)y;
+		const int32_t lp = (int32_t)(uint32_t)p;
+		const int32_t sy = ly >> ((K > 31) ? 31 : K), sx = lx >> ((K > 31) ? 31 : K);
+		const int32_t nd = ~d;
+		// y < 0 (d = -1): x - sy, y + sx, p - a;  y >= 0: x + sy, y - sx, p + a
+		const int32_t nx = lx + ((sy ^ d) - d);
+		const int32_t ny = ly + ((sx ^ nd) - nd);
+		const int32_t np = lp + (((int32_t)a ^ d) - d);
+		x = (int64_t)(uint32_t)nx;
+		y = (int64_t)(uint32_t)ny;
+		p = (int64_t)(uint32_t)np;
+		return;
+	}
+#endif
 	const int32_t t = d | 1;
 	const int32_t nt = op_flip(t);
 	if constexpr (!C::wide) {
@@ -1894,7 +1915,14 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	}
 
 	// Work distribution, static (no queue): every persistent block sweeps its
-	// own contiguous chunk.
+	// own contiguous chunk.  Round 5: in the DYNAMIC-EXIT instances only -- the
+	// launcher sends a launch without a queue (CORDIC_FLAG_STATIC_CHUNKS, a
+	// handle whose ring is exhausted by captured launches) there; a static
+	// instance then carries one copy of its stage chains instead of two, which
+	// halves the seeded units' code.
+	if constexpr (!DYN) {
+		__builtin_trap();	// never launched without a queue
+	} else {
 #ifdef CORDIC_SEED_GRIDSTRIDE
 	const size_t stride = (size_t)gridDim.x * kSeedBlock;
 	const size_t hi = nvec;
@@ -1931,6 +1959,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		CORDIC_STORE_OUT(false, &ox[g], IO::narrow(rx));
 		CORDIC_STORE_OUT(false, &oy[g], IO::narrow(ry));
 	}
+	}	// (DYN)
 }
 
 // ------------------------------------------------------- unrolled converter

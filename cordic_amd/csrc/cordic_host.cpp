@@ -38,6 +38,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "cordic_amd.h"
@@ -254,20 +255,30 @@ struct HostPipe {
 };
 
 std::mutex g_pipes_mu;
-std::map<int, HostPipe *> g_pipes;
+// one pipeline per (device, lane): a lane is an entry of the device list of
+// cordic_host_set_devices -- the same ordinal listed twice is two pipelines
+// on one device (how the one-GPU tests drive the multi-device logic)
+std::map<std::pair<int, int>, HostPipe *> g_pipes;
+std::vector<int> g_devices;		// empty: the caller's current device
+cordic_host_stats g_last_total = {};	// of the most recent multi-lane call
+
+HostPipe *pipe_for(int dev, int lane)
+{
+	std::lock_guard<std::mutex> lk(g_pipes_mu);
+	HostPipe *&p = g_pipes[std::make_pair(dev, lane)];
+	if (!p) {
+		p = new HostPipe;
+		p->device = dev;
+	}
+	return p;
+}
 
 HostPipe *pipe_for_current_device()
 {
 	int dev = 0;
 	if (!ok(hipGetDevice(&dev)))
 		return nullptr;
-	std::lock_guard<std::mutex> lk(g_pipes_mu);
-	HostPipe *&p = g_pipes[dev];
-	if (!p) {
-		p = new HostPipe;
-		p->device = dev;
-	}
-	return p;
+	return pipe_for(dev, 0);
 }
 
 // Is this host array something the DMA engines can take as it is?  Pinned /
@@ -449,6 +460,7 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 	st.staged_outputs = (stage_out[0] ? 1 : 0) + (stage_out[1] ? 1 : 0);
 	st.copy_threads = any_stage && hp.pool ? hp.pool->threads() : 0;
 	st.seeded_plan = any_seeded ? 1 : 0;	// a chunk ran the table-seeded kernel
+	st.lanes = 1;
 	st.seconds = std::chrono::duration<double>(
 			std::chrono::steady_clock::now() - t_begin).count();
 	return rc;
@@ -456,11 +468,103 @@ int run_pipeline(HostPipe &hp, const HostJob &j)
 
 int submit(const HostJob &j)
 {
-	HostPipe *hp = pipe_for_current_device();
-	if (!hp)
-		return CORDIC_ERR_DEVICE;
-	std::lock_guard<std::mutex> lk(hp->mu);
-	return run_pipeline(*hp, j);
+	std::vector<int> devs;
+	{
+		std::lock_guard<std::mutex> lk(g_pipes_mu);
+		devs = g_devices;
+	}
+	// too small to be worth a second PCIe link: one lane
+	const size_t nchunks = (j.n + kChunk - 1) / kChunk;
+	if (devs.size() <= 1 || nchunks < 2) {
+		HostPipe *hp = devs.empty() ? pipe_for_current_device()
+					    : pipe_for(devs[0], 0);
+		if (!hp)
+			return CORDIC_ERR_DEVICE;
+		int prev = -1;
+		if (!devs.empty()) {
+			if (!ok(hipGetDevice(&prev))) prev = -1;
+			if (!ok(hipSetDevice(devs[0])))
+				return CORDIC_ERR_DEVICE;
+		}
+		int rc;
+		{
+			std::lock_guard<std::mutex> lk(hp->mu);
+			rc = run_pipeline(*hp, j);
+			std::lock_guard<std::mutex> lk2(g_pipes_mu);
+			g_last_total = hp->last;
+		}
+		if (prev >= 0)
+			(void)hipSetDevice(prev);
+		return rc;
+	}
+	// Several devices: several PCIe links.  The job is cut into as many
+	// contiguous parts (whole chunks) as there are lanes; every lane runs its
+	// part through its own pipeline on its own device, from its own host
+	// thread (a pipeline is a host-driven loop).  Samples are independent and
+	// the parts' arrays do not overlap: nothing is shared but the host's
+	// memory bandwidth.
+	const auto t_begin = std::chrono::steady_clock::now();
+	const size_t lanes = devs.size() < nchunks ? devs.size() : nchunks;
+	std::vector<int> rcs(lanes, CORDIC_OK);
+	std::vector<cordic_host_stats> st(lanes);
+	std::vector<std::thread> th;
+	auto part = [&](size_t l, size_t *off, size_t *cnt) {
+		const size_t per = (nchunks + lanes - 1) / lanes * kChunk;
+		*off = l * per < j.n ? l * per : j.n;
+		*cnt = j.n - *off < per ? j.n - *off : per;
+	};
+	auto lane_fn = [&](size_t l) {
+		size_t off, cnt;
+		part(l, &off, &cnt);
+		if (cnt == 0)
+			return;
+		if (!ok(hipSetDevice(devs[l]))) {
+			rcs[l] = CORDIC_ERR_DEVICE;
+			return;
+		}
+		HostPipe *hp = pipe_for(devs[l], (int)l);
+		HostJob sub = j;
+		sub.n = cnt;
+		for (int a = 0; a < j.nin; a++)
+			sub.in[a] = static_cast<const char *>(j.in[a]) + off * 4;
+		for (int a = 0; a < 2; a++)
+			sub.out[a] = static_cast<char *>(j.out[a]) + off * 4;
+		std::lock_guard<std::mutex> lk(hp->mu);
+		rcs[l] = run_pipeline(*hp, sub);
+		st[l] = hp->last;
+	};
+	int prev = -1;
+	if (!ok(hipGetDevice(&prev))) prev = -1;
+	for (size_t l = 1; l < lanes; l++)
+		th.emplace_back(lane_fn, l);
+	lane_fn(0);
+	for (std::thread &t : th)
+		t.join();
+	if (prev >= 0)
+		(void)hipSetDevice(prev);
+	cordic_host_stats tot = {};
+	for (size_t l = 0; l < lanes; l++) {
+		tot.samples += st[l].samples;
+		tot.chunks += st[l].chunks;
+		tot.chunk_samples = st[l].chunk_samples ? st[l].chunk_samples : tot.chunk_samples;
+		tot.staged_inputs = st[l].staged_inputs > tot.staged_inputs
+				? st[l].staged_inputs : tot.staged_inputs;
+		tot.staged_outputs = st[l].staged_outputs > tot.staged_outputs
+				? st[l].staged_outputs : tot.staged_outputs;
+		tot.copy_threads += st[l].copy_threads;
+		tot.seeded_plan |= st[l].seeded_plan;
+	}
+	tot.lanes = (int32_t)lanes;
+	tot.seconds = std::chrono::duration<double>(
+			std::chrono::steady_clock::now() - t_begin).count();
+	{
+		std::lock_guard<std::mutex> lk(g_pipes_mu);
+		g_last_total = tot;
+	}
+	for (int rc : rcs)
+		if (rc != CORDIC_OK)
+			return rc;
+	return CORDIC_OK;
 }
 
 } // namespace
@@ -525,21 +629,69 @@ int cordic_host_last_stats(cordic_host_stats *out)
 {
 	if (!out)
 		return CORDIC_ERR_ARGS;
-	HostPipe *hp = pipe_for_current_device();
-	if (!hp)
-		return CORDIC_ERR_DEVICE;
+	std::lock_guard<std::mutex> lk(g_pipes_mu);
+	*out = g_last_total;
+	return CORDIC_OK;
+}
+
+int cordic_host_lane_stats(int lane, cordic_host_stats *out)
+{
+	if (!out || lane < 0)
+		return CORDIC_ERR_ARGS;
+	int dev = 0;
+	{
+		std::lock_guard<std::mutex> lk(g_pipes_mu);
+		if (g_devices.empty()) {
+			if (lane != 0 || !ok(hipGetDevice(&dev)))
+				return CORDIC_ERR_ARGS;
+		} else {
+			if ((size_t)lane >= g_devices.size())
+				return CORDIC_ERR_ARGS;
+			dev = g_devices[(size_t)lane];
+		}
+	}
+	HostPipe *hp = pipe_for(dev, lane);
 	std::lock_guard<std::mutex> lk(hp->mu);
 	*out = hp->last;
+	out->lanes = 1;
+	return CORDIC_OK;
+}
+
+int cordic_host_set_devices(const int *devices, int count)
+{
+	if (count < 0 || count > 64 || (count > 0 && !devices))
+		return CORDIC_ERR_ARGS;
+	int ndev = 0;
+	if (!ok(hipGetDeviceCount(&ndev))) {
+		(void)hipGetLastError();
+		return CORDIC_ERR_DEVICE;
+	}
+	for (int i = 0; i < count; i++)
+		if (devices[i] < 0 || devices[i] >= ndev)
+			return CORDIC_ERR_DEVICE;
+	std::lock_guard<std::mutex> lk(g_pipes_mu);
+	g_devices.assign(devices, devices + count);
 	return CORDIC_OK;
 }
 
 void cordic_host_release(void)
 {
-	HostPipe *hp = pipe_for_current_device();
-	if (!hp)
-		return;
-	std::lock_guard<std::mutex> lk(hp->mu);
-	hp->release();
+	// every pipeline of the process (each on its own device)
+	std::vector<HostPipe *> all;
+	{
+		std::lock_guard<std::mutex> lk(g_pipes_mu);
+		for (auto &kv : g_pipes)
+			all.push_back(kv.second);
+	}
+	int prev = -1;
+	if (!ok(hipGetDevice(&prev))) prev = -1;
+	for (HostPipe *hp : all) {
+		std::lock_guard<std::mutex> lk(hp->mu);
+		if (ok(hipSetDevice(hp->device)))
+			hp->release();
+	}
+	if (prev >= 0)
+		(void)hipSetDevice(prev);
 }
 
 } // extern "C"

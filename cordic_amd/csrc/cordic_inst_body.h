@@ -9,10 +9,25 @@
 // parallel (each unit compiles in ~15 s).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "cordic_device.h"
 #include "cordic_launch.h"
 
 namespace cordic_amd {
+
+// A/B knob (measurement only): CORDIC_FORCE_DYN=1 sends every launch of this
+// unit to its dynamic-exit instance, so that a static instance can be weighed
+// against it on the same box (profiles/r05/static_vs_dyn.txt decided which
+// static instances the library keeps)
+static inline bool force_dyn()
+{
+	static const bool v = [] {
+		const char *e = std::getenv("CORDIC_FORCE_DYN");
+		return e && e[0] == '1';
+	}();
+	return v;
+}
 
 #if CORDIC_INST_KIND == 1
 namespace {
@@ -35,7 +50,7 @@ bool launch_feed(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp,
 			j.n / kVec);
 		return true;
 	}
-	switch (nlive) {
+	switch (force_dyn() ? -1 : nlive) {
 #ifndef CORDIC_INST_DYN_ONLY	// (units that carry the dynamic-exit instance only)
 #define X(N) case N: \
 	hipLaunchKernelGGL((rotator_unrolled<CORDIC_INST_CONTAINER, N, \
@@ -154,7 +169,11 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	}
 	// a batch (cordic_jobset: tile descriptors) runs the dynamic-exit instance,
 	// the one whose tile loop reads them
-	switch (sa.tiles ? -1 : nlive) {
+	(void)tails_pay;	// (units that carry the dynamic-exit instance only)
+	// ... and so does a launch without a tile queue (the static instances
+	// carry the queued sweep only; build mode needs neither)
+	switch ((sa.tiles || (!sa.queue && !sa.image_out) || force_dyn()) ? -1 : nlive) {
+#ifndef CORDIC_INST_DYN_ONLY
 	// static instances; where the plan carries direction tails for the
 	// stages behind the seeds (left-justified cores with kDtMinStages or more of them),
 	// the instance that looks their multipliers up
@@ -175,6 +194,7 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	return true; }
 	CORDIC_ROT_STAGES(X)
 #undef X
+#endif
 	default: {
 		if (nlive < kSeedStages || nlive > kDynStages)
 			return false;
@@ -219,7 +239,8 @@ bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,
 			(const i32x4 *)y, (i32x4 *)mag, (u32x4 *)ph, n / kVec);
 		return true;
 	}
-	switch (nlive) {
+	switch (force_dyn() ? -1 : nlive) {
+#ifndef CORDIC_INST_DYN_ONLY
 #define X(N) case N: \
 	hipLaunchKernelGGL((topolar_unrolled<CORDIC_INST_CONTAINER, N, \
 			(G > N ? N : G)>), dim3(grid), dim3(kBlock), 0, st, kp, \
@@ -228,6 +249,7 @@ bool CORDIC_INST_NAME(int nlive, int grid, hipStream_t st,
 	return true;
 	CORDIC_POL_STAGES(X)
 #undef X
+#endif
 	default:
 		if (nlive < 1 || nlive > kDynStages)
 			return false;

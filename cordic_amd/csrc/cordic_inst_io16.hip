@@ -45,9 +45,11 @@ bool seed16(int nlive, int grid, hipStream_t st, const CoreParams &kp,
 		: rotator_seeded<Narrow32, kDynStages, kSeedStages, FEED, true, Io16>;
 	// the stage counts 16-bit cores usually have: static instances
 	// (-i 16 -o 16 -p 16: 13 live stages; -p 18..20: 16)
-	if (kp.post_mul == 0 && nlive == 13)
+	// (the static instances carry the queued sweep only: cordic_inst_body.h)
+	const bool queued = sa.queue != nullptr || sa.image_out != nullptr;
+	if (kp.post_mul == 0 && nlive == 13 && queued)
 		kern = rotator_seeded<Narrow32, 13, kSeedStages, FEED, false, Io16>;
-	if (kp.post_mul == 0 && nlive == 16)
+	if (kp.post_mul == 0 && nlive == 16 && queued)
 		kern = rotator_seeded<Narrow32, 16, kSeedStages, FEED, false, Io16>;
 	hipFuncAttributes attr;	// see cordic_inst_body.h: seeded_kernel_usable
 	if (hipFuncGetAttributes(&attr, (const void *)kern) != hipSuccess

@@ -3,6 +3,8 @@
 // WW 35 .. 40 whose registers cannot overflow.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "cordic_device.h"
 #include "cordic_launch.h"
 
@@ -23,7 +25,11 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	}
 	// the static instances are PLAIN: WW <= 32 and rounding at the 2^30 scale
 	const bool plain = (32 - kp.iw) - kp.in_shl >= 2 && kp.r >= 2 && kp.r <= 31;
-	switch (plain ? nlive : -1) {
+	static const bool force_dyn = [] {	// A/B knob: cordic_inst_body.h
+		const char *e = std::getenv("CORDIC_FORCE_DYN");
+		return e && e[0] == '1';
+	}();
+	switch ((plain && !force_dyn) ? nlive : -1) {
 #define X(N) case N: \
 	hipLaunchKernelGGL((topolar_lj<N, false, Io32, false, true>), dim3(grid), \
 		dim3(kBlock), 0, st, kp, (const i32x4 *)x, (const i32x4 *)y, \

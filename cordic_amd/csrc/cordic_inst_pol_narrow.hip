@@ -3,4 +3,9 @@
 #define CORDIC_INST_NAME launch_pol_narrow
 #define CORDIC_INST_CONTAINER dev::Narrow32
 #define CORDIC_INST_NGEN 0
+// Round 5: the dynamic-exit instance only.  Static
+// instances of this container measured within 2-4 % of it on their own cores
+// (profiles/r05/static_vs_dyn.txt: +1.6 / +3.2 per cent) and no core
+// gencordic derives by itself -- nor any BASELINE configuration -- runs here.
+#define CORDIC_INST_DYN_ONLY
 #include "cordic_inst_body.h"

@@ -852,10 +852,14 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 				};
 				if (j.images && cfg.ww <= 35) {
 					// the prologue's result for this vector, from the plan
-					sa.image = seed_image_for(*j.images, container, kp.x0,
+					// (a launch without a queue runs the dynamic-exit
+					// instance, whose image has no tail tables: own key)
+					sa.image = seed_image_for(*j.images,
+						container + (queue ? 0 : 8), kp.x0,
 						kp.y0, lds, st, [&](uint32_t *dst) {
 							SeedArgs b = sa;
-							b.queue = nullptr;
+							// (queue kept as it is: it selects the
+							// instance, build mode never touches it)
 							b.image = nullptr;
 							b.image_out = dst;
 							b.image_words = (uint32_t)(lds / 4);

@@ -104,7 +104,10 @@ enum cordic_status {
 #define CORDIC_FLAG_STATIC_CHUNKS	0x20u	/* plans: one contiguous chunk
 						   per persistent block instead
 						   of the address-ordered tile
-						   queue (for A/B)              */
+						   queue (for A/B; since round 5
+						   on the dynamic-exit instance,
+						   the only one that still
+						   carries that sweep)          */
 
 /*
  * One generated core.  The first block mirrors, field for field, the
@@ -920,7 +923,7 @@ int	cordic_r2p_host(const cordic_config *cfg, size_t n,
 /* pinned host memory for the arrays of the calls above (hipHostMalloc) */
 int	cordic_host_alloc(void **p, size_t bytes);
 void	cordic_host_free(void *p);
-/* drop the current device's cached pipeline (memory, streams, threads) */
+/* drop every cached pipeline of the process (memory, streams, threads) */
 void	cordic_host_release(void);
 /* what the most recent host-array call on the current device did */
 typedef struct cordic_host_stats {
@@ -931,9 +934,22 @@ typedef struct cordic_host_stats {
 	int32_t	copy_threads;		/* host threads that staged (0: none) */
 	int32_t	seeded_plan;		/* 1: a chunk ran the table-seeded
 					   kernel (cordic_last_kernel)      */
+	int32_t	lanes;			/* pipelines (devices) that shared it */
 	double	seconds;		/* wall time inside the call         */
 } cordic_host_stats;
 int	cordic_host_last_stats(cordic_host_stats *out);
+/* Several GPUs = several PCIe links: with a device list set, every host-array
+ * call is cut into as many contiguous parts (whole 16 MiB chunks) as the list
+ * has entries, and each part runs through its own pipeline on its own device,
+ * driven by its own host thread -- the path shards exactly like the compute
+ * does.  An ordinal may be listed more than once (two pipelines sharing one
+ * device and its link: how the one-GPU tests exercise it).  count == 0: back
+ * to the caller's current device.  Process-wide; takes effect for calls that
+ * start afterwards.  cordic_host_last_stats then reports the whole call
+ * (chunks and copy threads summed, lanes = parts), cordic_host_lane_stats one
+ * lane's share of it. */
+int	cordic_host_set_devices(const int *devices, int count);
+int	cordic_host_lane_stats(int lane, cordic_host_stats *out);
 
 /* ------------------------------------------------ device-side test inputs */
 

@@ -181,3 +181,65 @@ def test_concurrent_callers_queue_up_behind_each_other():
         rx, ry = O.rotate(ocfg, x0, y0, ph & np.uint32((1 << pw) - 1 if pw < 32
                                                        else 0xffffffff))
         assert np.array_equal(a, rx) and np.array_equal(b, ry), k
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_two_lanes_on_one_device_split_the_job(pinned):
+    """cordic_host_set_devices (round 5): with a device
+    list every host-array call is cut into contiguous parts, one pipeline per
+    list entry, each driven by its own host thread -- with 8 GPUs that is 8
+    PCIe links.  devices = [0, 0]: two pipelines on THIS device; both must do
+    their share, the parts must not disturb each other, the bits must be the
+    oracle's."""
+    cfg, ocfg = both(ca.P2R, 32, 32, 2, 32, 16)
+    n = 5 * CHUNK + 77
+    x, y, ph = _inputs(n, 32, 21)
+    keep = []
+
+    def arr(a, dtype):
+        if not pinned:
+            return a
+        h = ca.HostArray(n, dtype)
+        keep.append(h)
+        h.array[:] = a
+        return h.array
+    xi, yi, pi = arr(x, "int32"), arr(y, "int32"), arr(ph, "uint32")
+    ca.host_set_devices([0, 0])
+    try:
+        for scalar in (True, False):
+            if scalar:
+                a = ca.p2r_host(cfg, 2**31 - 1, 0, pi)
+                b = O.rotate(ocfg, 2**31 - 1, 0, ph)
+            else:
+                a = ca.p2r_host(cfg, xi, yi, pi)
+                b = O.rotate(ocfg, x, y, ph)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            st = ca.host_last_stats()
+            assert st["lanes"] == 2 and st["samples"] == n and st["chunks"] == 6
+            l0, l1 = ca.host_lane_stats(0), ca.host_lane_stats(1)
+            # 6 chunks over 2 lanes: 3 whole chunks, and 2 chunks + 77 samples
+            assert l0["samples"] == 3 * CHUNK and l1["samples"] == 2 * CHUNK + 77
+            assert l0["chunks"] == 3 and l1["chunks"] == 3
+            if scalar:
+                assert st["seeded_plan"] == 1
+        # the converter through the same lanes
+        rcfg, rocfg = both(ca.R2P, 24, 24, 2, -1, 20)
+        x24, y24, _ = _inputs(n, 24, 22)
+        a = ca.r2p_host(rcfg, x24, y24)
+        b = O.topolar(rocfg, x24, y24)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert ca.host_last_stats()["lanes"] == 2
+        # a job of one chunk is not worth a second lane
+        a = ca.p2r_host(cfg, 5, 6, ph[:CHUNK])
+        assert ca.host_last_stats()["lanes"] == 1
+        b = O.rotate(ocfg, 5, 6, ph[:CHUNK])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    finally:
+        ca.host_set_devices([])
+    a = ca.p2r_host(cfg, 2**31 - 1, 0, pi)
+    assert ca.host_last_stats()["lanes"] == 1
+    with pytest.raises(ca.CordicError):
+        ca.host_set_devices([0, 99])
+    for h in keep:
+        h.close()
+    ca.host_release()

@@ -134,11 +134,11 @@ def run_direct(args, w, launch):
     m, iw, ow, xtra, pw, ns = w["cli"]
     cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
     if args.generic:
-        cfg = cfg.with_flags(ca.FLAG_FORCE_GENERIC)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_FORCE_GENERIC)
     if args.no_seed:
-        cfg = cfg.with_flags(ca.FLAG_NO_SEED)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_NO_SEED)
     if args.static_chunks:
-        cfg = cfg.with_flags(ca.FLAG_STATIC_CHUNKS)
+        cfg = cfg.with_flags(cfg.flags | ca.FLAG_STATIC_CHUNKS)
     n = 1 << args.log2_samples
     index0 = rank * n                   # shard by global sample index
     x0, y0 = (1 << (iw - 1)) - 1, 0

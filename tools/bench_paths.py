@@ -33,7 +33,7 @@ def other_paths(args, steps=24, warmup=4):
                "--steps", str(steps), "--warmup", str(warmup),
                "--log2-samples", str(log2n), "--input", args.input,
                "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
-               "--pmc-counters", "SQ_INSTS_VALU"]
+               "--pmc-counters", "SQ_INSTS_VALU+SQ_INSTS_VALU_INT64"]
         if args.no_pmc:
             cmd.append("--no-pmc")
         if args.no_power:
@@ -138,6 +138,30 @@ def host_paths(log2n=28, reps=3):
     t = best(lambda: ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32),
                                  out=out))
     res["p2r_const_pinned"] = line(t, 4, 8, want, dig(*out))
+    # the same call spread over every device of the node (round 5:
+    # cordic_host_set_devices -- one pipeline, one PCIe link per device); on a
+    # one-GPU box two lanes SHARE the device and its link, which exercises the
+    # code and should cost nothing
+    ndev = ca.device_count()
+    devs = list(range(ndev)) if ndev > 1 else [0, 0]
+    ca.host_set_devices(devs)
+    try:
+        ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32), out=out)
+        t = best(lambda: ca.p2r_host(cfg, x0, 0, pin[0].array.view(np.uint32),
+                                     out=out))
+        e = line(t, 4, 8, want, dig(*out))
+        e["devices"] = devs
+        e["per_lane"] = []
+        for k in range(len(devs)):
+            ls = ca.host_lane_stats(k)
+            e["per_lane"].append({
+                "device": devs[k], "samples": ls["samples"],
+                "Msamples_per_s": (ls["samples"] / ls["seconds"] / 1e6
+                                   if ls["seconds"] else None)})
+        res["p2r_const_pinned_all_devices" if ndev > 1 else
+            "p2r_const_pinned_two_lanes_one_device"] = e
+    finally:
+        ca.host_set_devices([])
     pa, pb = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
     ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb))
     t = best(lambda: ca.p2r_host(cfg, x0, 0, ramp, out=(pa, pb)))

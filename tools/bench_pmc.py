@@ -69,23 +69,27 @@ def measure_pmc(args):
             "--no-full-digest"]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks),
-                     ("--no-tails", args.no_tails)):
+                     ("--no-tails", args.no_tails),
+                     ("--no-lj", getattr(args, "no_lj", False))):
         if on:
             base.append(flag)
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp")
+    # one rocprofv3 pass per comma-separated item; "A+B" collects A and B in
+    # the same pass (counters of one block that fit together: the SQ ones)
     counters = [c for c in args.pmc_counters.split(",") if c]
-    for ctr in counters:
+    for item in counters:
+        names = [c for c in item.split("+") if c]
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
-            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format",
-                                "csv", "-d", td, "--"] + base, cwd="/tmp",
-                               env=env, capture_output=True, text=True,
-                               timeout=600)
-            rows = []
+            r = subprocess.run(["rocprofv3", "--pmc"] + names + [
+                                "--output-format", "csv", "-d", td, "--"] + base,
+                               cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=600)
+            rows = {c: [] for c in names}
             for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"),
                                recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if (row["Counter_Name"] == ctr and kern
+                    if (row["Counter_Name"] in rows and kern
                             and kern in row["Kernel_Name"]):
                         # (not the one-block launch that builds a plan's seed
                         # image: same kernel, build mode, no samples)
@@ -94,11 +98,12 @@ def measure_pmc(args):
                                 continue
                         except (KeyError, ValueError):
                             pass
-                        rows.append(float(row["Counter_Value"]))
-            if not rows:
-                return {"error": "no %s rows for %s (rocprofv3 rc %d)"
-                        % (ctr, kern, r.returncode)}
-            vals[ctr] = (sum(rows) / len(rows), len(rows))
+                        rows[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for ctr in names:
+                if not rows[ctr]:
+                    return {"error": "no %s rows for %s (rocprofv3 rc %d)"
+                            % (ctr, kern, r.returncode)}
+                vals[ctr] = (sum(rows[ctr]) / len(rows[ctr]), len(rows[ctr]))
     out = {"kernel": kern, "passes": counters}
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
@@ -112,4 +117,10 @@ def measure_pmc(args):
         out["SQ_INSTS_VALU_per_launch"] = vals["SQ_INSTS_VALU"][0]
         out["valu_instr_per_sample"] = (vals["SQ_INSTS_VALU"][0] * 64.0
                                         / float(1 << args.log2_samples))
+    # the EXECUTED share of 64-bit integer instructions (v_mad_i64_i32 and the
+    # 64-bit shifts / adds: all half rate), for the per-opcode VALU model
+    for ctr, key in (("SQ_INSTS_VALU_INT64", "valu_int64_per_sample"),
+                     ("SQ_INSTS_VALU_INT32", "valu_int32_per_sample")):
+        if ctr in vals:
+            out[key] = vals[ctr][0] * 64.0 / float(1 << args.log2_samples)
     return out

@@ -17,7 +17,7 @@ figures, because "VALU-bound" can mean two things:
                         1.0 = THIS instruction mix cannot issue faster; the gap
                         to valu_issue_fraction is the price of the half-rate
                         opcodes, most of it v_mad_i64_i32
-                        (mad_i64_share_of_issue_time).
+                        (int64_share_of_issue_time).
 
 Both at the shader clock the kernel actually held (hwmon, same run).
 """
@@ -92,10 +92,19 @@ def hot_loop(workload):
     return (db.get(stem), stem) if stem else (None, None)
 
 
-def opcode_model(workload, instr_per_sample):
-    """Issue cycles per sample of the workload's hot loop, per-opcode priced,
-    scaled from the listing's static count to the measured instruction count
-    (the listing holds both bodies of a kernel that chooses per row)."""
+_IS64 = re.compile(r"^v_(mad_[iu]64_[iu]32|lshl_add_u64|ashrrev_i64|lshrrev_b64|"
+                   r"lshlrev_b64|mov_b64|add_co_u32|addc_co_u32|cmp_\w+_[iu]64)")
+
+
+def opcode_model(workload, instr_per_sample, int64_per_sample=None):
+    """Issue cycles per sample, per-opcode priced.  The listing's hot loop
+    holds code a given core does not execute (both bodies of a kernel that
+    chooses per row, three rounding variants), so its histogram is not taken
+    at face value: the EXECUTED count comes from this run's SQ_INSTS_VALU, the
+    executed share of 64-bit integer instructions (v_mad_i64_i32 above all:
+    half rate) from SQ_INSTS_VALU_INT64 where that pass ran, and the listing
+    only says what fraction of the remaining 32-bit instructions is half rate
+    (VOP3 forms: v_lshl_add_u32, v_bfe, v_mad_u32_u24, v_and_or_b32 ...)."""
     loop, stem = hot_loop(workload)
     if not loop or not loop.get("hist"):
         return None
@@ -104,32 +113,45 @@ def opcode_model(workload, instr_per_sample):
     n_static = float(sum(valu.values()))
     if not n_static:
         return None
-    cyc = sum(v * cycles_of(k, table) for k, v in valu.items())
-    mad = sum(v * cycles_of(k, table) for k, v in valu.items()
-              if k.startswith("v_mad_i64_i32") or k.startswith("v_mad_u64_u32"))
-    half = sum(v for k, v in valu.items()
-               if cycles_of(k, table) > FULL_RATE_CYCLES)
-    per_instr = cyc / n_static
+    w64 = {k: v for k, v in valu.items() if _IS64.match(k)}
+    w32 = {k: v for k, v in valu.items() if not _IS64.match(k)}
+    n64_static, n32_static = float(sum(w64.values())), float(sum(w32.values()))
+    half32 = sum(v for k, v in w32.items()
+                 if cycles_of(k, table) > FULL_RATE_CYCLES) / max(n32_static, 1.0)
+    cyc32 = (sum(v * cycles_of(k, table) for k, v in w32.items())
+             / max(n32_static, 1.0))
+    cyc64 = (sum(v * cycles_of(k, table) for k, v in w64.items())
+             / max(n64_static, 1.0)) if n64_static else HALF_RATE_CYCLES
+    if int64_per_sample is not None and int64_per_sample <= instr_per_sample:
+        n64, src64 = int64_per_sample, "SQ_INSTS_VALU_INT64 of this run"
+    else:
+        n64 = instr_per_sample * n64_static / n_static
+        src64 = "share in the listing (no SQ_INSTS_VALU_INT64 pass)"
+    n32 = instr_per_sample - n64
+    cyc = n64 * cyc64 + n32 * cyc32
     return {"listing": "profiles/isa/%s.s" % stem,
             "static_instr_per_sample": n_static / loop["samples_per_pass"],
-            "cycles_per_instruction": per_instr,
-            "cycles_per_sample": per_instr * instr_per_sample,
-            "half_rate_share_of_instructions": half / n_static,
-            "mad_i64_share_of_issue_time": mad / cyc,
-            "source": "hot-loop histogram (tools/dump_isa.py) x per-opcode "
-                      "cycles (tools/valu_microbench.hip: 2 full rate, 4 half "
-                      "rate), scaled to the measured instruction count"}
+            "int64_instr_per_sample": n64, "int64_source": src64,
+            "int32_half_rate_share": half32,
+            "cycles_per_instruction": cyc / instr_per_sample,
+            "cycles_per_sample": cyc,
+            "int64_share_of_issue_time": n64 * cyc64 / cyc,
+            "source": "executed counts (SQ_INSTS_VALU, SQ_INSTS_VALU_INT64) x "
+                      "per-opcode cycles (tools/valu_microbench.hip: 2 full "
+                      "rate, 4 half rate); the 32-bit mix from the hot-loop "
+                      "histogram (tools/dump_isa.py)"}
 
 
 def valu_block(samples_per_s, instr_per_sample, sclk_ghz, instr_source,
-               sclk_source, workload=None):
+               sclk_source, workload=None, int64_per_sample=None):
     if not instr_per_sample:
         return None
     clk = sclk_ghz or SCLK_MAX_GHZ
     simd_cycles_per_s = N_SIMD * clk * 1e9
     wave_instr_per_s = samples_per_s * instr_per_sample / WAVE_LANES
     issue = wave_instr_per_s * FULL_RATE_CYCLES / simd_cycles_per_s
-    model = opcode_model(workload, instr_per_sample) if workload else None
+    model = (opcode_model(workload, instr_per_sample, int64_per_sample)
+             if workload else None)
     if model:
         frac = (samples_per_s * model["cycles_per_sample"] / WAVE_LANES
                 / simd_cycles_per_s)
@@ -172,7 +194,8 @@ def add_valu(roof, samples_per_s, pm, power, prof, workload=None):
             sclk = power[key]["sclk_mhz_median"] / 1e3
             ssrc = "hwmon freq1_input median, %s window of this run" % key
             break
-    vb = valu_block(samples_per_s, instr, sclk, src, ssrc, workload)
+    vb = valu_block(samples_per_s, instr, sclk, src, ssrc, workload,
+                    (pm or {}).get("valu_int64_per_sample"))
     if vb:
         roof["valu"] = vb
         roof["valu_fraction"] = vb["frac"]

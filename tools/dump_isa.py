@@ -59,6 +59,14 @@ KERNELS = [
 ]
 
 
+# hot loop of a listing = the innermost loop with this many full-width stores;
+# one pass of it covers this many samples per lane.  The seeded kernels' tile
+# loop does two rows per rendezvous (4 stores, 8 samples); everything else one
+# vector per array (2 stores, 4 samples).
+def loop_shape(stem):
+    return (4, 8) if stem.startswith("rotator_seeded") else (2, 4)
+
+
 def sh(*cmd, **kw):
     return subprocess.run(cmd, check=True, capture_output=True, text=True, **kw).stdout
 
@@ -90,6 +98,7 @@ def metadata(co, mangled):
 def main():
     os.makedirs(OUT, exist_ok=True)
     rows = []
+    loops = {}
     with tempfile.TemporaryDirectory() as td:
         for stem, obj, pat, what in KERNELS:
             co = code_object(os.path.join(BUILD, obj), td)
@@ -118,6 +127,7 @@ def main():
             # address + 4 + 4 * (simm16 - 65536)) whose body holds the most
             # VALU instructions
             best = (0, len(ins) - 1, -1)
+            want_st, per_pass = loop_shape(stem)
             for i, ln in enumerate(lines[1:]):
                 m = re.match(r"\s*s_cbranch_\w+\s+(\d+)", ln)
                 if not m or int(m.group(1)) < 0x8000 or addr[i] is None:
@@ -129,9 +139,10 @@ def main():
                 n_valu = sum(1 for t in ins[b:i + 1] if t.startswith("v_"))
                 n_st = sum(1 for t in ins[b:i + 1]
                            if t.startswith("global_store_dwordx"))
-                # one pass stores each output array once: a range with more
-                # stores spans two loops (a kernel with two work distributions)
-                if n_st == 2 and n_valu > best[2]:
+                # one pass stores each output array once per row: a range
+                # with more stores spans two loops (a kernel with two work
+                # distributions)
+                if n_st == want_st and n_valu > best[2]:
                     best = (b, i, n_valu)
             lo, hi = best[0], best[1]
             hot = ins[lo:hi + 1]
@@ -142,9 +153,9 @@ def main():
                 f.write("; %s\n; %s\n; object %s, llvm-objdump -d --no-show-raw-insn\n"
                         % (what, heads_d[k][1], obj))
                 f.write("; registers / memory: %s\n" % md)
-                f.write("; hot loop = listing lines %d..%d (one pass: 4 samples per lane), "
+                f.write("; hot loop = listing lines %d..%d (one pass: %d samples per lane), "
                         "%d VALU instructions = %.1f per sample\n"
-                        % (lo + 2, hi + 2, valu, valu / 4.0))
+                        % (lo + 2, hi + 2, per_pass, valu, valu / float(per_pass)))
                 f.write("; histogram of the hot loop: %s\n\n" % ", ".join(
                     "%s x%d" % kv for kv in hist.most_common()))
                 f.write("\n".join(lines) + "\n")
@@ -154,12 +165,20 @@ def main():
                 # 136 KiB of dynamic LDS per 1024-thread block: one block,
                 # 16 waves, per CU
                 waves = min(waves, 4)
-            rows.append((stem, what, md, valu / 4.0, hist, waves))
+            rows.append((stem, what, md, valu / float(per_pass), hist, waves))
+            loops[stem] = {"samples_per_pass": per_pass, "valu": valu,
+                           "hist": dict(hist), "kernel": heads_d[k][1]}
+    # machine-readable twin: tools/bench_valu.py prices these histograms per
+    # opcode (roofline.valu.model of every bench line)
+    import json
+    with open(os.path.join(OUT, "hot_loops.json"), "w") as f:
+        json.dump(loops, f, indent=1, sort_keys=True)
     with open(os.path.join(OUT, "README.md"), "w") as f:
         f.write("# ISA of the hot kernels (gfx950, shipped code objects)\n\n"
                 "Written by `tools/dump_isa.py` from `cordic_amd/csrc/build/*.o`. "
                 "\"VALU / sample\" counts the `v_*` instructions of the hot loop "
-                "(one pass = 4 samples per lane) divided by 4; waves / SIMD is "
+                "divided by the samples a lane handles per pass (4; 8 in the "
+                "seeded kernels' two-row tile loop); waves / SIMD is "
                 "what the VGPR allocation allows (512 VGPRs per SIMD lane, "
                 "granule 8, at most 8).\n\n"
                 "| listing | kernel | VGPR | SGPR | static LDS B | scratch B | spills | waves/SIMD | VALU / sample | v_mad_i64_i32 | v_bitop3_b32 | v_ashrrev_i32 |\n"

@@ -11,9 +11,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}	# as cordic_amd/csrc/Makefile
 ARCH=${ARCH:-gfx950}
 cd "$ROOT/cordic_amd/csrc"
-# the product build's objects are reused: make them if a snapshot (or `make
-# clean`) left only the library behind
-ls build/*.o > /dev/null 2>&1 || make -j"$(nproc)" HIPCC="$HIPCC" ARCH="$ARCH"
+# the product build's objects are reused; a snapshot (the GPU boxes get the
+# libraries without build/) or `make clean` leaves none: nothing to do here
+# then -- the test that wants lib_fault.so skips when it is missing
+ls build/*.o > /dev/null 2>&1 || { echo "no product objects: lib_fault.so not rebuilt"; exit 0; }
 mkdir -p build_fault
 find build_fault -type l -delete	# objects of an earlier source layout
 # every other object is identical: reuse the product build's
