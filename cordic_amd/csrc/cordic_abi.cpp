@@ -366,6 +366,11 @@ int cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
 		j.io16 = io16 != 0;
 		j.prepare_only = true;
 		attach_seed(plan, j);
+		// the image of the instance a QUEUED launch runs (the ordinary case;
+		// a launch without a queue runs the dynamic-exit instance and keeps
+		// its own): any counter block stands for "queued" here -- build mode
+		// never touches it
+		j.queue = plan->queues.d;
 		const int r = launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
 		if (!io16)
 			rc = r;

@@ -454,9 +454,11 @@ def test_one_rank_under_torchrun_measures_what_the_direct_run_measures():
     """N = 1 through the driver's multi-rank command (process group, host
     group, guards) against the plain N = 1 run: same value within 2 % (best
     of two each: the boxes' own run-to-run spread is ~1 %)."""
-    # (BASELINE's size: the rank-to-rank barrier that closes the timed region
-    # costs the torchrun form ~0.3 ms, 2 % of a 2^28-sample run)
-    args = ["--steps", "20", "--warmup", "5", "--log2-samples", "30",
+    # (BASELINE's size and the default 100 steps: behind the rank-to-rank
+    # barrier that opens the timed region the first step runs ~0.3 ms long --
+    # the device idled through the collective -- which is 1.7 % of a 20-step
+    # run and 0.15 % of this one; profiles/r05/torchrun_vs_direct.txt)
+    args = ["--steps", "100", "--warmup", "5", "--log2-samples", "30",
             "--no-full-digest"] + QUIET
 
     def best(fn):

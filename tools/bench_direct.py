@@ -44,9 +44,12 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             dist.barrier()
         torch.cuda.synchronize()
     sampler = start_power(dev.index or 0, rank == 0 and not args.no_power)
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.warmup - 1)):
         tab.lookup(phase, out)
     barrier()
+    if args.warmup >= 1:        # (the last warm-up behind the barrier: bench.py)
+        tab.lookup(phase, out)
+        torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
@@ -220,9 +223,12 @@ def run_direct(args, w, launch):
         torch.cuda.synchronize()
 
     sampler = start_power(local, rank == 0 and not args.no_power)
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, args.warmup - 1)):
         step()
     barrier()
+    if args.warmup >= 1:        # (the last warm-up behind the barrier: bench.py)
+        step()
+        torch.cuda.synchronize()
     ran = ca.last_kernel()      # the family that really serves this batch size
 
     # ---- timed region: exactly K steps; HIP events (on the stream the
