@@ -1117,7 +1117,8 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 	};
 	typename IO::uvec pa[kSeedSub] = {};
 	bool early = false;
-	if (!DYN && sa.queue != nullptr && sa.image_out == nullptr) {
+	if (!DYN && sa.queue != nullptr && sa.image_out == nullptr
+			&& sa.tiles == nullptr) {
 		const uint32_t lo = q_home * per;
 		const uint32_t cnt = lo >= ntiles ? 0u : (ntiles - lo < per ? ntiles - lo : per);
 		early = q_rank < cnt;		// else: fewer tiles than blocks here
@@ -1573,7 +1574,16 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		apply_unit_gain<UG>(ry, kp);
 	};
 
-	if constexpr (DYN) {
+	// (A/B, profiles/r05/ab_desc_loop.txt: this loop in the STATIC instances
+	// too would let job sets run them -- +8 % / +22 % on batches of 16- / 24-
+	// stage cores -- and costs single jobs 6-7 % where the VALU binds (cfg4
+	// 385 -> 362, cfg5 582 -> 541 Gsample/s): not adopted)
+#ifdef CORDIC_DESC_LOOP_ALL
+	constexpr bool kDescLoop = true;	// A/B: every instance walks descriptors
+#else
+	constexpr bool kDescLoop = DYN;
+#endif
+	if constexpr (kDescLoop) {
 	if (sa.queue != nullptr) {
 		// Dynamic-exit instances: the queue of the static instances (below:
 		// read that comment first) one slot deeper and over TILE DESCRIPTORS
@@ -1693,8 +1703,14 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		int ring = 0;
 		Desc dcur = settle(fetch(cur)), dnxt = settle(fetch(nxt));
 		typename IO::uvec pd[kSeedSub] = {};
-		if (cur != kEnd)
+		if (early) {
+			// (requested before the prologue: the head of this function)
+#pragma unroll
+			for (int s = 0; s < kSeedSub; s++)
+				pd[s] = pa[s];
+		} else if (cur != kEnd) {
 			load_rows(dcur, pd);
+		}
 		while (cur != kEnd) {
 			// the tile after next: its descriptor is asked for now ...
 			const uint32_t nn = __builtin_amdgcn_readfirstlane(slot[(ring + 2) % kRing]);
@@ -1729,7 +1745,12 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 			for (int s = 0; s < kSeedSub; s++) {
 				if (lane + (uint32_t)s * kSeedBlock < dcur.live) {
 					i32x4 rx, ry;
-					pass_pb(std::false_type{}, pb[s], rx, ry);
+					if constexpr (DT && dt_always(kDtR))
+						pass_pb(std::true_type{}, pb[s], rx, ry);
+					else if (DT && row_is_coherent(pb[s]))
+						pass_pb(std::true_type{}, pb[s], rx, ry);
+					else
+						pass_pb(std::false_type{}, pb[s], rx, ry);
 					typename IO::ivec *o0 = reinterpret_cast<typename IO::ivec *>(
 						(uintptr_t)dcur.ox) + (size_t)s * kSeedBlock;
 					typename IO::ivec *o1 = reinterpret_cast<typename IO::ivec *>(
@@ -1752,7 +1773,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		return;
 	}
 	}
-	if (!DYN && sa.queue != nullptr) {
+	if (!kDescLoop && sa.queue != nullptr) {
 		// Work distribution, dynamic: the persistent blocks (they keep the
 		// table in LDS) pull 4096-sample tiles from a counter IN ADDRESS
 		// ORDER, the way the hardware dispatcher hands out the blocks of a

@@ -172,7 +172,12 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	(void)tails_pay;	// (units that carry the dynamic-exit instance only)
 	// ... and so does a launch without a tile queue (the static instances
 	// carry the queued sweep only; build mode needs neither)
-	switch ((sa.tiles || (!sa.queue && !sa.image_out) || force_dyn()) ? -1 : nlive) {
+#ifdef CORDIC_DESC_LOOP_ALL
+	const bool batch_needs_dyn = false;	// A/B: every instance reads descriptors
+#else
+	const bool batch_needs_dyn = sa.tiles != nullptr;
+#endif
+	switch ((batch_needs_dyn || (!sa.queue && !sa.image_out) || force_dyn()) ? -1 : nlive) {
 #ifndef CORDIC_INST_DYN_ONLY
 	// static instances; where the plan carries direction tails for the
 	// stages behind the seeds (left-justified cores with kDtMinStages or more of them),

@@ -1026,7 +1026,14 @@ int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j
 	if (tabs.ntiles) {
 		SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets, j.seed_nleaves,
 				j.queue, j.dt};
+#ifdef CORDIC_DESC_LOOP_ALL
+		constexpr int kJobImageKey = 0;	// A/B: the static instances, their image
+		if (cfg.flags & CORDIC_FLAG_NO_TAILS)
+			sa.dt.n = 0;
+#else
+		constexpr int kJobImageKey = 4;	// (its own image slot: no tail tables in it)
 		sa.dt.n = 0;		// (dynamic-exit instances run the recurrence behind the seeds)
+#endif
 		sa.tiles = tabs.tiles;
 		sa.ntiles = tabs.ntiles;
 		const size_t lds = (dt_lds_layout(sa.dt,
@@ -1051,8 +1058,7 @@ int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j
 			}
 		};
 		if (j.images) {
-			// (its own image slot: no tail tables in it -- container ids 4..6)
-			sa.image = seed_image_for(*j.images, 4 + container, kp.x0, kp.y0,
+			sa.image = seed_image_for(*j.images, kJobImageKey + container, kp.x0, kp.y0,
 				lds, st, [&](uint32_t *dst) {
 					// one block of the same (dynamic-exit) instance in build
 					// mode: it returns behind the prologue, the tile table is
