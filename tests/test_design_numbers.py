@@ -1,5 +1,5 @@
 """DESIGN.md section 4.4 against the committed sweep:
-the kernel table is GENERATED from profiles/bench_r04/*.json
+the kernel table is GENERATED from profiles/bench_r05/*.json
 (tools/design_table.py), and every one of those lines was measured on the
 kernel sources as they are now (tools/build_stamp.py: SHA-256 over the device /
 launch / table-builder sources without comments and white space) -- a kernel
@@ -18,20 +18,20 @@ import design_table  # noqa: E402
 def test_the_table_in_design_md_is_the_generated_one():
     lines = design_table.lines()
     if not lines:
-        pytest.skip("profiles/bench_r04/ holds no sweep yet")
+        pytest.skip("profiles/bench_r05/ holds no sweep yet")
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     assert design_table.BEGIN in text and design_table.END in text
     a = text.index(design_table.BEGIN)
     b = text.index(design_table.END) + len(design_table.END)
     assert text[a:b] == design_table.block(), (
-        "DESIGN.md section 4.4 differs from profiles/bench_r04: run "
+        "DESIGN.md section 4.4 differs from profiles/bench_r05: run "
         "python tools/design_table.py --write")
 
 
 def test_every_sweep_line_was_measured_on_the_current_kernel_sources():
     lines = design_table.lines()
     if not lines:
-        pytest.skip("profiles/bench_r04/ holds no sweep yet")
+        pytest.skip("profiles/bench_r05/ holds no sweep yet")
     now = build_stamp.kernel_sources_sha256()
     stale = []
     for w, e in lines.items():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """DESIGN.md section 4.4's kernel table, GENERATED from the committed bench
-lines of one sweep (profiles/bench_r04/*.json: tools/gpu_session.sh sweep on
+lines of one sweep (profiles/bench_r05/*.json: tools/gpu_session.sh sweep on
 one box, one code state) -- so every number in it IS a committed line's.
 
     python tools/design_table.py            # print the block
@@ -14,10 +14,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEP = os.path.join(ROOT, "profiles", "bench_r04")
+SWEEP = os.path.join(ROOT, "profiles", "bench_r05")
 BEGIN = "<!-- BEGIN generated: tools/design_table.py -->"
 END = "<!-- END generated -->"
-ORDER = ["cfg2", "cfg4", "cfg5", "cfg5seq", "p2rxy", "cfg3", "cfg1", "nat32",
+ORDER = ["cfg2", "cfg4", "cfg5", "cfg5seq", "p2rxy", "ddc", "cfg3", "cfg1", "nat32",
          "nat24", "nat16", "natr2p24", "sintbl", "qtrtbl16", "qtrtbl24",
          "qtrtbl", "quadtbl", "quadtbl24"]
 
@@ -47,23 +47,24 @@ def fmt(v, nd=0):
 
 def block():
     rows = ["| workload | kernel | B/sample | instr/sample | ramp: Gsample/s | "
-            "HBM frac | valu_fraction | bound | random: Gsample/s | HBM frac |",
-            "|---|---|---|---|---|---|---|---|---|---|"]
+            "HBM frac | valu_fraction | valu_issue_fraction | bound | "
+            "random: Gsample/s | HBM frac |",
+            "|---|---|---|---|---|---|---|---|---|---|---|"]
     for w, e in lines().items():
         a, b = e["ramp"], e["random"]
         ra = a["roofline"]
         valu = ra.get("valu") or {}
         full = a.get("full_recurrence_kernel")
-        rows.append("| %s | `%s` | %d | %s | %s | %.3f | %s | %s | %s | %s |" % (
+        rows.append("| %s | `%s` | %d | %s | %s | %.3f | %s | %s | %s | %s | %s |" % (
             a["config"]["workload"].split(":")[0], a["config"]["kernel"],
             ra["bytes_per_sample"], fmt(valu.get("instr_per_sample"), 1),
             fmt(a["value"] / 1e3), ra["frac"], fmt(ra.get("valu_fraction"), 2),
-            ra.get("bound", "hbm"),
+            fmt(ra.get("valu_issue_fraction"), 2), ra.get("bound", "hbm"),
             fmt(b["value"] / 1e3) if b else "—",
             ("%.3f" % b["roofline"]["frac"]) if b else "—"))
         if full:
             rows.append("| %s, full recurrence | `rotator_unrolled` | %d | — | %s "
-                        "| %.3f | — | valu | — | — |" % (
+                        "| %.3f | — | — | valu | — | — |" % (
                             w, ra["bytes_per_sample"],
                             fmt(full["value_per_gpu"] / 1e3), full["hbm_frac"]))
     d = load("default.json")

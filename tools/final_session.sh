@@ -18,6 +18,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/de
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/bench_sweep gpurun_out/prof
 bash tools/gpu_session.sh env sweep > $OUT/session.log 2>&1
-for w in cfg2 cfg3 cfg4 cfg5 p2rxy cfg1 nat24 nat32; do timeout 900 bash tools/profile_workload.sh $w > $OUT/prof_$w.log 2>&1; done
-for w in cfg2 cfg4 nat24 p2rxy; do timeout 900 bash tools/profile_workload.sh $w --input random > $OUT/prof_${w}_random.log 2>&1; done
+for w in cfg2 cfg3 cfg4 cfg5 p2rxy ddc cfg1 nat24 nat32; do timeout 900 bash tools/profile_workload.sh $w > $OUT/prof_$w.log 2>&1; done
+for w in cfg2 cfg4 p2rxy; do timeout 900 bash tools/profile_workload.sh $w --input random > $OUT/prof_${w}_random.log 2>&1; done
 python bench.py --host-paths-only > $OUT/host_paths.json 2>/dev/null
+timeout 900 python tools/small_batch_probe.py > $OUT/small_batch.txt 2>&1
+# the driver's multi-rank command, default flags, 8 ranks SHARING this GPU (test
+# switch; RCCL entry points from tests/rccl_shim): the line an 8-GPU node prints
+BENCH_TEST_SHARE_GPU=1 CORDIC_RCCL_LIB=$PWD/tests/rccl_shim/librccl_shim.so HSA_ENABLE_IPC_MODE_LEGACY=0 \
+	timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+	--master-port 29533 bench.py --gpus 8 --workload cfg4 --log2-samples 26 --steps 20 --warmup 5 \
+	> $OUT/bench_8_ranks_one_gpu.json 2> $OUT/bench_8_ranks_one_gpu.err

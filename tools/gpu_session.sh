@@ -70,9 +70,9 @@ d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['ro
 		# carry this run's SQ_INSTS_VALU pass (instr/sample); every line is
 		# stamped with the code state (build.kernel_sources_sha256)
 		mkdir -p gpurun_out/bench_sweep
-		for w in ${SWEEP_WORKLOADS:-cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy nat32 nat24 nat16 natr2p24 sintbl qtrtbl qtrtbl16 qtrtbl24 quadtbl quadtbl24}; do
+		for w in ${SWEEP_WORKLOADS:-cfg2 cfg1 cfg3 cfg4 cfg5 cfg5seq p2rxy ddc nat32 nat24 nat16 natr2p24 sintbl qtrtbl qtrtbl16 qtrtbl24 quadtbl quadtbl24}; do
 			python bench.py --workload $w --input ramp --no-cpu-baseline --no-other-paths \
-				--pmc-counters SQ_INSTS_VALU > gpurun_out/bench_sweep/${w}_ramp.json 2>> $log
+				--pmc-counters SQ_INSTS_VALU+SQ_INSTS_VALU_INT64 > gpurun_out/bench_sweep/${w}_ramp.json 2>> $log
 			python bench.py --workload $w --input random --no-cpu-baseline --no-other-paths --no-pmc \
 				> gpurun_out/bench_sweep/${w}_random.json 2>> $log
 		done

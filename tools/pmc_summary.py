@@ -55,7 +55,7 @@ def short(name):
 
 
 res = {"tag": tag, "kernels": {}}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_int"):
     acc = counters(sub)
     for k, d in acc.items():
         sk = short(k)

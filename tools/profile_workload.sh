@@ -18,4 +18,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH3 > $O
 BENCH10="python $R/bench.py --workload $W $EXTRA --steps 10 --warmup 2 --no-cpu-baseline --no-other-paths --no-copy-probe --no-pmc --no-power"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH10 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds -- $BENCH3 > $OUT/pmc_lds.log 2>&1
+# (round 5) the executed 32- / 64-bit integer split: the 64-bit ones are the half-rate v_mad_i64_i32
+rocprofv3 --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/pmc_int -- $BENCH3 > $OUT/pmc_int.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT $TAG
