@@ -1145,11 +1145,28 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		dt_lds_layout(sa.dt, seed_base + 4u * (uint32_t)L * 16u + 16u, dt_bk, dt_lf);
 	}
 	if (sa.image != nullptr) {
-		// the plan holds this prologue's result for (x0, y0): copy it
+		// the plan holds this prologue's result for (x0, y0): copy it.  All of
+		// a thread's loads are in flight together (a plain loop waits out the
+		// L2 latency once per 16 bytes: ~9 round trips, 5 us; profiles/r05/
+		// small_batch.txt): indices clamped so that the loads need no
+		// predicate, stores predicated.  160 KiB / 16 B / 1024 threads = 10.
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(sa.image);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
-		for (uint32_t i = threadIdx.x; i < sa.image_words / 4u; i += kSeedBlock)
-			dst[i] = src[i];
+		const uint32_t nv = sa.image_words / 4u;
+		constexpr int kCopies = (int)(CORDIC_SEED_LDS_BYTES / 16u / kSeedBlock);
+		u32x4 r[kCopies];
+#pragma unroll
+		for (int k = 0; k < kCopies; k++) {
+			uint32_t i = threadIdx.x + (uint32_t)k * kSeedBlock;
+			i = i < nv ? i : nv - 1u;
+			r[k] = src[i];
+		}
+#pragma unroll
+		for (int k = 0; k < kCopies; k++) {
+			const uint32_t i = threadIdx.x + (uint32_t)k * kSeedBlock;
+			if (i < nv)
+				dst[i] = r[k];
+		}
 	} else {
 	// bucket entries as the lookup wants them: {bound - 1, byte address of
 	// the bucket's first leaf in quadrant 0}.  A bucket without a boundary

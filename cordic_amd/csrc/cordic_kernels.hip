@@ -825,7 +825,9 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			int per_cu = 32 / (kSeedBlock / 64);
 			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
 			if (by_lds < per_cu) per_cu = by_lds;
-			const int g2 = grid_for((size_t)kSeedBlock * kVec, j.n,
+			// (a block per tile at most: a block without one would stage the
+			// table for nothing)
+			const int g2 = grid_for((size_t)kSeedBlock * kVec * kSeedSub, j.n,
 					per_cu < 1 ? 1 : per_cu);
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
