@@ -56,8 +56,9 @@ def other_paths(args, steps=24, warmup=4):
              "digest_check": {k: (d.get("digest_check") or {}).get(k) for k in (
                  "samples", "equal", "oracle", "oracle_seconds")},
              "roofline": {k: roof[k] for k in (
-                 "bound", "achieved", "peak", "unit", "frac", "valu_fraction",
-                 "valu", "kernel_ms_avg", "kernel_ms_min") if k in roof},
+                 "bound", "limiter", "achieved", "peak", "unit", "frac",
+                 "valu_fraction", "valu_issue_fraction", "valu", "kernel_ms_avg",
+                 "kernel_ms_min") if k in roof},
              "wall_s": time.perf_counter() - t0}
         pw = (roof.get("power") or {}).get("sustained")
         if pw:

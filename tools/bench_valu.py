@@ -40,7 +40,12 @@ SCLK_MAX_GHZ = 2.4
 LISTING_OF = {"cfg2": "rotator_seeded_lj29_16", "cfg4": "rotator_seeded_lj29_24",
               "cfg5": "rotator_seeded_lj29_16_nco", "p2rxy": "rotator_xydir_lj29_16",
               "ddc": "rotator_xydir_lj29_16", "cfg3": "topolar_lj_20",
-              "cfg2_noseed": "rotator_unrolled_lj29_16"}
+              "cfg2_noseed": "rotator_unrolled_lj29_16",
+              # no listing of their own: the 32-bit opcode mix of the same kernel
+              # family (the executed counts are their own)
+              "cfg5seq": "rotator_seeded_lj29_16_nco", "cfg1": "rotator_seeded_lj29_16",
+              "nat16": "rotator_seeded_lj29_24", "nat24": "rotator_seeded_lj29_24",
+              "nat32": "rotator_seeded_lj29_24", "natr2p24": "topolar_lj_20"}
 
 _MICRO = re.compile(r"^(\w+)\s+[\d.]+ ms\s+[\d.]+ T lane-ops/s\s+([\d.]+) cyc")
 
@@ -202,6 +207,25 @@ def add_valu(roof, samples_per_s, pm, power, prof, workload=None):
         roof["valu_issue_fraction"] = vb["issue_fraction"]
         # whichever ceiling the kernel sits nearer to
         roof["bound"] = "hbm" if roof["frac"] >= vb["frac"] else "valu"
+        # ... and what actually holds it there: the copy
+        # ceiling of this run's arrays, VALU issue, or -- for kernels that
+        # saturate neither -- the socket's power limit, which sets the clock
+        cf = roof.get("copy_frac")
+        cap = (power or {}).get("at_cap")
+        if cf and roof["frac"] >= 0.95 * cf:
+            roof["limiter"] = "hbm: at the same-run copy ceiling (%.3f of %.3f)" % (
+                roof["frac"], cf)
+        elif vb["frac"] >= 0.75:
+            roof["limiter"] = "valu: this instruction mix issues %.0f %% of the time" % (
+                100 * vb["frac"])
+        elif cap:
+            roof["limiter"] = ("power: socket at its limit (%.0f W), clock %.2f GHz; "
+                               "neither HBM (%.2f) nor VALU issue (%.2f) saturated"
+                               % (power["sustained"]["socket_w_median"],
+                                  vb["sclk_ghz"], roof["frac"], vb["frac"]))
+        else:
+            roof["limiter"] = "undetermined (hbm %.2f, valu %.2f)" % (
+                roof["frac"], vb["frac"])
         roof["bound_note"] = (
             "hbm frac %.3f vs valu_fraction %.3f (this instruction mix at the "
             "clock the power limit allowed) / valu_issue_fraction %.3f (the "
