@@ -109,6 +109,28 @@ __device__ __forceinline__ int64_t sext64(int64_t v, int w)
 // the shared VCC is not a bottleneck.)
 // -s for s = +/-1 as one full-rate VOP2 (hipcc would fuse (d|1)^-2 into a
 // three-operand v_bitop3_b32)
+//
+// CORDIC_STAGE_YIELD (A/B knob, off).  A wave issues at most one VALU
+// instruction per four cycles and a SIMD keeps issuing from the wave it is on:
+// a full-rate 32-bit instruction (two cycles of the SIMD) leaves the other two
+// empty unless that wave steps aside and another one fills them.
+// tools/sched_probe (the r2p micro-rotation's seven instructions, 4 samples a
+// lane, 8 waves a SIMD, 2 ms bursts): 4.19 cycles per instruction as written,
+// 3.76 with the wait states hipcc happens to pad behind asm-defined registers,
+// 3.36 with `s_nop 0` behind every 32-bit instruction and none behind the
+// multiply-adds (3.02 = the opcodes' own 2 / 4 cycles); s_nop 1, a wait state
+// behind a multiply-add, or an SALU instruction as the filler are all worse
+// (profiles/r05/sched_probe.txt).  Built into topolar_lj (=1) the kernel needs
+// 1 % fewer cycles and is no faster: it runs for seconds, not bursts, the
+// SMU's PPT limiter holds the clock (active 71 % of the time at 1.29 kW), and
+// the better schedule is answered with a lower clock: 224 against 229
+// Gsample/s at 2.09 / 2.16 GHz, 5.73 / 5.80 nJ per sample
+// (profiles/r05/ab_stage_yield.txt).  What is left to gain there is energy
+// per sample, not issue slots.
+#ifndef CORDIC_STAGE_YIELD
+#define CORDIC_STAGE_YIELD 0
+#endif
+#define CORDIC_YIELD "\n\ts_nop 0"
 __device__ __forceinline__ int32_t op_flip(int32_t s)
 {
 	int32_t r;
@@ -2105,13 +2127,52 @@ __global__ __launch_bounds__(kBlock) void topolar_unrolled(CoreParams kp,
 // values as topolar_unrolled, bit for bit.
 struct PolLjRegs { uint32_t sign, p30; };	// 2^31, 2^30 in VGPRs
 
+// scratch registers of one sample's micro-rotations (CORDIC_STAGE_YIELD: kept
+// live from stage to stage so that neighbouring statements share no register
+// -- hipcc pads a wait state between two asm statements that do, and one
+// behind a multiply-add costs more than the ones behind the 32-bit
+// instructions gain)
+struct PolTmp { uint32_t t, nt, sy, sx; uint64_t cc; };
+
 template <int K>
 __device__ __forceinline__ void pol_stage_lj(int64_t &x, int64_t &y, int64_t &p,
-		uint32_t a, const PolLjRegs &c)
+		uint32_t a, const PolLjRegs &c, PolTmp &m)
 {
 	static_assert(K >= 2, "stage 1 runs on the 32-bit values");
 	constexpr int sh = (K - 2 > 31) ? 31 : K - 2;
 	const uint32_t yh = (uint32_t)((uint64_t)y >> 32);
+#if CORDIC_STAGE_YIELD
+	// the whole micro-rotation as ONE statement, so that the wait state
+	// behind each 32-bit instruction stays where it is put (see
+	// CORDIC_STAGE_YIELD); the high words are read before the multiply-adds
+	// write their pairs
+	const uint32_t xh = (uint32_t)((uint64_t)x >> 32);
+	// (the carry-out nobody reads goes to the sample's own SGPR pair: two
+	// statements that both clobber VCC count as sharing a register)
+	if constexpr (sh == 0) {
+		// y's high word is the multiplicand as it stands; x's is copied,
+		// the first multiply-add overwrites it
+		asm("v_bitop3_b32 %3, %7, %9, %10 bitop3:0xec" CORDIC_YIELD "\n\t"
+		    "v_mov_b32 %5, %8" CORDIC_YIELD "\n\t"
+		    "v_xor_b32 %4, %3, %10" CORDIC_YIELD "\n\t"
+		    "v_mad_i64_i32 %0, %6, %7, %3, %0\n\t"
+		    "v_mad_i64_i32 %1, %6, %5, %4, %1\n\t"
+		    "v_mad_i64_i32 %2, %6, %11, %3, %2"
+		    : "+v"(x), "+v"(y), "+v"(p), "+v"(m.t), "+v"(m.nt), "+v"(m.sx), "+s"(m.cc)
+		    : "v"(yh), "v"(xh), "v"(c.p30), "v"(c.sign), "s"(a));
+		return;
+	}
+	asm("v_bitop3_b32 %3, %8, %10, %11 bitop3:0xec" CORDIC_YIELD "\n\t"
+	    "v_ashrrev_i32 %5, %12, %8" CORDIC_YIELD "\n\t"
+	    "v_ashrrev_i32 %6, %12, %9" CORDIC_YIELD "\n\t"
+	    "v_xor_b32 %4, %3, %11" CORDIC_YIELD "\n\t"
+	    "v_mad_i64_i32 %0, %7, %5, %3, %0\n\t"
+	    "v_mad_i64_i32 %1, %7, %6, %4, %1\n\t"
+	    "v_mad_i64_i32 %2, %7, %13, %3, %2"
+	    : "+v"(x), "+v"(y), "+v"(p), "+v"(m.t), "+v"(m.nt), "+v"(m.sy), "+v"(m.sx),
+	      "+s"(m.cc)
+	    : "v"(yh), "v"(xh), "v"(c.p30), "v"(c.sign), "n"(sh), "s"(a));
+#else
 	const int32_t t = (int32_t)op_and_or(yh, c.p30, c.sign);	// +/- 2^30
 	const int32_t nt = (int32_t)((uint32_t)t ^ c.sign);		// -t
 	const int32_t sy = (int32_t)yh >> sh;
@@ -2119,19 +2180,20 @@ __device__ __forceinline__ void pol_stage_lj(int64_t &x, int64_t &y, int64_t &p,
 	op_mad(x, sy, t);		// x' = x + t * (y >>> k)
 	op_mad(y, sx, nt);		// y' = y - t * (x >>> k)
 	op_mad_s(p, a, t);		// p' = p + t * a_k
+#endif
 }
 
 template <int NLIVE, int I, bool DYN> struct PolChainLJ {
 	static __device__ __forceinline__ void run(int64_t (&x)[kVec],
 			int64_t (&y)[kVec], int64_t (&p)[kVec], const PolLjRegs &c,
-			const CoreParams &kp)
+			const CoreParams &kp, PolTmp (&m)[kVec])
 	{
 		if constexpr (I < NLIVE) {
 			if (!DYN || I < kp.nlive) {
 #pragma unroll
 				for (int v = 0; v < kVec; v++)
-					pol_stage_lj<I + 1>(x[v], y[v], p[v], kp.angle[I], c);
-				PolChainLJ<NLIVE, I + 1, DYN>::run(x, y, p, c, kp);
+					pol_stage_lj<I + 1>(x[v], y[v], p[v], kp.angle[I], c, m[v]);
+				PolChainLJ<NLIVE, I + 1, DYN>::run(x, y, p, c, kp, m);
 			}
 		}
 	}
@@ -2256,7 +2318,14 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 				pol_stage1_lj_early(x[v], y[v], p[v], kp.angle[0], c);
 		}
 
-		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp);
+		PolTmp m[kVec];
+#if CORDIC_STAGE_YIELD
+#pragma unroll
+		for (int v = 0; v < kVec; v++)	// (registers, no values: nothing to emit)
+			asm volatile("" : "=v"(m[v].t), "=v"(m[v].nt), "=v"(m[v].sy), "=v"(m[v].sx),
+					"=s"(m[v].cc));
+#endif
+		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp, m);
 
 		i32x4 rm;
 		u32x4 rp;

@@ -177,42 +177,45 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 #else
 	const bool batch_needs_dyn = sa.tiles != nullptr;
 #endif
+	auto go = [&](auto kern) {
+		if (!seeded_kernel_usable((const void *)kern, lds_bytes))
+			return false;
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp, sa,
+			(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec);
+		return true;
+	};
 	switch ((batch_needs_dyn || (!sa.queue && !sa.image_out) || force_dyn()) ? -1 : nlive) {
 #ifndef CORDIC_INST_DYN_ONLY
 	// static instances; where the plan carries direction tails for the
-	// stages behind the seeds (left-justified cores with kDtMinStages or more of them),
-	// the instance that looks their multipliers up
+	// stages behind the seeds (left-justified cores with kDtMinStages or more
+	// of them), the instance that looks their multipliers up.  A phase ARRAY
+	// on such a core -- and an NCO where every row looks up (dt_always) -- runs
+	// without its tails under CORDIC_FLAG_NO_TAILS only (an A/B flag): no
+	// static instance for that, the dynamic-exit one below.
 #define X(N) case N: { \
-	auto kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>; \
-	if constexpr ((CORDIC_INST_CONTAINER::lj != 0 || !CORDIC_INST_CONTAINER::wide) \
+	constexpr bool kTails = (CORDIC_INST_CONTAINER::lj != 0 || !CORDIC_INST_CONTAINER::wide) \
 			&& dt_levels(N - kSeedStages) >= 1 \
-			&& dt_levels(N - kSeedStages) <= kDtMaxLevels) { \
+			&& dt_levels(N - kSeedStages) <= kDtMaxLevels; \
+	if constexpr (kTails) { \
 		if (sa.dt.n == dt_levels(N - kSeedStages) \
 				&& (tails_pay || dt_always(N - kSeedStages))) \
-			kern = rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, \
-					FEED, false, Io32, false, true>; \
+			return go(rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, \
+					FEED, false, Io32, false, true>); \
 	} \
-	if (!seeded_kernel_usable((const void *)kern, lds_bytes)) \
-		return false; \
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st, kp, sa, \
-		(const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy, j.n / kVec); \
-	return true; }
+	if constexpr (kTails && (FEED == Feed::PhaseArray_ConstXY \
+				|| dt_always(N - kSeedStages))) \
+		break; \
+	else \
+		return go(rotator_seeded<CORDIC_INST_CONTAINER, N, kSeedStages, FEED>); }
 	CORDIC_ROT_STAGES(X)
 #undef X
 #endif
-	default: {
-		if (nlive < kSeedStages || nlive > kDynStages)
-			return false;
-		auto kern = rotator_seeded<CORDIC_INST_CONTAINER, kDynStages,
-				kSeedStages, FEED, true>;
-		if (!seeded_kernel_usable((const void *)kern, lds_bytes))
-			return false;
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(kSeedBlock), lds_bytes, st,
-			kp, sa, (const u32x4 *)j.phase, (i32x4 *)j.ox, (i32x4 *)j.oy,
-			j.n / kVec);
-		return true;
+	default:
+		break;
 	}
-	}
+	if (nlive < kSeedStages || nlive > kDynStages)
+		return false;
+	return go(rotator_seeded<CORDIC_INST_CONTAINER, kDynStages, kSeedStages, FEED, true>);
 }
 } // namespace
 

@@ -215,17 +215,22 @@ def add_valu(roof, samples_per_s, pm, power, prof, workload=None):
         if cf and roof["frac"] >= 0.95 * cf:
             roof["limiter"] = "hbm: at the same-run copy ceiling (%.3f of %.3f)" % (
                 roof["frac"], cf)
-        elif vb["frac"] >= 0.75:
-            roof["limiter"] = "valu: this instruction mix issues %.0f %% of the time" % (
-                100 * vb["frac"])
         elif cap:
-            roof["limiter"] = ("power: socket at its limit (%.0f W), clock %.2f GHz; "
+            thr = power.get("throttle") or {}
+            held = ("PPT limiter active %.0f %% of the sustained window"
+                    % (100 * thr["ppt_frac"])) if "ppt_frac" in thr else "socket at its limit"
+            roof["limiter"] = ("power: %s (%.0f W of %.0f), clock %.2f GHz; "
                                "neither HBM (%.2f) nor VALU issue (%.2f) saturated"
-                               % (power["sustained"]["socket_w_median"],
+                               % (held, power["sustained"]["socket_w_median"],
+                                  power.get("limit_w") or 0,
                                   vb["sclk_ghz"], roof["frac"], vb["frac"]))
+        elif vb["frac"] >= 0.70:
+            roof["limiter"] = ("valu: this instruction mix occupies the issue port "
+                               "%.0f %% of the time"
+                               % (100 * vb["frac"]))
         else:
-            roof["limiter"] = "undetermined (hbm %.2f, valu %.2f)" % (
-                roof["frac"], vb["frac"])
+            roof["limiter"] = ("latency / LDS: HBM %.2f, VALU issue %.2f, socket "
+                               "below its limit" % (roof["frac"], vb["frac"]))
         roof["bound_note"] = (
             "hbm frac %.3f vs valu_fraction %.3f (this instruction mix at the "
             "clock the power limit allowed) / valu_issue_fraction %.3f (the "

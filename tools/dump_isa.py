@@ -27,16 +27,10 @@ KERNELS = [
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true>",
      "cfg2 headline: seeded p2r, WW 35, 16 stages (5 after the seed: one group of "
      "direction tails on every row)"),
-    ("rotator_seeded_lj29_16_notails", "cordic_inst_seed_lj29.o",
-     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, false>",
-     "cfg2 with the phase recurrence behind the seeds (CORDIC_FLAG_NO_TAILS)"),
     ("rotator_seeded_lj29_24", "cordic_inst_seed_lj29.o",
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true>",
      "cfg4: seeded p2r, 24 stages (13 after the seed: direction tails in groups of "
      "6 and 7 on coherent rows, phase recurrence on the others)"),
-    ("rotator_seeded_lj29_24_notails", "cordic_inst_seed_lj29.o",
-     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, false>",
-     "cfg4 with the phase recurrence only (CORDIC_FLAG_NO_TAILS)"),
     ("rotator_seeded_lj29_16_nco", "cordic_inst_seed_lj29.o",
      r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)2, false, cordic_amd::dev::Io32, false, true>",
      "cfg5: fused NCO + seeded p2r with the group of direction tails, store only"),
@@ -50,9 +44,6 @@ KERNELS = [
      r"rotator_xydir<29, 16>",
      "p2rxy through a plan (round 4): per-sample x, y and phase, directions of "
      "stages 2-16 looked up in three groups of five"),
-    ("topolar_unrolled_narrow_20", "cordic_inst_pol_narrow.o",
-     r"topolar_unrolled<cordic_amd::dev::Narrow32, 20, 0, false, cordic_amd::dev::Io32, false>",
-     "cfg3 r2p, round-1 form (8 instructions per micro-rotation)"),
     ("topolar_lj_20", "cordic_inst_pol_lj.o",
      r"topolar_lj<20, false, cordic_amd::dev::Io32, false, true>",
      "cfg3 r2p, left-justified form (7 instructions per micro-rotation)"),

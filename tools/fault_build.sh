@@ -8,23 +8,19 @@
 # round-3 one (exchange complete inside ncclGroupEnd) could not.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}	# as cordic_amd/csrc/Makefile
-ARCH=${ARCH:-gfx950}
 cd "$ROOT/cordic_amd/csrc"
-# the product build's objects are reused; a snapshot (the GPU boxes get the
-# libraries without build/) or `make clean` leaves none: nothing to do here
-# then -- the test that wants lib_fault.so skips when it is missing
-ls build/*.o > /dev/null 2>&1 || { echo "no product objects: lib_fault.so not rebuilt"; exit 0; }
+# only cordic_group.cpp differs, and it sits on the public C ABI (plus one
+# exported probe launcher): the fault library is that ONE object with the
+# product library as its dependency ($ORIGIN), ~60 KB instead of a second copy
+# of every kernel.  dlsym() on its handle finds cordic_group_* here first and
+# everything else in libcordic_amd.so.
+[ -f "$ROOT/cordic_amd/libcordic_amd.so" ] || { echo "no product library: lib_fault.so not rebuilt"; exit 0; }
 mkdir -p build_fault
-find build_fault -type l -delete	# objects of an earlier source layout
-# every other object is identical: reuse the product build's
-for o in build/*.o; do
-	b=$(basename $o)
-	[ "$b" = cordic_group.o ] || ln -sf ../$o build_fault/$b
-done
+rm -f build_fault/*.o
 g++ -O3 -std=c++17 -fPIC -fwrapv -Wall -Wno-unused-function -I"$ROOT/include" -I. \
 	-ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include \
 	-DCORDIC_FAULT_SKIP_JOB_ORDER -c cordic_group.cpp -o build_fault/cordic_group.o
-"$HIPCC" --offload-arch="$ARCH" -shared -fPIC -o "$ROOT/cordic_amd/lib_fault.so" \
-	build_fault/*.o -ldl
+g++ -shared -fPIC -o "$ROOT/cordic_amd/lib_fault.so" build_fault/cordic_group.o \
+	-L"$ROOT/cordic_amd" -l:libcordic_amd.so -Wl,-rpath,'$ORIGIN' \
+	-L/opt/rocm/lib -lamdhip64 -ldl -lpthread
 echo "built cordic_amd/lib_fault.so"

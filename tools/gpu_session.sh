@@ -13,6 +13,7 @@
 #   sweep      every bench.py workload x {ramp, random} + the default line
 #   states     alternate copy probe / bench while logging clocks and power
 #   ab:<flags> build a second library with HIPFLAGS_EXTRA=<flags> and A/B it
+#   abrun      A/B against a prebuilt cordic_amd/lib_ab.so  [AB_WORKLOADS=...]
 #   power      rocm-smi power / sclk sampled WHILE each workload runs 6000 steps
 #              [POWER_WORKLOADS="cfg5 cfg2 ..."]
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -66,6 +67,15 @@ d=json.loads(open('gpurun_out/power_$w.json').readline()); print('   value', rou
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$lib', round(d['value']), round(d['roofline']['frac'],3))" >> $log
 		done; done ;;
+	abrun)	# the same A/B against a cordic_amd/lib_ab.so built beforehand (here:
+		# make -C cordic_amd/csrc BUILD=build_ab OUT=.../lib_ab.so HIPFLAGS_EXTRA=...;
+		# take lib_ab.so out of .gpurunignore for the call)  [AB_WORKLOADS=...]
+		for w in ${AB_WORKLOADS:-cfg3}; do for r in 1 2 3; do for lib in libcordic_amd.so lib_ab.so; do
+			CORDIC_AMD_LIB=$PWD/cordic_amd/$lib python bench.py --workload $w ${BENCH_ARGS} --no-cpu-baseline --no-other-paths --no-pmc --no-power 2>/dev/null \
+			| python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$w $lib', round(d['value']), round(d['roofline']['frac'],3), d['bit_exact_vs_oracle'])" >> $log
+		done; done; done ;;
 	sweep)	# one bench.py line per workload x {ramp, random}; the ramp lines
 		# carry this run's SQ_INSTS_VALU pass (instr/sample); every line is
 		# stamped with the code state (build.kernel_sources_sha256)

@@ -21,7 +21,8 @@ except (OSError, ValueError):
     db = {}
 MAIN = {"cfg2": "rotator_seeded", "cfg4": "rotator_seeded",
         "cfg5": "rotator_seeded", "cfg1": "rotator_seeded",
-        "cfg3": None, "p2rxy": "rotator_unrolled", "quadtbl": "quad_lookup",
+        "cfg3": None, "p2rxy": "rotator_xydir", "ddc": "rotator_xydir",
+        "quadtbl": "quad_lookup",
         "nat32": "rotator_seeded", "nat24": "rotator_seeded",
         "nat16": "rotator_seeded", "natr2p24": "topolar_lj"}
 for w in sorted(os.listdir(os.path.join(ROOT, rnd))):
