@@ -47,32 +47,29 @@ def fmt(v, nd=0):
 
 def block():
     rows = ["| workload | kernel | B/sample | instr/sample | ramp: Gsample/s | "
-            "HBM frac | valu_fraction | valu_issue_fraction | bound | "
-            "random: Gsample/s | HBM frac |",
-            "|---|---|---|---|---|---|---|---|---|---|---|"]
+            "HBM frac | valu_fraction | valu_issue_fraction | bound | limiter | "
+            "random: Gsample/s | HBM frac | full recurrence: Gsample/s |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for w, e in lines().items():
         a, b = e["ramp"], e["random"]
         ra = a["roofline"]
         valu = ra.get("valu") or {}
         full = a.get("full_recurrence_kernel")
-        rows.append("| %s | `%s` | %d | %s | %s | %.3f | %s | %s | %s | %s | %s |" % (
+        rows.append("| %s | `%s` | %d | %s | %s | %.3f | %s | %s | %s | %s | %s | %s | %s |" % (
             a["config"]["workload"].split(":")[0], a["config"]["kernel"],
             ra["bytes_per_sample"], fmt(valu.get("instr_per_sample"), 1),
             fmt(a["value"] / 1e3), ra["frac"], fmt(ra.get("valu_fraction"), 2),
             fmt(ra.get("valu_issue_fraction"), 2), ra.get("bound", "hbm"),
+            (ra.get("limiter") or "—").split(":")[0].split(" (")[0],
             fmt(b["value"] / 1e3) if b else "—",
-            ("%.3f" % b["roofline"]["frac"]) if b else "—"))
-        if full:
-            rows.append("| %s, full recurrence | `rotator_unrolled` | %d | — | %s "
-                        "| %.3f | — | — | valu | — | — |" % (
-                            w, ra["bytes_per_sample"],
-                            fmt(full["value_per_gpu"] / 1e3), full["hbm_frac"]))
+            ("%.3f" % b["roofline"]["frac"]) if b else "—",
+            fmt(full["value_per_gpu"] / 1e3) if full else "—"))
     d = load("default.json")
     tail = []
     if d:
         cb = d.get("cpu_baseline") or {}
         tail.append("")
-        tail.append("Default line of the same sweep (`python bench.py`): %s Gsample/s, "
+        tail.append("Default line at the END of the same sweep (`python bench.py`): %s Gsample/s, "
                     "%.3f of the HBM peak (same-run copy %s), `digest_check` over %d "
                     "samples equal: %s; CPU beside it: %s Msample/s on %s threads "
                     "(%s on one)." % (
@@ -82,6 +79,13 @@ def block():
                         (d.get("digest_check") or {}).get("equal"),
                         fmt(cb.get("value")), cb.get("cores"),
                         fmt(cb.get("value_1thread"), 1)))
+        o = load("default_driver_order.json")
+        if o:
+            tail.append("The same command as the session's FIRST bench run (the driver's order, "
+                        "`default_driver_order.json`): %s Gsample/s, %.3f (same-run copy %s) — the "
+                        "headline follows the copy state of the box, which moved during the "
+                        "session (§3)." % (fmt(o["value"] / 1e3), o["roofline"]["frac"],
+                                           fmt(o["roofline"].get("copy_frac"), 3)))
         b = d.get("build") or {}
         tail.append("Code state: `kernel_sources_sha256` %s, commit %s." % (
             (b.get("kernel_sources_sha256") or "?")[:16], (b.get("git_head") or "?")[:10]))
