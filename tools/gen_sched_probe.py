@@ -91,6 +91,15 @@ def body(variant):
         elif variant == "onlymad":          # the three multiply-adds alone
             for s in range(NS):
                 out += [t for t, kind in per[s] if kind == "m"]
+        elif variant in ONLY:               # one opcode alone (energy probe)
+            i = ONLY[variant]
+            for s in range(NS):
+                t, kind = per[s][i]
+                # result into the scratch register so that the chains stay short
+                out += [t] * 4
+        elif variant == "onlyalign":        # v_alignbit_b32 (the direction-bit collect)
+            for s in range(NS):
+                out += ["v_alignbit_b32 v%d, v%d, v%d, 31" % (R(s, "m"), R(s, "m"), R(s, "yh"))] * 4
         elif variant == "nop_all":          # a wait state behind EVERY instruction
             for s in range(NS):
                 for t, _ in per[s]:
@@ -187,6 +196,8 @@ def kernel(variant):
 """ % (variant, text, ", ".join(clob))
 
 
+# one opcode alone, four times per sample and stage (index into instrs())
+ONLY = {"onlybitop3": 0, "onlyxor": 1, "onlyashr": 2, "onlymadv": 4, "onlymads": 6}
 # sample-major order + (yield instruction, where(i, kind, count of 32-bit so far))
 RULES = {
     "nop_32_s1": ("s_nop 1", lambda i, k, n: k != "m"),
@@ -201,11 +212,12 @@ RULES = {
 }
 VARIANTS = ["sample_major", "sample_major_nop", "instr_major", "mads_last", "only32",
             "onlymad", "nop_all", "instr_major_nop", "nop_mads", "nop_32", "alternate",
-            "instr_major_nop32"] + list(RULES)
-PER_STAGE = {"only32": 4, "onlymad": 3}
+            "instr_major_nop32"] + list(RULES) + list(ONLY) + ["onlyalign"]
+PER_STAGE = {"only32": 4, "onlymad": 3, "onlyalign": 4}
+PER_STAGE.update({k: 4 for k in ONLY})
 
 MAIN = r"""
-int main()
+int main(int argc, char **argv)
 {
 	hipDeviceProp_t p;
 	CHECK(hipGetDeviceProperties(&p, 0));
@@ -221,6 +233,34 @@ int main()
 	CHECK(hipEventCreate(&e1));
 	struct V { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t); int per_stage; };
 	const V vs[] = { VLIST };
+	if (argc >= 4 && !strcmp(argv[1], "--sustain")) {
+		// ./sched_probe --sustain <variant> <seconds>: keep ONE variant running from
+		// 8 waves a SIMD (the caller samples the socket power meanwhile) and print
+		// the rate it held: wave-instructions per second per SIMD
+		const double secs = atof(argv[3]);
+		for (const V &v : vs) {
+			if (strcmp(v.name, argv[2]))
+				continue;
+			const int blocks = cus * 8;
+			const double per_launch = (double)NSTAGES * NSAMP * v.per_stage * NITERS * 8;
+			auto t0 = std::chrono::steady_clock::now();
+			long launches = 0;
+			double el = 0;
+			do {
+				for (int r = 0; r < 50; r++)
+					hipLaunchKernelGGL(v.k, dim3(blocks), dim3(256), 0, 0, out, 0x40000000u, 0x80000000u);
+				CHECK(hipDeviceSynchronize());
+				launches += 50;
+				el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			} while (el < secs);
+			printf("%s: %.2f s, %.4g wave-instructions/s/SIMD, %.4g lane-instructions/s (chip)\n",
+				v.name, el, launches * per_launch / el,
+				launches * per_launch / el * 64 * 4 * cus);
+			return 0;
+		}
+		printf("no variant %s\n", argv[2]);
+		return 1;
+	}
 		printf("%-18s %6s %10s %12s %16s\n", "variant", "waves", "ms", "checksum",
 		"cyc/instr @2.4GHz");
 	for (int wps = 8; wps >= 1; wps /= 2) {
@@ -256,7 +296,7 @@ int main()
 def main():
     src = ["// sched_probe.hip -- GENERATED by tools/gen_sched_probe.py (see there)",
            "#include <hip/hip_runtime.h>", "#include <cstdio>", "#include <cstdint>",
-           "#include <vector>",
+           "#include <vector>", "#include <chrono>", "#include <cstring>", "#include <cstdlib>",
            "#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \\",
            '\tprintf("HIP error %s at %d\\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)',
            "#define NSTAGES %d" % len(STAGES), "#define NSAMP %d" % NS,
