@@ -100,6 +100,46 @@ def body(variant):
         elif variant == "onlyalign":        # v_alignbit_b32 (the direction-bit collect)
             for s in range(NS):
                 out += ["v_alignbit_b32 v%d, v%d, v%d, 31" % (R(s, "m"), R(s, "m"), R(s, "yh"))] * 4
+        elif variant in ("vop2_stage", "vop2_stage_im", "xad_stage", "xad_stage_im"):
+            # the same micro-rotation in a 32-bit container (x = xh, y = yh, p = pl)
+            # without multiply-adds: conditional negate as (v ^ m) - m with m the
+            # sign mask of y -- 12 full-rate VOP2, or 10 with v_xad_u32
+            # ((a ^ b) + c, a half-rate VOP3); _im = instruction-major over the samples
+            def st(s):
+                x, y, pp = R(s, "xh"), R(s, "yh"), R(s, "pl")
+                m, nm, sy, sx = R(s, "m"), R(s, "mn"), R(s, "sy"), R(s, "sx")
+                sa = 20 + (k % 8)
+                if variant.startswith("vop2"):
+                    return ["v_ashrrev_i32_e32 v%d, 31, v%d" % (m, y),
+                            "v_ashrrev_i32_e32 v%d, %d, v%d" % (sy, k, y),
+                            "v_ashrrev_i32_e32 v%d, %d, v%d" % (sx, k, x),
+                            "v_xor_b32_e32 v%d, v%d, v%d" % (sy, sy, m),
+                            "v_sub_u32_e32 v%d, v%d, v%d" % (sy, sy, m),
+                            "v_add_u32_e32 v%d, v%d, v%d" % (x, x, sy),
+                            "v_xor_b32_e32 v%d, v%d, v%d" % (sx, sx, m),
+                            "v_sub_u32_e32 v%d, v%d, v%d" % (sx, sx, m),
+                            "v_sub_u32_e32 v%d, v%d, v%d" % (y, y, sx),
+                            "v_xor_b32_e32 v%d, s%d, v%d" % (nm, sa, m),
+                            "v_sub_u32_e32 v%d, v%d, v%d" % (nm, nm, m),
+                            "v_add_u32_e32 v%d, v%d, v%d" % (pp, pp, nm)]
+                return ["v_ashrrev_i32_e32 v%d, 31, v%d" % (m, y),
+                        "v_ashrrev_i32_e32 v%d, %d, v%d" % (sy, k, y),
+                        "v_ashrrev_i32_e32 v%d, %d, v%d" % (sx, k, x),
+                        "v_not_b32_e32 v%d, v%d" % (nm, m),
+                        "v_xad_u32 v%d, v%d, v%d, v%d" % (x, sy, m, x),
+                        "v_sub_u32_e32 v%d, v%d, v%d" % (x, x, m),
+                        "v_xad_u32 v%d, v%d, v%d, v%d" % (y, sx, nm, y),
+                        "v_sub_u32_e32 v%d, v%d, v%d" % (y, y, nm),
+                        "v_xad_u32 v%d, s%d, v%d, v%d" % (pp, sa, m, pp),
+                        "v_sub_u32_e32 v%d, v%d, v%d" % (pp, pp, m)]
+            blocks = [st(s) for s in range(NS)]
+            if variant.endswith("_im"):
+                for i in range(len(blocks[0])):
+                    for b in blocks:
+                        out.append(b[i])
+            else:
+                for b in blocks:
+                    out += b
         elif variant == "nop_all":          # a wait state behind EVERY instruction
             for s in range(NS):
                 for t, _ in per[s]:
@@ -212,9 +252,10 @@ RULES = {
 }
 VARIANTS = ["sample_major", "sample_major_nop", "instr_major", "mads_last", "only32",
             "onlymad", "nop_all", "instr_major_nop", "nop_mads", "nop_32", "alternate",
-            "instr_major_nop32"] + list(RULES) + list(ONLY) + ["onlyalign"]
+            "instr_major_nop32"] + list(RULES) + list(ONLY) + ["onlyalign", "vop2_stage", "vop2_stage_im", "xad_stage", "xad_stage_im"]
 PER_STAGE = {"only32": 4, "onlymad": 3, "onlyalign": 4}
 PER_STAGE.update({k: 4 for k in ONLY})
+PER_STAGE.update({"vop2_stage": 12, "vop2_stage_im": 12, "xad_stage": 10, "xad_stage_im": 10})
 
 MAIN = r"""
 int main(int argc, char **argv)
