@@ -663,9 +663,11 @@ def run_group(args, w, launch):
         # (cordic_group placement: include/cordic_amd.h)
         roof["placement"] = dict(
             grp_placement,
-            what="arrays allocated +2 spare, arithmetic-free probes of the "
-                 "job's traffic over the role assignments, best kept "
-                 "(--no-placement: as hipMalloc hands them out)")
+            what="arrays allocated +2 spare (more, up to +24, while no pair "
+                 "of written arrays is fast: allocations come in classes and "
+                 "two of one class written together are slow), arithmetic-free "
+                 "probes of the job's traffic over the role assignments, best "
+                 "kept (--no-placement: as hipMalloc hands them out)")
         if probes and probes[0]:
             # the plain-copy ceiling of THIS run on THESE arrays: best of the
             # probes before and after the timed region

@@ -79,14 +79,27 @@ struct Shard {
 
 constexpr uint64_t kPlaceMinWords = (uint64_t)1 << 24;	// arrays of 64 MiB and up
 constexpr int kPlaceSpare = 2;		// candidates beyond the need, always
-constexpr int kPlaceSpareMax = 6;	// ... and at most, while no good pair shows
-// a pair of written arrays is good enough at 0.88 of the 8 TB/s peak (single
-// arrays sweep at 0.88-0.89, good pairs reach 0.90)
-constexpr double kPlaceGoodBytesPerMs = 0.88 * 8e9;
+// Allocations come in CLASSES (profiles/r05/pair_matrix.txt: 40 arrays of
+// 4 GiB, every pair): two arrays of the same class written together run at
+// 0.79-0.82 of the 8 TB/s peak, two of different classes at 0.95-0.97, nothing
+// in between except for arrays that straddle two classes; consecutive
+// allocations share a class in runs of 2-16.  A box whose first five
+// allocations are one run has no fast pair among them (4 of 8 boxes one day:
+// 0.77 of the peak for cfg2 instead of 0.85).  So: while no pair is fast, take
+// more candidates -- up to kPlaceSpareMax, each tried against a few of the
+// ones at hand (one of another class is fast with all of them).
+constexpr int kPlaceSpareMax = 24;
+constexpr int kPlaceTryAgainst = 3;
+// ... for arrays from 512 MiB: a probe over a smaller one is a few tens of
+// microseconds and says nothing about classes -- the round-4 limits apply
+constexpr uint64_t kPlaceWideWords = (uint64_t)1 << 27;
+constexpr int kPlaceSpareMaxSmall = 6, kPlaceReadExtraSmall = 6;
+// a pair of written arrays is fast from 0.93 of the peak (slow ones: <= 0.90)
+constexpr double kPlaceGoodBytesPerMs = 0.93 * 8e9;
 // the 1R2W pattern of a constant-vector rotator: 0.845 is what a well placed
 // triple reaches (0.85-0.86 at best)
 constexpr double kPlaceGoodMixBytesPerMs = 0.845 * 8e9;
-constexpr int kPlaceReadExtra = 6;
+constexpr int kPlaceReadExtra = 10;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
 struct Rccl {
@@ -348,7 +361,9 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 			for (size_t j = i + 1; j < pool.size() && !failed; j++)
 				try_pair(i, j);
 		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
-		while (!failed && best > good && pool.size() < need + (size_t)kPlaceSpareMax) {
+		const size_t spare_max = (size_t)(words >= kPlaceWideWords ? kPlaceSpareMax
+									   : kPlaceSpareMaxSmall);
+		while (!failed && best > good && pool.size() < need + spare_max) {
 			void *p = nullptr;
 			if (!room_for_spare())
 				break;
@@ -358,8 +373,13 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 			}
 			pool.push_back(p);
 			ps.candidates++;
-			for (size_t i = 0; i + 1 < pool.size() && !failed; i++)
-				try_pair(i, pool.size() - 1);
+			// against a few of the others, spread over the pool (the early
+			// ones are the likeliest to share a run among themselves)
+			const size_t last = pool.size() - 1;
+			const size_t step = last > (size_t)kPlaceTryAgainst
+				? last / (size_t)kPlaceTryAgainst : 1;
+			for (size_t i = 0; i < last && !failed && best > good; i += step)
+				try_pair(i, last);
 		}
 		if (failed) {
 			(void)hipGetLastError();
@@ -425,7 +445,8 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		// one at a time (a 4 GiB hipMalloc + three launches each), keeping
 		// only a better one.
 		const float good_mix = (float)((double)words * 12.0 / kPlaceGoodMixBytesPerMs);
-		for (int extra = 0; extra < kPlaceReadExtra && best > good_mix
+		const int read_extra = words >= kPlaceWideWords ? kPlaceReadExtra : kPlaceReadExtraSmall;
+		for (int extra = 0; extra < read_extra && best > good_mix
 				&& room_for_spare(); extra++) {
 			void *cand = nullptr;
 			if (!ok(hipMalloc(&cand, bytes))) {

@@ -222,7 +222,8 @@ def test_placement_of_the_arrays():
             # two spare candidates at least; up to four more while no good
             # written pair shows, then up to six more in the read role while
             # the job's full pattern stays under 0.845 of the peak (arrays
-            # this small never reach either mark)
+            # this small never reach either mark; from 512 MiB the search
+            # for a pair of different classes goes on for up to 24 + 10)
             k = info["candidates"]
             assert 5 <= k <= 15 and info["probes"] >= 13
             assert 0 < info["written_pair_best_ms"] <= info["written_pair_worst_ms"]
@@ -234,11 +235,12 @@ def test_placement_of_the_arrays():
     rx, ry = oracle_p2r(ocfg, 0, n_total)
     want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
     assert digests == [want, want]
-    # store-only job: two written arrays out of four candidates, every pair
+    # store-only job: two written arrays out of four candidates, every pair;
+    # each further candidate against a few of those at hand
     g = ca.Group(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16), devices=[0])
     g.nco(n_total, 0, 0x01234567, AMP, 0)
     k = g.placement(0)["candidates"]
-    assert 4 <= k <= 8 and g.placement(0)["probes"] == k * (k - 1) // 2
+    assert 4 <= k <= 8 and 6 + (k - 4) <= g.placement(0)["probes"] <= k * (k - 1) // 2
     # a later job that needs an input leaves the results alone: no probing
     before = g.read(0, g.OUT0, 0, 1024).copy()
     g.reserve(n_total, 1)

@@ -47,6 +47,17 @@ def pairs(idx, label):
     return res
 
 
+if os.environ.get("MANY_MATRIX", "1") == "1":
+    # the whole pair matrix (0R2W ms x 100), one launch pair per entry
+    print("# 0R2W ms x 100 for every pair (row i, column j > i)")
+    for i in range(N):
+        row = []
+        for j in range(N):
+            if j <= i:
+                row.append("   ")
+            else:
+                row.append("%3d" % round(100 * hbm_probe(None, None, P[i], P[j], n, 0, 2, 3, 2)))
+        print("m %2d %s" % (i, " ".join(row)))
 first = pairs(range(5), "the first 5 arrays")
 order = sorted(range(N), key=lambda i: w1[i])
 fast = pairs(order[:8], "the 8 fastest writers")
