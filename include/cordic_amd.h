@@ -711,24 +711,28 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
  * forwarding set: a job's kernels wait (in stream order, on the device) until
  * the previous job's pieces have left out0 / out1. */
 /* Placement of the shards' arrays.  What HBM delivers to a job's streams
- * depends on which allocations they run over (a property of the combination of
- * arrays, stable for their lifetime, not visible in the addresses: 0.75-0.82 of
- * the 8 TB/s peak for one and the same 1R2W stream, profiles/r02/
- * hbm_placement.txt).  When a group allocates arrays of 64 MiB or more it
- * therefore allocates two more than it needs, times an arithmetic-free twin of
- * the job's traffic over the candidate role assignments (tens of
- * milliseconds, once per allocation), keeps the fastest and frees the rest.
- * While no pair of written arrays reaches 0.88 of the peak it tries up to four
- * more candidates, and while a 1R2W job's full pattern stays under 0.845 up to
- * six more in the READ role (the array that is read decides most), one at a
- * time; spares are taken only while as much memory again stays free.
+ * depends on which allocations they run over: allocations come in CLASSES
+ * (profiles/r05/pair_matrix.txt) -- two arrays of one class written together
+ * run at 0.73-0.81 of the 8 TB/s peak, two of different classes at 0.93-0.95,
+ * single arrays all alike; consecutive hipMallocs share a class in runs of
+ * 2-16, nothing in the addresses shows it, and it holds for the arrays'
+ * lifetime.  When a group allocates arrays of 64 MiB or more it therefore
+ * allocates two more than it needs, times an arithmetic-free twin of the
+ * job's traffic over the candidate role assignments (tens of milliseconds,
+ * once per allocation), keeps the fastest and frees the rest.  While no pair
+ * of written arrays reaches 0.93 of the peak it takes more candidates, each
+ * tried against three of those at hand -- up to 24 for arrays of 512 MiB and
+ * up (a box whose first allocations are one long run: up to a second, once),
+ * 4 below -- and while a 1R2W job's full pattern stays under 0.845 up to ten
+ * (six) more in the READ role, one at a time; spares are taken only while as
+ * much memory again stays free.
  * On by default; cordic_group_set_placement(grp, 0) before the first
  * reserve / job call, or CORDIC_GROUP_PLACEMENT=0 in the environment, takes
  * the arrays as hipMalloc hands them out.  cordic_group_placement reports
  * what the last allocation of a shard saw: candidate arrays, probes run, the
- * times of the best and the worst pair of written arrays (0R2W over every
- * pair) and, with those chosen, of the best and the worst choice of the read
- * arrays (the job's full pattern); 0 candidates: not tuned. */
+ * times of the best and the worst pair of written arrays (0R2W) and, with
+ * those chosen, of the best and the worst choice of the read arrays (the
+ * job's full pattern); 0 candidates: not tuned. */
 int	cordic_group_set_placement(cordic_group *grp, int enable);
 /* The same for callers of the stateless entry points: n_read (0..2) +
  * n_write (1..2) arrays of `bytes` bytes each on the current device, placed as

@@ -21,3 +21,10 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_
 # (round 5) the executed 32- / 64-bit integer split: the 64-bit ones are the half-rate v_mad_i64_i32
 rocprofv3 --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/pmc_int -- $BENCH3 > $OUT/pmc_int.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT $TAG
+# the summaries are what travels back (gpurun merges at most 64 MiB): keep
+# summary.json, kernel_stats.csv and the logs, drop the raw per-dispatch files
+cp $(ls $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats.csv 2>/dev/null
+if [ -s $OUT/summary.json ]; then
+	find $OUT -name '*counter_collection.csv' -delete
+	find $OUT -name '*kernel_trace.csv' -delete
+fi
