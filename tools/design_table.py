@@ -82,9 +82,8 @@ def block():
         o = load("default_driver_order.json")
         if o:
             tail.append("The same command as the session's FIRST bench run (the driver's order, "
-                        "`default_driver_order.json`): %s Gsample/s, %.3f (same-run copy %s) — the "
-                        "headline follows the copy state of the box, which moved during the "
-                        "session (§3)." % (fmt(o["value"] / 1e3), o["roofline"]["frac"],
+                        "`default_driver_order.json`): %s Gsample/s, %.3f (same-run copy %s): each "
+                        "run places its arrays anew (§3)." % (fmt(o["value"] / 1e3), o["roofline"]["frac"],
                                            fmt(o["roofline"].get("copy_frac"), 3)))
         b = d.get("build") or {}
         tail.append("Code state: `kernel_sources_sha256` %s, commit %s." % (
