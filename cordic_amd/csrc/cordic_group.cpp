@@ -94,6 +94,7 @@ constexpr int kPlaceTryAgainst = 3;
 // microseconds and says nothing about classes -- the round-4 limits apply
 constexpr uint64_t kPlaceWideWords = (uint64_t)1 << 27;
 constexpr int kPlaceSpareMaxSmall = 6, kPlaceReadExtraSmall = 6;
+constexpr uint64_t kPlaceSpareBytes = (uint64_t)96 << 30;	// of candidates at most
 // a pair of written arrays is fast from 0.93 of the peak (slow ones: <= 0.90)
 constexpr double kPlaceGoodBytesPerMs = 0.93 * 8e9;
 // the 1R2W pattern of a constant-vector rotator: 0.845 is what a well placed
@@ -361,8 +362,15 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 			for (size_t j = i + 1; j < pool.size() && !failed; j++)
 				try_pair(i, j);
 		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
-		const size_t spare_max = (size_t)(words >= kPlaceWideWords ? kPlaceSpareMax
-									   : kPlaceSpareMaxSmall);
+		// (and bounded in bytes: a fresh hipMalloc costs 0.2-1 s per 4 GiB,
+		// and arrays of 16 GiB and more span several runs anyway)
+		size_t spare_max = (size_t)kPlaceSpareMaxSmall;
+		if (words >= kPlaceWideWords) {
+			const size_t by_bytes = (size_t)(kPlaceSpareBytes / bytes);
+			spare_max = by_bytes > (size_t)kPlaceSpareMax ? (size_t)kPlaceSpareMax
+				: by_bytes < (size_t)kPlaceSpareMaxSmall ? (size_t)kPlaceSpareMaxSmall
+				: by_bytes;
+		}
 		while (!failed && best > good && pool.size() < need + spare_max) {
 			void *p = nullptr;
 			if (!room_for_spare())
@@ -445,7 +453,8 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		// one at a time (a 4 GiB hipMalloc + three launches each), keeping
 		// only a better one.
 		const float good_mix = (float)((double)words * 12.0 / kPlaceGoodMixBytesPerMs);
-		const int read_extra = words >= kPlaceWideWords ? kPlaceReadExtra : kPlaceReadExtraSmall;
+		const int read_extra = words >= kPlaceWideWords && bytes <= ((size_t)4 << 30)
+			? kPlaceReadExtra : kPlaceReadExtraSmall;
 		for (int extra = 0; extra < read_extra && best > good_mix
 				&& room_for_spare(); extra++) {
 			void *cand = nullptr;
