@@ -1,7 +1,8 @@
 """place_time.py -- how long a group's placement takes (3 x 4 GiB, twice more), and what a
 fresh hipMalloc / hipFree of 4 GiB costs (0.2-1 s when the memory is new)."""
 import sys, time, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import cordic_amd as ca
 torch.cuda.init()
