@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void for_each_queued_tile_prefetched(uint32_t *queue,
 
 
 template <typename C, int NLIVE, int M, Feed FEED, bool DYN = false,
-		typename IO = Io32, bool UG = false, bool DT = false>
+		typename IO = Io32, bool UG = false, bool DT = false, bool DESC = false>
 __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		SeedArgs sa, const typename IO::uvec *__restrict__ phin,
 		typename IO::ivec *__restrict__ ox,
@@ -1613,14 +1613,16 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		apply_unit_gain<UG>(ry, kp);
 	};
 
-	// (A/B, profiles/r05/ab_desc_loop.txt: this loop in the STATIC instances
-	// too would let job sets run them -- +8 % / +22 % on batches of 16- / 24-
-	// stage cores -- and costs single jobs 6-7 % where the VALU binds (cfg4
-	// 385 -> 362, cfg5 582 -> 541 Gsample/s): not adopted)
+	// (A/B, profiles/r05/ab_desc_loop.txt: this loop in EVERY static instance
+	// would let job sets run them -- +8 % / +22 % on batches of 16- / 24-stage
+	// cores -- and costs single jobs 6-7 % where the VALU binds (cfg4 385 ->
+	// 362, cfg5 582 -> 541 Gsample/s).  So single jobs keep their instances,
+	// and the stage counts BASELINE names (16, 24) get a second static
+	// instance, DESC, that job sets run: cordic_internal.h desc_static.)
 #ifdef CORDIC_DESC_LOOP_ALL
 	constexpr bool kDescLoop = true;	// A/B: every instance walks descriptors
 #else
-	constexpr bool kDescLoop = DYN;
+	constexpr bool kDescLoop = DYN || DESC;
 #endif
 	if constexpr (kDescLoop) {
 	if (sa.queue != nullptr) {

@@ -3,4 +3,6 @@
 #define CORDIC_INST_NAME launch_seed_lj29
 #define CORDIC_INST_CONTAINER dev::WideLJ<29>
 #define CORDIC_INST_NGEN 0
+// job sets of the 16- / 24-stage cores on their own static instances
+#define CORDIC_INST_DESC_STATIC 1
 #include "cordic_inst_body.h"

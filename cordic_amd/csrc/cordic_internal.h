@@ -132,6 +132,17 @@ constexpr bool dt_always(int r)
 	const int n = dt_levels(r);
 	return n > 0 && dt_size(r, n - 1) <= 5 && dt_rest_stages(r) == 0;
 }
+// Job sets (tile descriptors) run the dynamic-exit instance -- except on the
+// stage counts BASELINE names, for which the left-justified WW 35 unit
+// carries a static instance WITH the descriptor loop and the direction tails:
+// 16 stages (one always-lookup group: any feed), 24 stages on phase arrays
+// (an NCO bank's jobs each have their own increment: no per-launch choice of
+// the tails).  dtn = the tail groups the plan carries.
+constexpr bool desc_static(int nlive, int dtn, bool nco)
+{
+	return dtn >= 1 && dtn == dt_levels(nlive - CORDIC_SEED_STAGES)
+		&& (nlive == 16 || (nlive == 24 && !nco));
+}
 constexpr int dt_rest(int r)			// stages left to the phase chain
 {
 	return dt_levels(r) == 0 ? r : r - dt_covered(r);

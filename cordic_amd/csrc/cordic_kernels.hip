@@ -1033,8 +1033,16 @@ int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j
 		if (cfg.flags & CORDIC_FLAG_NO_TAILS)
 			sa.dt.n = 0;
 #else
-		constexpr int kJobImageKey = 4;	// (its own image slot: no tail tables in it)
-		sa.dt.n = 0;		// (dynamic-exit instances run the recurrence behind the seeds)
+		// WW 35 cores of 16 / 24 stages: a static instance reads the
+		// descriptors (cordic_internal.h: desc_static), tails and image as in
+		// a single job; all others the dynamic-exit instance, which runs the
+		// recurrence behind the seeds: no tail tables, an image slot of its own
+		const bool stat = cfg.ww == 35		// (the WideLJ<29> unit carries them)
+			&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))
+			&& desc_static(cfg.nlive, j.dt.n, feed == Feed::Nco_ConstXY);
+		const int kJobImageKey = stat ? 0 : 4;
+		if (!stat)
+			sa.dt.n = 0;
 #endif
 		sa.tiles = tabs.tiles;
 		sa.ntiles = tabs.ntiles;

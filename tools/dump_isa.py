@@ -24,15 +24,15 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # (file stem, object, demangled-name regex, what it is)
 KERNELS = [
     ("rotator_seeded_lj29_16", "cordic_inst_seed_lj29.o",
-     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true>",
+     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true, false>",
      "cfg2 headline: seeded p2r, WW 35, 16 stages (5 after the seed: one group of "
      "direction tails on every row)"),
     ("rotator_seeded_lj29_24", "cordic_inst_seed_lj29.o",
-     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true>",
+     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 24, 11, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false, true, false>",
      "cfg4: seeded p2r, 24 stages (13 after the seed: direction tails in groups of "
      "6 and 7 on coherent rows, phase recurrence on the others)"),
     ("rotator_seeded_lj29_16_nco", "cordic_inst_seed_lj29.o",
-     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)2, false, cordic_amd::dev::Io32, false, true>",
+     r"rotator_seeded<cordic_amd::dev::WideLJ<29>, 16, 11, \(cordic_amd::Feed\)2, false, cordic_amd::dev::Io32, false, true, false>",
      "cfg5: fused NCO + seeded p2r with the group of direction tails, store only"),
     ("rotator_unrolled_lj29_16", "cordic_inst_rot_lj29.o",
      r"rotator_unrolled<cordic_amd::dev::WideLJ<29>, 16, 2, \(cordic_amd::Feed\)0, false, cordic_amd::dev::Io32, false>",
