@@ -99,7 +99,7 @@ def test_phase_array_jobs_equal_the_oracle_job_by_job(name):
     js.close(); plan.close()
 
 
-@pytest.mark.parametrize("name", ["cfg2", "pw20", "nat16"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "pw20", "nat16"])
 def test_nco_jobs_equal_the_oracle_job_by_job(name):
     args, flags = CORES[name]
     cfg, ocfg = both(*args, flags=flags)
