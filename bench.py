@@ -25,10 +25,18 @@ under torch.distributed.run with N ranks (one GPU each); fewer than N visible
 GPUs is an error, never a silent 1-GPU run.  `--single-process` instead
 drives all N devices from one host process (cordic_group, no process group).
 
-Rank 0 prints ONE JSON line.  The helpers that do not decide the metric live
-in tools/bench_*.py: power / clock sampling, the rocprofv3 counter passes, the
-copy probes, the VALU model, the CPU legs, the table / 16-bit / per-sample
-vector workloads and the informational `other_paths`.
+Rank 0 prints ONE JSON line of at most 4 KB (tools/bench_line.py: the contract
+keys, `roofline`, `cpu_baseline`, `digest_check`, `full_recurrence`, `scale`;
+numbers and short tokens only) and writes everything else it collected to
+--detail (default ./bench_detail.json).  The default command measures: the K
+timed steps, the oracle's digest of EVERY output, the full-recurrence kernel,
+one second of sustained running (power / clock), three rocprofv3 counter
+passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) and the CPU baseline -- about
+half a minute.  `--full` adds what round 5's default line carried: copy probes
+on the run's own arrays, the other BASELINE configurations at their sizes, the
+host-array entry points and the small-batch sweep (minutes; all of it lands in
+the detail file).  The helpers that do not decide the metric live in
+tools/bench_*.py.
 """
 import argparse
 import json
@@ -37,6 +45,7 @@ import sys
 import threading
 import time
 
+T_START = time.perf_counter()   # `wall_s` of the line counts from here
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
@@ -49,6 +58,7 @@ import build_stamp  # noqa: E402
 from bench_common import (HBM_PEAK_GBS, MODE, RW, SHARE_GPU, WORKLOADS,  # noqa: E402
                           RawWords, claim_stdout, coll_device, dist_init, emit,
                           ranks_on_this_node, spot_indices, usable_cpus)
+from bench_line import publish  # noqa: E402
 from bench_oracle import (cpu_baseline, oracle_digest_leg,  # noqa: E402
                           reduce_digest_legs)
 from bench_pmc import from_profile, measure_pmc  # noqa: E402
@@ -129,8 +139,9 @@ class LineGuard:
     phase labelled `error: timed out`) and every rank leaves with status 0,
     so the launcher sees a finished job and the driver a complete record."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, detail_path=None):
         self.rank = rank
+        self.detail_path = detail_path
         self.line = None            # rank 0: the record so far (a dict)
         self.on_timeout = None      # rank 0: phase -> None, patches self.line
         self._gen = 0
@@ -165,7 +176,10 @@ class LineGuard:
             try:
                 if self.on_timeout:
                     self.on_timeout(phase, limit_s)
-                emit(json.dumps(self.line))
+                if self.detail_path is None:
+                    emit(json.dumps(self.line))
+                else:
+                    publish(self.line, self.detail_path, emit)
             finally:
                 os._exit(0)
         time.sleep(3.0)             # let rank 0 write first
@@ -343,22 +357,32 @@ def single_process_block(args, ndev, expect):
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE",
                         "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
                         "TORCHELASTIC_RUN_ID", "BENCH_SELF_SPAWNED")}
+    import tempfile
+    fd, dpath = tempfile.mkstemp(prefix="bench_sp_", suffix=".json", dir="/tmp")
+    os.close(fd)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(ndev),
            "--single-process", "--workload", args.workload, "--steps",
            str(args.steps), "--warmup", str(args.warmup), "--log2-samples",
            str(args.log2_samples), "--input", args.input,
-           "--no-cpu-baseline", "--no-other-paths", "--no-copy-probe",
-           "--no-pmc", "--no-power", "--no-full-digest"]
+           "--no-cpu-baseline", "--no-pmc", "--no-power", "--no-full-digest",
+           "--detail", dpath]
     for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
                      ("--static-chunks", args.static_chunks)):
         if on:
             cmd.append(flag)
-    r = subprocess.run(cmd, env=env, text=True, capture_output=True,
-                       timeout=300)
-    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not rows:
-        return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
-    d = json.loads(rows[-1])
+    try:
+        r = subprocess.run(cmd, env=env, text=True, capture_output=True,
+                           timeout=args.single_process_limit)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not rows:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+        with open(dpath) as f:
+            d = json.load(f)
+    finally:
+        try:
+            os.unlink(dpath)
+        except OSError:
+            pass
     res = {"n_gpus": d["n_gpus"], "value": d["value"], "unit": d["unit"],
            "ms_per_step": d["ms_per_step"], "steps": d["steps"],
            "mode": d["launch"]["mode"],
@@ -409,13 +433,24 @@ def run_group(args, w, launch):
         devices = [0] * args.gpus if SHARE_GPU else list(range(args.gpus))
     else:
         total, nlocal, first, devices = world, 1, rank, [local]
-    guard = LineGuard(rank)
+    guard = LineGuard(rank, args.detail)
+    phases = {}                 # seconds per phase of this command (rank 0)
+    t_phase = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + now - t_phase[0]
+        t_phase[0] = now
 
     n = 1 << args.log2_samples
     n_total = n * total
     kind = w["kind"]
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
+    # since round 6 the library takes its arrays as hipMalloc hands them out
+    # unless asked (include/cordic_amd.h, "Placement"); the bench asks, and
+    # says so in the line (roofline.placement)
+    grp.set_placement(not args.no_placement)
     seeded, seed_stages, tails = False, 0, []
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
         probe_plan = ca.Plan(cfg)
@@ -473,10 +508,12 @@ def run_group(args, w, launch):
     # ---- same-run copy probes on the very arrays of shard 0 (before)
     _, ptrs, _ = grp.buffers(0)
     probes = []
-    if not args.no_copy_probe:
+    lap("setup")
+    if args.copy_probe:
         with torch.cuda.device(devices[0]):
             probes.append(copy_probe(ptrs, n, RW[kind]))
 
+    lap("copy_probe")
     sampler = start_power(devices[0], rank == 0 and not args.no_power)
 
     # W untimed warm-up steps, the last of them BEHIND the barrier: the ranks'
@@ -505,8 +542,11 @@ def run_group(args, w, launch):
             marks.append(k + 1)
     barrier()
     elapsed = time.perf_counter() - t0
+    lap("timed_region")
     power = finish_power(sampler, lambda: step(grp), grp.sync, t0, elapsed,
-                         args.steps, float(nlocal) * n)
+                         args.steps, float(nlocal) * n,
+                         seconds=2.0 if args.full else 1.0)
+    lap("sustained_window")
     per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(dev))
@@ -595,6 +635,7 @@ def run_group(args, w, launch):
                 "leading_2^20_also_equal": got == want}
             check = check and digest_check["equal"]
 
+    lap("oracle_digest")
     # ---- constant-vector feeds: also time the full-recurrence kernel (every
     # sample runs all micro-rotations) so both numbers are on record
     full = None
@@ -633,9 +674,11 @@ def run_group(args, w, launch):
 
     # ---- same-run copy probes again (after): the memory system may have
     # changed state under sustained load
-    if not args.no_copy_probe:
+    lap("full_recurrence")
+    if args.copy_probe:
         with torch.cuda.device(devices[0]):
             probes.append(copy_probe(ptrs, n, RW[kind]))
+        lap("copy_probe")
     grp_placement = grp.placement(0)
 
     # ---- the record so far: everything the metric needs.  What follows (the
@@ -663,11 +706,10 @@ def run_group(args, w, launch):
         # (cordic_group placement: include/cordic_amd.h)
         roof["placement"] = dict(
             grp_placement,
-            what="arrays allocated +2 spare (more, up to +24, while no pair "
-                 "of written arrays is fast: allocations come in classes and "
-                 "two of one class written together are slow), arithmetic-free "
-                 "probes of the job's traffic over the role assignments, best "
-                 "kept (--no-placement: as hipMalloc hands them out)")
+            what="cordic_group_set_placement(grp, 1): arrays allocated with two "
+                 "spares, arithmetic-free probes of the job's traffic over the "
+                 "role assignments, best kept (off in the library by default; "
+                 "--no-placement: as hipMalloc hands them out)")
         if probes and probes[0]:
             # the plain-copy ceiling of THIS run on THESE arrays: best of the
             # probes before and after the timed region
@@ -794,6 +836,7 @@ def run_group(args, w, launch):
     grp.close()
 
     single = None
+    lap("gather")
     if (launch == "torchrun" and not args.no_single_process_check
             and (world > 1 or os.environ.get("BENCH_FORCE_SINGLE_CHECK"))):
         # the C++ one-process layer on the same GPUs, for the record (and the
@@ -805,7 +848,8 @@ def run_group(args, w, launch):
                 single = single_process_block(args, world, digest)
             except Exception as e:            # never lose the main line
                 single = {"error": repr(e)}
-        guard.arm("ranks_rejoin", 420.0)      # (a rank may have left: LineGuard)
+        guard.arm("ranks_rejoin", args.single_process_limit + 120.0)
+        # (a rank may have left: LineGuard)
         try:
             dist.barrier(group=host_pg)
         except Exception as e:
@@ -834,6 +878,7 @@ def run_group(args, w, launch):
                     for k, v in gather.items() if v}}
         if single is not None:
             out["single_process_cordic_group"] = single
+        lap("single_process_check")
         roof = out["roofline"]
         pm = None
         if not args.no_pmc and total == 1:
@@ -847,11 +892,13 @@ def run_group(args, w, launch):
                     n / float(1 << args.log2_samples))
                 roof["traffic_over_algorithmic"] = roof["traffic"] / (
                     w["bytes"] * n)
+            lap("pmc_passes")
         add_valu(roof, n / kern_avg_s, pm, power, out["from_profile"],
                  args.workload)
         if not args.no_cpu_baseline and total == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, leg=leg)
-        if (total == 1 and args.workload == "cfg2" and not args.no_other_paths):
+            lap("cpu_baseline")
+        if total == 1 and args.workload == "cfg2" and args.full:
             import bench_paths
             torch.cuda.empty_cache()
             out["other_paths"] = bench_paths.other_paths(args)
@@ -863,7 +910,15 @@ def run_group(args, w, launch):
                 out["other_paths"]["small_batches"] = bench_paths.small_batches()
             except Exception as e:            # never lose the main line
                 out["other_paths"]["small_batches"] = {"error": repr(e)}
-        emit(json.dumps(out))
+            try:
+                out["other_paths"]["small_batches_xy"] = (
+                    bench_paths.small_batches_xy())
+            except Exception as e:            # never lose the main line
+                out["other_paths"]["small_batches_xy"] = {"error": repr(e)}
+            lap("other_paths")
+        out["phases_s"] = phases
+        out["wall_s"] = time.perf_counter() - T_START
+        publish(out, args.detail, emit)
         sys.stdout.flush()
     if dist is not None:
         guard.line = None                     # printed: nothing left to save
@@ -888,19 +943,38 @@ def main():
     ap.add_argument("--spawn", action="store_true",
                     help="go through the self-launch path (re-exec under "
                     "torch.distributed.run) even for --gpus 1")
+    ap.add_argument("--full", action="store_true",
+                    help="everything round 5's default command ran: copy "
+                    "probes before and after the timed region, two seconds of "
+                    "sustained running, and (cfg2, one GPU) the other BASELINE "
+                    "configurations at their sizes, the host-array entry points "
+                    "and the small-batch sweep; minutes instead of half a "
+                    "minute, all of it in the detail file")
+    ap.add_argument("--detail", default="bench_detail.json",
+                    help="where the full record goes (the printed line is a "
+                    "<= 4 KB selection of it: tools/bench_line.py); '-' or "
+                    "/dev/null: nowhere")
+    ap.add_argument("--copy-probe", action="store_true",
+                    help="arithmetic-free twins of the kernel's traffic on the "
+                    "run's own arrays, before and after the timed region "
+                    "(roofline.copy_frac in the detail file; part of --full)")
     ap.add_argument("--no-other-paths", action="store_true",
-                    help="skip the informational rates of the other entry "
-                    "points after the default (cfg2) run")
+                    help="(accepted for round 1-5 command lines: the other "
+                    "entry points are measured only with --full)")
     ap.add_argument("--host-paths-only", action="store_true",
                     help="print only the host-array entry points' rates "
                     "(other_paths.host_arrays of the default line)")
+    ap.add_argument("--small-batches-only", action="store_true",
+                    help="print only the small-batch rows (one call per job "
+                    "against one job set; other_paths.small_batches* of --full)")
     ap.add_argument("--log2-samples", type=int, default=30,
                     help="samples per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-digest", action="store_true",
                     help="skip the oracle digest over ALL samples (rank 0, "
                     "all host cores, ~2 s per 2^30 samples on 16 cores)")
-    ap.add_argument("--no-copy-probe", action="store_true")
+    ap.add_argument("--no-copy-probe", action="store_true",
+                    help="(accepted for older command lines: see --copy-probe)")
     ap.add_argument("--no-placement", action="store_true",
                     help="take the group's arrays as hipMalloc hands them out "
                          "instead of probing candidate allocations")
@@ -923,6 +997,9 @@ def main():
                     "--gpus 1 (with more than one GPU it always runs)")
     ap.add_argument("--no-gather", action="store_true",
                     help="multi-GPU runs: skip the gather block")
+    ap.add_argument("--single-process-limit", type=float, default=240.0,
+                    help="seconds the embedded one-process run of a multi-rank "
+                    "job may take (it is dropped with a labelled error beyond)")
     ap.add_argument("--gather-limit", type=float, default=180.0,
                     help="seconds the gather phase may take before the line "
                     "is printed without it (gather.*.error)")
@@ -950,6 +1027,12 @@ def main():
     ap.add_argument("--ramp-shift", type=int, default=-1,
                     help="experiments: phase ramp n << this (steeper ramps)")
     args = ap.parse_args()
+    if args.full:
+        args.copy_probe = True
+    if args.no_copy_probe:
+        args.copy_probe = False
+    if args.no_other_paths and args.full:
+        raise SystemExit("bench.py: --full and --no-other-paths disagree")
     if args.ramp_shift >= 0:
         w0 = WORKLOADS[args.workload]
         w0["shift"] = args.ramp_shift
@@ -958,14 +1041,20 @@ def main():
         w0 = WORKLOADS[args.workload]
         w0["cli"] = tuple(w0["cli"][:5]) + (args.nstages,)
         w0["desc"] += " [--nstages %d]" % args.nstages
-    if args.no_placement:
-        # read by cordic_group_create / cordic_arrays_alloc (and inherited by
-        # the ranks and sub-runs this process starts)
-        os.environ["CORDIC_GROUP_PLACEMENT"] = "0"
+    # placement of the arrays: off in the library unless asked (round 6); the
+    # bench asks -- run_group through cordic_group_set_placement, the stateless
+    # workloads' cordic_arrays_alloc through the environment (also inherited
+    # by the ranks and sub-runs this process starts)
+    os.environ["CORDIC_GROUP_PLACEMENT"] = "0" if args.no_placement else "1"
 
     if args.host_paths_only:
         import bench_paths
         print(json.dumps(bench_paths.host_paths()))
+        return
+    if args.small_batches_only:
+        import bench_paths
+        print(json.dumps({"small_batches": bench_paths.small_batches(),
+                          "small_batches_xy": bench_paths.small_batches_xy()}))
         return
     launch = resolve_launch(args)
     if launch == "spawn":

@@ -16,8 +16,8 @@ from ._native import (  # noqa: F401
     P2R, R2P, SP2R, SR2P,
     FLAG_FORCE_GENERIC, FLAG_NO_LJ, FLAG_NO_SEED, FLAG_NO_TAILS, FLAG_STATIC_CHUNKS,
     FLAG_UNIT_GAIN,
-    ERR_ARGS, ERR_DEVICE, ERR_CONTAINER, ERR_UNSUPPORTED,
-    Config, CordicError, Plan, Jobset, JOBS_PHASE_ARRAYS, JOBS_NCO, jobset_reap, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, dir_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED, KERNEL_DIRECTIONS,
+    ERR_ARGS, ERR_DEVICE, ERR_CONTAINER, ERR_UNSUPPORTED, ERR_MODE,
+    Config, CordicError, Plan, Jobset, JOBS_PHASE_ARRAYS, JOBS_NCO, JOBS_R2P, JOBS_P2R_XY, JOBS_MIX, jobset_reap, Group, Arrays, device_count, shard_range, rccl_unique_id, RCCL_ID_BYTES, Table, TBL, QTR, Quad, Stream, Seq, seed_table, dir_table, Quality, fill_circle, last_kernel, KERNEL_GENERIC, KERNEL_UNROLLED, KERNEL_SEEDED, KERNEL_LEFT_JUSTIFIED, KERNEL_DIRECTIONS,
     lib, lib_path,
     p2r, p2r_const, nco, mix, r2p,
     p2r_host, r2p_host, HostArray, host_last_stats, host_release,

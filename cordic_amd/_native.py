@@ -11,6 +11,7 @@ FLAG_STATIC_CHUNKS = 0x20
 FLAG_UNIT_GAIN = 0x10
 FLAG_NO_TAILS = 0x40
 # enum cordic_status (the codes tests assert on)
+ERR_MODE = -1
 ERR_UNSUPPORTED = -6
 ERR_ARGS, ERR_DEVICE, ERR_CONTAINER = -7, -8, -9
 
@@ -139,6 +140,12 @@ ABI = {
                                               C.c_void_p]),
     "cordic_plan_nco_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
                                         C.c_int32, C.c_int32, C.c_void_p]),
+    "cordic_plan_r2p_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]),
+    "cordic_plan_p2r_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]),
+    "cordic_plan_mix_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]),
     "cordic_jobset_reap": (None, []),
     "cordic_plan_image_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_uint64),
@@ -458,6 +465,15 @@ class Plan:
             self._h, len(jobs), _job_array(jobs), x0, y0, _stream(stream)),
             "cordic_plan_nco_batch")
 
+    def xy_batch(self, kind, jobs, stream=None):
+        """one-shot batch of data-fed jobs (cordic_plan_r2p_batch / _p2r_batch
+        / _mix_batch by kind)"""
+        name = {JOBS_R2P: "cordic_plan_r2p_batch",
+                JOBS_P2R_XY: "cordic_plan_p2r_batch",
+                JOBS_MIX: "cordic_plan_mix_batch"}[kind]
+        _check(getattr(lib(), name)(self._h, len(jobs), _job_array(jobs),
+                                    _stream(stream)), name)
+
     def set_min_samples(self, n):
         """batch size from which the table-driven kernels serve (< 0: default)"""
         _check(lib().cordic_plan_set_min_samples(self._h, n),
@@ -503,15 +519,17 @@ class _CJob(C.Structure):
     _fields_ = [("d_phase", C.c_void_p), ("phase0", C.c_uint32),
                 ("fcw", C.c_uint32), ("index0", C.c_uint64),
                 ("d_oxval", C.c_void_p), ("d_oyval", C.c_void_p),
-                ("n", C.c_uint64)]
+                ("n", C.c_uint64),
+                ("d_xval", C.c_void_p), ("d_yval", C.c_void_p)]
 
 
-JOBS_PHASE_ARRAYS, JOBS_NCO = 0, 1
+JOBS_PHASE_ARRAYS, JOBS_NCO, JOBS_R2P, JOBS_P2R_XY, JOBS_MIX = 0, 1, 2, 3, 4
 
 
 def _job_array(jobs):
-    """jobs: dicts / tuples with phase (tensor or None), ox, oy, n and, for
-    NCO jobs, phase0, fcw, index0 -> a C array of cordic_job"""
+    """jobs: dicts with phase (tensor or None), ox, oy, n; for NCO / MIX jobs
+    phase0, fcw, index0; for the data-fed kinds x, y (R2P: ox = o_mag, oy =
+    o_phase) -> a C array of cordic_job"""
     arr = (_CJob * max(1, len(jobs)))()
     for k, jb in enumerate(jobs):
         ph = jb.get("phase")
@@ -522,6 +540,9 @@ def _job_array(jobs):
         arr[k].d_oxval = _ptr(jb["ox"])
         arr[k].d_oyval = _ptr(jb["oy"])
         arr[k].n = jb["n"]
+        for key, field in (("x", "d_xval"), ("y", "d_yval")):
+            v = jb.get(key)
+            setattr(arr[k], field, _ptr(v) if v is not None else None)
     return arr
 
 
@@ -544,7 +565,7 @@ class Jobset:
                                         C.byref(c)), "cordic_jobset_info")
         return dict(samples=a.value, tiles=b.value, tail_samples=c.value)
 
-    def run(self, x0, y0, stream=None, plan=None):
+    def run(self, x0=0, y0=0, stream=None, plan=None):
         _check(lib().cordic_plan_run_jobs((plan or self.plan)._h, self._h, x0,
                                           y0, _stream(stream)),
                "cordic_plan_run_jobs")
@@ -729,9 +750,10 @@ class Group:
 
 
 class Arrays:
-    """cordic_arrays_alloc: n_read + n_write device arrays of `nbytes` bytes,
-    placed by measurement (include/cordic_amd.h, "Placement"), as torch tensor
-    views; read arrays first."""
+    """cordic_arrays_alloc: n_read + n_write device arrays of `nbytes` bytes
+    (plain hipMalloc; placed by measurement with CORDIC_GROUP_PLACEMENT=1 in
+    the environment: include/cordic_amd.h, "Placement"), as torch tensor views;
+    read arrays first."""
 
     class _View:
         def __init__(self, ptr, count, typestr):

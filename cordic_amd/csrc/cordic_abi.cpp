@@ -247,6 +247,14 @@ int cordic_plan_dir_info(const cordic_plan *plan, int32_t *ngroups, int32_t stag
 	return CORDIC_OK;
 }
 
+// the plan's direction tables for the per-sample-vector kernels
+static void attach_dirs(const cordic_plan *plan, RotatorJob &j)
+{
+	j.dir_table = plan->d_dir;
+	j.dx = plan->dx;
+	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
+}
+
 int cordic_plan_p2r(const cordic_plan *plan, size_t n, const int32_t *d_xval,
 		const int32_t *d_yval, const uint32_t *d_phase, int32_t *d_oxval,
 		int32_t *d_oyval, void *stream)
@@ -256,9 +264,7 @@ int cordic_plan_p2r(const cordic_plan *plan, size_t n, const int32_t *d_xval,
 	RotatorJob j;
 	j.x = d_xval; j.y = d_yval; j.phase = d_phase;
 	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
-	j.dir_table = plan->d_dir;
-	j.dx = plan->dx;
-	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
+	attach_dirs(plan, j);
 	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
@@ -272,9 +278,7 @@ int cordic_plan_mix(const cordic_plan *plan, size_t n, uint32_t phase0,
 	j.x = d_xval; j.y = d_yval;
 	j.phase0 = phase0; j.fcw = fcw; j.index0 = index0; j.xy_nco = true;
 	j.ox = d_oxval; j.oy = d_oyval; j.n = n;
-	j.dir_table = plan->d_dir;
-	j.dx = plan->dx;
-	j.min_samples = plan->min_samples.load(std::memory_order_relaxed);
+	attach_dirs(plan, j);
 	return launch_rotator(plan->cfg, Feed::PhaseArray_XYArray, j, stream);
 }
 
@@ -388,7 +392,7 @@ int cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
 // the device; running the set is then ONE launch of the dynamic-exit instance
 // (+ one small launch for trailing samples), whatever the number of jobs.
 struct cordic_jobset {
-	int	kind = 0;		// CORDIC_JOBS_PHASE_ARRAYS / CORDIC_JOBS_NCO
+	int	kind = 0;		// enum cordic_jobs_kind
 	int	device = 0;
 	std::vector<cordic_job> jobs;	// host copy: the one-by-one fallback
 	uint32_t *d_tiles = nullptr, *d_tails = nullptr;
@@ -413,7 +417,10 @@ void reap_parked(bool wait)
 			Parked &p = g_parked[k];
 			const hipError_t e = wait ? hipEventSynchronize(p.done)
 						  : hipEventQuery(p.done);
-			if (e == hipSuccess || (wait && e != hipErrorNotReady)) {
+			// (only a launch that is KNOWN to have passed gives its tables
+			// back: an event in an error state says nothing about who still
+			// reads them, and the set then stays parked for good)
+			if (e == hipSuccess) {
 				dead.push_back(p);
 				g_parked.erase(g_parked.begin() + (long)k);
 			} else {
@@ -429,53 +436,124 @@ void reap_parked(bool wait)
 }
 } // namespace
 
+namespace {
+// same core?  field by field: the PODs come from different places and their
+// padding bytes are nobody's business
+bool same_core(const cordic_config &a, const cordic_config &b)
+{
+	if (a.mode != b.mode || a.iw != b.iw || a.ow != b.ow || a.nextra != b.nextra
+			|| a.ww != b.ww || a.pw != b.pw || a.nstages != b.nstages
+			|| a.nlive != b.nlive || a.needs_wrap != b.needs_wrap
+			|| a.flags != b.flags)
+		return false;
+	for (int i = 0; i < a.nstages && i < CORDIC_AMD_MAX_STAGES; i++)
+		if (a.angle[i] != b.angle[i])
+			return false;
+	return true;
+}
+
+// Tile length (vectors) of the data-fed kinds: whole passes of a 256-thread
+// block, as long as the seeded kernels' tiles where the set is big enough to
+// give every resident block (8 per CU) four of them, shorter below.
+uint32_t xy_tile_vecs(uint64_t total_vecs)
+{
+	int cus = 0, dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus,
+			hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+		(void)hipGetLastError();
+		cus = 256;
+	}
+	const uint64_t per = total_vecs / ((uint64_t)cus * 8u * 4u);
+	uint64_t v = per / kJobPassVecs * kJobPassVecs;
+	if (v < kJobPassVecs) v = kJobPassVecs;
+	if (v > kJobTileVecs) v = kJobTileVecs;
+	return (uint32_t)v;
+}
+} // namespace
+
 int cordic_jobset_create(const cordic_plan *plan, int kind, size_t njobs,
 		const cordic_job *jobs, cordic_jobset **out)
 {
-	if (!plan || !out || (njobs && !jobs)
-			|| (kind != CORDIC_JOBS_PHASE_ARRAYS && kind != CORDIC_JOBS_NCO))
+	if (!plan || !out || (njobs && !jobs) || kind < CORDIC_JOBS_PHASE_ARRAYS
+			|| kind > CORDIC_JOBS_MIX)
 		return CORDIC_ERR_ARGS;
-	if (plan->cfg.mode != CORDIC_P2R && plan->cfg.mode != CORDIC_SP2R)
+	const bool rot = plan->cfg.mode == CORDIC_P2R || plan->cfg.mode == CORDIC_SP2R;
+	if (rot == (kind == CORDIC_JOBS_R2P))
 		return CORDIC_ERR_MODE;
+	const bool xy = kind >= CORDIC_JOBS_R2P;	// per-sample vectors from memory
+	const bool phase_array = kind == CORDIC_JOBS_PHASE_ARRAYS
+			|| kind == CORDIC_JOBS_P2R_XY;
+	const bool gen_phase = kind == CORDIC_JOBS_NCO || kind == CORDIC_JOBS_MIX;
 	std::vector<TileDesc> tiles;
 	std::vector<TailDesc> tails;
-	uint64_t samples = 0;
+	std::vector<TileDescXY> xtiles, xtails;
+	uint64_t samples = 0, vecs = 0;
 	const int sh = 32 - plan->cfg.pw;
 	for (size_t k = 0; k < njobs; k++) {
 		const cordic_job &jb = jobs[k];
 		if (jb.n == 0)
 			continue;
-		if (!jb.d_oxval || !jb.d_oyval
-				|| (kind == CORDIC_JOBS_PHASE_ARRAYS && !jb.d_phase)
+		if (!jb.d_oxval || !jb.d_oyval || (phase_array && !jb.d_phase)
+				|| (xy && (!jb.d_xval || !jb.d_yval))
 				|| ((uintptr_t)jb.d_oxval & 3) || ((uintptr_t)jb.d_oyval & 3)
-				|| (kind == CORDIC_JOBS_PHASE_ARRAYS && ((uintptr_t)jb.d_phase & 3)))
+				|| (phase_array && ((uintptr_t)jb.d_phase & 3))
+				|| (xy && (((uintptr_t)jb.d_xval & 3) || ((uintptr_t)jb.d_yval & 3))))
 			return CORDIC_ERR_ARGS;
 		samples += jb.n;
+		vecs += jb.n / 4;
+	}
+	const uint32_t tile_vecs = xy ? xy_tile_vecs(vecs) : kJobTileVecs;
+	for (size_t k = 0; k < njobs; k++) {
+		const cordic_job &jb = jobs[k];
+		if (jb.n == 0)
+			continue;
 		const uint64_t nvec = jb.n / 4;
-		// the phase of sample s of the job, left-justified (NCO jobs)
+		// the phase of sample s of the job, left-justified (NCO / MIX jobs)
 		auto nco_word = [&](uint64_t s) -> uint64_t {
 			const uint32_t f = jb.fcw << sh;
 			const uint32_t p = (jb.phase0 << sh) + (uint32_t)(jb.index0 + s) * f;
 			return ((uint64_t)f << 32) | p;
 		};
-		for (uint64_t v0 = 0; v0 < nvec; v0 += kJobTileVecs) {
+		auto in_word = [&](uint64_t s) -> uint64_t {
+			return gen_phase ? nco_word(s)
+				: phase_array ? (uint64_t)(uintptr_t)(jb.d_phase + s) : 0;
+		};
+		auto xy_desc = [&](uint64_t s, uint32_t live) {
+			TileDescXY d{};
+			d.in0 = (uint64_t)(uintptr_t)(jb.d_xval + s);
+			d.in1 = (uint64_t)(uintptr_t)(jb.d_yval + s);
+			d.in2 = in_word(s);
+			d.o0 = (uint64_t)(uintptr_t)(jb.d_oxval + s);
+			d.o1 = (uint64_t)(uintptr_t)(jb.d_oyval + s);
+			d.live = live;
+			return d;
+		};
+		for (uint64_t v0 = 0; v0 < nvec; v0 += tile_vecs) {
+			const uint32_t live = (uint32_t)(nvec - v0 < tile_vecs ? nvec - v0 : tile_vecs);
+			if (xy) {
+				xtiles.push_back(xy_desc(v0 * 4, live));
+				continue;
+			}
 			TileDesc d{};
-			d.in = kind == CORDIC_JOBS_NCO ? nco_word(v0 * 4)
-				: (uint64_t)(uintptr_t)(jb.d_phase + v0 * 4);
+			d.in = in_word(v0 * 4);
 			d.ox = (uint64_t)(uintptr_t)(jb.d_oxval + v0 * 4);
 			d.oy = (uint64_t)(uintptr_t)(jb.d_oyval + v0 * 4);
-			d.live = (uint32_t)(nvec - v0 < kJobTileVecs ? nvec - v0 : kJobTileVecs);
+			d.live = live;
 			tiles.push_back(d);
 		}
 		for (uint64_t s = nvec * 4; s < jb.n; s++) {
+			if (xy) {
+				xtails.push_back(xy_desc(s, 0));
+				continue;
+			}
 			TailDesc d{};
-			d.in = kind == CORDIC_JOBS_NCO ? nco_word(s)
-				: (uint64_t)(uintptr_t)(jb.d_phase + s);
+			d.in = in_word(s);
 			d.ox = (uint64_t)(uintptr_t)(jb.d_oxval + s);
 			d.oy = (uint64_t)(uintptr_t)(jb.d_oyval + s);
 			tails.push_back(d);
 		}
-		if (tiles.size() > 0x7fffffffu || tails.size() > 0x7fffffffu)
+		if (tiles.size() > 0x7fffffffu || tails.size() > 0x7fffffffu
+				|| xtiles.size() > 0x7fffffffu || xtails.size() > 0x7fffffffu)
 			return CORDIC_ERR_ARGS;
 	}
 	cordic_jobset *set = new (std::nothrow) cordic_jobset;
@@ -484,24 +562,30 @@ int cordic_jobset_create(const cordic_plan *plan, int kind, size_t njobs,
 	set->kind = kind;
 	set->cfg = plan->cfg;
 	set->jobs.assign(jobs, jobs + njobs);
-	if (hipGetDevice(&set->device) != hipSuccess)
-		set->device = 0;
+	if (hipGetDevice(&set->device) != hipSuccess) {
+		(void)hipGetLastError();
+		set->device = -1;
+	}
 	auto upload = [](const void *src, size_t bytes, uint32_t **dst) {
 		if (!bytes)
 			return true;
 		return hipMalloc((void **)dst, bytes) == hipSuccess
 			&& hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
 	};
-	if (!upload(tiles.data(), tiles.size() * sizeof(TileDesc), &set->d_tiles)
-			|| !upload(tails.data(), tails.size() * sizeof(TailDesc), &set->d_tails)) {
+	const bool up = xy
+		? upload(xtiles.data(), xtiles.size() * sizeof(TileDescXY), &set->d_tiles)
+			&& upload(xtails.data(), xtails.size() * sizeof(TileDescXY), &set->d_tails)
+		: upload(tiles.data(), tiles.size() * sizeof(TileDesc), &set->d_tiles)
+			&& upload(tails.data(), tails.size() * sizeof(TailDesc), &set->d_tails);
+	if (!up) {
 		(void)hipGetLastError();
 		cordic_jobset_destroy(set);
 		return CORDIC_ERR_DEVICE;
 	}
 	set->tabs.tiles = set->d_tiles;
-	set->tabs.ntiles = (uint32_t)tiles.size();
+	set->tabs.ntiles = (uint32_t)(xy ? xtiles.size() : tiles.size());
 	set->tabs.tails = set->d_tails;
-	set->tabs.ntails = (uint32_t)tails.size();
+	set->tabs.ntails = (uint32_t)(xy ? xtails.size() : tails.size());
 	set->tabs.samples = samples;
 	*out = set;
 	return CORDIC_OK;
@@ -532,9 +616,39 @@ int cordic_plan_run_jobs(const cordic_plan *plan, const cordic_jobset *set,
 {
 	if (!plan || !set)
 		return CORDIC_ERR_ARGS;
-	// cut for this core?  (the tile table holds PW-scaled phase words)
-	if (std::memcmp(&set->cfg, &plan->cfg, sizeof plan->cfg) != 0)
+	// cut for this core (the tile table holds PW-scaled phase words) and for
+	// this device (it holds device addresses)?
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return CORDIC_ERR_DEVICE;
+	}
+	if (!same_core(set->cfg, plan->cfg) || dev != set->device)
 		return CORDIC_ERR_ARGS;
+	if (set->kind >= CORDIC_JOBS_R2P) {
+		RotatorJob j;
+		if (set->kind != CORDIC_JOBS_R2P)
+			attach_dirs(plan, j);
+		int rc = launch_xy_jobs(plan->cfg, set->kind, j, set->tabs, stream);
+		if (rc != CORDIC_ERR_UNSUPPORTED)
+			return rc;
+		// no tile-reading instance for this core: the jobs one by one
+		for (const cordic_job &jb : set->jobs) {
+			if (jb.n == 0)
+				continue;
+			rc = set->kind == CORDIC_JOBS_R2P
+				? launch_topolar(plan->cfg, (size_t)jb.n, jb.d_xval, jb.d_yval,
+					jb.d_oxval, reinterpret_cast<uint32_t *>(jb.d_oyval), stream)
+				: set->kind == CORDIC_JOBS_MIX
+				? cordic_plan_mix(plan, (size_t)jb.n, jb.phase0, jb.fcw, jb.index0,
+					jb.d_xval, jb.d_yval, jb.d_oxval, jb.d_oyval, stream)
+				: cordic_plan_p2r(plan, (size_t)jb.n, jb.d_xval, jb.d_yval,
+					jb.d_phase, jb.d_oxval, jb.d_oyval, stream);
+			if (rc != CORDIC_OK)
+				return rc;
+		}
+		return CORDIC_OK;
+	}
 	const Feed feed = set->kind == CORDIC_JOBS_NCO ? Feed::Nco_ConstXY
 						     : Feed::PhaseArray_ConstXY;
 	RotatorJob j;
@@ -565,6 +679,16 @@ int cordic_plan_run_jobs(const cordic_plan *plan, const cordic_jobset *set,
 static int run_batch_once(const cordic_plan *plan, int kind, size_t njobs,
 		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream)
 {
+	// cutting a set allocates and copies (blocking): not inside a capture --
+	// and the graph would outlive the tables this call frees behind its launch
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs)
+			!= hipSuccess) {
+		(void)hipGetLastError();
+		cs = hipStreamCaptureStatusNone;
+	}
+	if (cs != hipStreamCaptureStatusNone)
+		return CORDIC_ERR_UNSUPPORTED;
 	reap_parked(false);
 	cordic_jobset *set = nullptr;
 	if (int rc = cordic_jobset_create(plan, kind, njobs, jobs, &set))
@@ -596,6 +720,24 @@ int cordic_plan_nco_batch(const cordic_plan *plan, size_t njobs,
 		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream)
 {
 	return run_batch_once(plan, CORDIC_JOBS_NCO, njobs, jobs, xval, yval, stream);
+}
+
+int cordic_plan_r2p_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream)
+{
+	return run_batch_once(plan, CORDIC_JOBS_R2P, njobs, jobs, 0, 0, stream);
+}
+
+int cordic_plan_p2r_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream)
+{
+	return run_batch_once(plan, CORDIC_JOBS_P2R_XY, njobs, jobs, 0, 0, stream);
+}
+
+int cordic_plan_mix_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream)
+{
+	return run_batch_once(plan, CORDIC_JOBS_MIX, njobs, jobs, 0, 0, stream);
 }
 
 void cordic_jobset_reap(void) { reap_parked(true); }

@@ -2242,13 +2242,17 @@ __device__ __forceinline__ void pol_stage1_lj_early(int64_t &x, int64_t &y, int6
 // scale), so the kernel carries neither alternative -- as run-time branches
 // they cost a block of register copies where the paths join (16 v_mov_b64 per
 // pass in profiles/isa/topolar_lj_20.s of round 2).
-template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false,
-	  bool PLAIN = false>
-__global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
+//
+// topolar_lj_sweep: vectors g, g + stride, ... < nvec of ONE contiguous
+// stretch (the whole call for topolar_lj, one tile of one job for
+// topolar_lj_jobs).
+template <int NLIVE, bool DYN, typename IO, bool UG, bool PLAIN>
+__device__ __forceinline__ void topolar_lj_sweep(const CoreParams &kp,
 		const typename IO::ivec *__restrict__ xin,
 		const typename IO::ivec *__restrict__ yin,
 		typename IO::ivec *__restrict__ omag,
-		typename IO::uvec *__restrict__ oph, size_t nvec)
+		typename IO::uvec *__restrict__ oph, size_t nvec, size_t g,
+		const size_t stride)
 {
 	PolLjRegs c;
 	c.sign = vgpr_const(0x80000000u);
@@ -2259,8 +2263,6 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 	const int up = 32 - kp.iw;			// port -> sign bit of the word
 	const int down = up - kp.in_shl;		// ... and back to e = i << in_shl
 
-	const size_t stride = (size_t)gridDim.x * kBlock;
-	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	typename IO::ivec nx{}, ny{};		// software prefetch
 	if (g < nvec) {
 		nx = CORDIC_LOAD_IN(&xin[g]);
@@ -2358,6 +2360,41 @@ __global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
 		apply_unit_gain<UG>(rm, kp);
 		CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
 		CORDIC_STORE_OUT(true, &oph[g], IO::narrow(rp));
+	}
+}
+
+template <int NLIVE, bool DYN = false, typename IO = Io32, bool UG = false,
+	  bool PLAIN = false>
+__global__ __launch_bounds__(kBlock) void topolar_lj(CoreParams kp,
+		const typename IO::ivec *__restrict__ xin,
+		const typename IO::ivec *__restrict__ yin,
+		typename IO::ivec *__restrict__ omag,
+		typename IO::uvec *__restrict__ oph, size_t nvec)
+{
+	topolar_lj_sweep<NLIVE, DYN, IO, UG, PLAIN>(kp, xin, yin, omag, oph, nvec,
+		(size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock);
+}
+
+// Many small jobs in one launch (cordic_jobset, CORDIC_JOBS_R2P; round 6): the
+// host has cut every job into tiles of at most `live` whole vectors -- never
+// across a job's end -- and block b sweeps tiles b, b + gridDim.x, ... in the
+// table's order, which is the jobs' own: neighbouring blocks work on
+// neighbouring tiles of the same arrays.  Per tile the descriptor's five
+// words arrive as scalar loads and the sweep above runs over that tile alone
+// (its software prefetch starts afresh: one exposed load per 8 passes of a
+// full tile, hidden by the other waves of the SIMD).
+template <int NLIVE, bool DYN = false, bool PLAIN = false>
+__global__ __launch_bounds__(kBlock) void topolar_lj_jobs(CoreParams kp,
+		const TileDescXY *__restrict__ tiles, uint32_t ntiles)
+{
+	for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const TileDescXY d = tiles[t];
+		topolar_lj_sweep<NLIVE, DYN, Io32, false, PLAIN>(kp,
+			reinterpret_cast<const i32x4g *>((uintptr_t)d.in0),
+			reinterpret_cast<const i32x4g *>((uintptr_t)d.in1),
+			reinterpret_cast<i32x4g *>((uintptr_t)d.o0),
+			reinterpret_cast<u32x4g *>((uintptr_t)d.o1),
+			(size_t)d.live, (size_t)threadIdx.x, (size_t)kBlock);
 	}
 }
 

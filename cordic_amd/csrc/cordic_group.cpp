@@ -21,10 +21,11 @@
 // property of the combination (the two written arrays most of all), stable
 // for the life of the allocations, not predictable from the virtual addresses
 // (tools/hbm_alloc_probe*.py, profiles/r02/hbm_placement.txt).  Since the
-// group owns its arrays it can choose: when it allocates the arrays of a
-// shard it allocates two more than it needs, times the arithmetic-free twin of
-// the job's traffic (launch_stream_probe) over the candidate assignments,
-// keeps the best and frees the rest.
+// group owns its arrays it can choose: when asked to
+// (cordic_group_set_placement; off by default since round 6) it allocates two
+// more arrays than a shard needs, times the arithmetic-free twin of the job's
+// traffic (launch_stream_probe) over the candidate assignments, keeps the best
+// and frees the rest.
 //
 // The reference has nothing of the kind (bench/cpp/cordic_tb.cpp:127-178 steps
 // one model from one thread), so there is no reference text to follow here.
@@ -78,29 +79,13 @@ struct Shard {
 };
 
 constexpr uint64_t kPlaceMinWords = (uint64_t)1 << 24;	// arrays of 64 MiB and up
-constexpr int kPlaceSpare = 2;		// candidates beyond the need, always
-// Allocations come in CLASSES (profiles/r05/pair_matrix.txt: 40 arrays of
-// 4 GiB, every pair): two arrays of the same class written together run at
-// 0.79-0.82 of the 8 TB/s peak, two of different classes at 0.95-0.97, nothing
-// in between except for arrays that straddle two classes; consecutive
-// allocations share a class in runs of 2-16.  A box whose first five
-// allocations are one run has no fast pair among them (4 of 8 boxes one day:
-// 0.77 of the peak for cfg2 instead of 0.85).  So: while no pair is fast, take
-// more candidates -- up to kPlaceSpareMax, each tried against a few of the
-// ones at hand (one of another class is fast with all of them).
-constexpr int kPlaceSpareMax = 24;
-constexpr int kPlaceTryAgainst = 3;
-// ... for arrays from 512 MiB: a probe over a smaller one is a few tens of
-// microseconds and says nothing about classes -- the round-4 limits apply
-constexpr uint64_t kPlaceWideWords = (uint64_t)1 << 27;
-constexpr int kPlaceSpareMaxSmall = 6, kPlaceReadExtraSmall = 6;
-constexpr uint64_t kPlaceSpareBytes = (uint64_t)96 << 30;	// of candidates at most
-// a pair of written arrays is fast from 0.93 of the peak (slow ones: <= 0.90)
-constexpr double kPlaceGoodBytesPerMs = 0.93 * 8e9;
-// the 1R2W pattern of a constant-vector rotator: 0.845 is what a well placed
-// triple reaches (0.85-0.86 at best)
-constexpr double kPlaceGoodMixBytesPerMs = 0.845 * 8e9;
-constexpr int kPlaceReadExtra = 10;
+constexpr int kPlaceSpare = 2;		// candidates beyond the need, at most
+// ... and in bytes: a tenth of what is free on the device when the arrays are
+// allocated (round 6: the library may not transiently claim tens of GiB of a
+// caller's HBM; rounds 4-5 took up to 24 spares while no pair of written
+// arrays was fast -- allocations come in classes, profiles/r05/pair_matrix.txt
+// -- which bought ~5 % on one box in eight and is gone)
+constexpr double kPlaceSpareFreeShare = 0.10;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
 struct Rccl {
@@ -165,7 +150,7 @@ struct cordic_group {
 	int32_t	*g0 = nullptr, *g1 = nullptr;
 	int	chunks = 1;
 	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
-	bool	placement = true;
+	bool	placement = false;	// cordic_group_set_placement
 	// the job size the shards' input arrays were last filled for by the fill
 	// kernels (0: not filled), and how many of them; what the CALLER wrote is
 	// tracked per shard and array (Shard::written)
@@ -265,32 +250,36 @@ float probe_ms(hipStream_t st, int reads, int writes, const void *r0, const void
 }
 
 // Allocate nread (0..2) + nwrite (1..2) arrays of `words` 32-bit words on the
-// current device.  With `tune`, allocate kPlaceSpare more than needed, time the
-// arithmetic-free twin of the traffic over the candidate assignments -- first
-// the written arrays (two: every pair, 0R2W; while no pair is good enough, up
-// to kPlaceSpareMax - kPlaceSpare more candidates, each tried against the ones
-// at hand), then the read ones over what is left -- keep the best and free the
-// rest.  A probe that cannot run just means "in order".
+// current device.  With `tune`, allocate up to kPlaceSpare more than needed,
+// time the arithmetic-free twin of the traffic over the candidate assignments
+// -- first the written arrays (two: every pair, 0R2W), then the read ones over
+// what is left -- keep the best and free the rest.  A probe that cannot run
+// just means "in order".
 int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tune,
 		void **reads, void **writes, PlaceStats *stats)
 {
 	const size_t need = (size_t)(nread + nwrite);
 	const size_t bytes = (size_t)(words ? words : 1) * 4;
 	std::vector<void *> pool;
-	const size_t want = need + (tune ? (size_t)kPlaceSpare : 0);
-	// a spare candidate is taken only while as much again stays free (other
-	// shards or processes may share the device)
-	auto room_for_spare = [&] {
+	// spares: min(kPlaceSpare arrays, a tenth of the device's free memory once
+	// the needed arrays are there) -- other shards or processes may share the
+	// device
+	size_t spares = 0;
+	auto spare_budget = [&] {
 		size_t fr = 0, tot = 0;
 		if (!ok(hipMemGetInfo(&fr, &tot))) {
 			(void)hipGetLastError();
-			return false;
+			return (size_t)0;
 		}
-		return fr >= 2 * bytes;
+		const size_t by_bytes = (size_t)((double)fr * kPlaceSpareFreeShare) / bytes;
+		return by_bytes < (size_t)kPlaceSpare ? by_bytes : (size_t)kPlaceSpare;
 	};
+	const size_t want = need + (tune ? (size_t)kPlaceSpare : 0);
 	for (size_t k = 0; k < want; k++) {
 		void *p = nullptr;
-		if (k >= need && !room_for_spare())
+		if (k == need)
+			spares = spare_budget();
+		if (k >= need + spares)
 			break;
 		if (!ok(hipMalloc(&p, bytes))) {
 			(void)hipGetLastError();
@@ -361,34 +350,6 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		for (size_t i = 0; i < pool.size() && !failed; i++)
 			for (size_t j = i + 1; j < pool.size() && !failed; j++)
 				try_pair(i, j);
-		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
-		// (and bounded in bytes: a fresh hipMalloc costs 0.2-1 s per 4 GiB,
-		// and arrays of 16 GiB and more span several runs anyway)
-		size_t spare_max = (size_t)kPlaceSpareMaxSmall;
-		if (words >= kPlaceWideWords) {
-			const size_t by_bytes = (size_t)(kPlaceSpareBytes / bytes);
-			spare_max = by_bytes > (size_t)kPlaceSpareMax ? (size_t)kPlaceSpareMax
-				: by_bytes < (size_t)kPlaceSpareMaxSmall ? (size_t)kPlaceSpareMaxSmall
-				: by_bytes;
-		}
-		while (!failed && best > good && pool.size() < need + spare_max) {
-			void *p = nullptr;
-			if (!room_for_spare())
-				break;
-			if (!ok(hipMalloc(&p, bytes))) {
-				(void)hipGetLastError();
-				break;		// no room: make do with what there is
-			}
-			pool.push_back(p);
-			ps.candidates++;
-			// against a few of the others, spread over the pool (the early
-			// ones are the likeliest to share a run among themselves)
-			const size_t last = pool.size() - 1;
-			const size_t step = last > (size_t)kPlaceTryAgainst
-				? last / (size_t)kPlaceTryAgainst : 1;
-			for (size_t i = 0; i < last && !failed && best > good; i += step)
-				try_pair(i, last);
-		}
 		if (failed) {
 			(void)hipGetLastError();
 			ps = PlaceStats{};
@@ -446,40 +407,6 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		}
 		if (failed) { (void)hipGetLastError(); return finish(true); }
 		take(&reads[0], bi);
-		// Which array is READ matters most in a mixed stream (profiles/r03/
-		// hbm_vmm_probe.txt: rotating the roles over one triple gives 0.72 /
-		// 0.86 / 0.86).  While the job's full pattern stays under 0.845 of the
-		// peak, try up to kPlaceReadExtra fresh allocations in the read role,
-		// one at a time (a 4 GiB hipMalloc + three launches each), keeping
-		// only a better one.
-		const float good_mix = (float)((double)words * 12.0 / kPlaceGoodMixBytesPerMs);
-		const int read_extra = words >= kPlaceWideWords && bytes <= ((size_t)4 << 30)
-			? kPlaceReadExtra : kPlaceReadExtraSmall;
-		for (int extra = 0; extra < read_extra && best > good_mix
-				&& room_for_spare(); extra++) {
-			void *cand = nullptr;
-			if (!ok(hipMalloc(&cand, bytes))) {
-				(void)hipGetLastError();
-				break;
-			}
-			ps.candidates++;
-			const float ms = probe_ms(st, 1, 2, cand, nullptr, writes[0], writes[1],
-					words, queue);
-			if (ms < 0.f) {
-				(void)hipGetLastError();
-				(void)hipFree(cand);
-				break;
-			}
-			ps.probes++;
-			if (ms > worst) worst = ms;
-			if (ms < best) {
-				best = ms;
-				pool.push_back(reads[0]);	// the old one is freed with the rest
-				reads[0] = cand;
-			} else {
-				(void)hipFree(cand);
-			}
-		}
 	} else {
 		for (size_t i = 0; i < pool.size() && !failed; i++)
 			for (size_t j = i + 1; j < pool.size() && !failed; j++) {
@@ -745,8 +672,9 @@ int cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices
 	g->cfg = *cfg;
 	g->first = first_shard;
 	g->total = total_shards;
+	// off unless asked: cordic_group_set_placement, or CORDIC_GROUP_PLACEMENT=1
 	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
-		g->placement = !(e[0] == '0' && e[1] == 0);
+		g->placement = e[0] == '1' && e[1] == 0;
 	DeviceScope scope;
 	g->shards.resize((size_t)nlocal);
 	int rc = CORDIC_OK;
@@ -800,10 +728,10 @@ int cordic_arrays_alloc(size_t bytes, int n_read, int n_write, void **ptrs,
 	if (!ptrs || n_read < 0 || n_read > 2 || n_write < 1 || n_write > 2)
 		return CORDIC_ERR_ARGS;
 	const uint64_t words = ((uint64_t)bytes + 3) / 4;
-	bool tune = words >= kPlaceMinWords;
+	// plain hipMalloc unless CORDIC_GROUP_PLACEMENT=1 asks for the probes
+	bool tune = false;
 	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
-		if (e[0] == '0' && e[1] == 0)
-			tune = false;
+		tune = e[0] == '1' && e[1] == 0 && words >= kPlaceMinWords;
 	void *rd[2] = {nullptr, nullptr}, *wr[2] = {nullptr, nullptr};
 	if (int rc = alloc_placed(static_cast<hipStream_t>(stream), words, n_read, n_write,
 			tune, rd, wr, nullptr))

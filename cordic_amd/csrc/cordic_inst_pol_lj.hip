@@ -45,6 +45,32 @@ bool launch_pol_lj(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	}
 }
 
+// Job sets (CORDIC_JOBS_R2P): the 20-stage core of BASELINE config 3 and the
+// 29 stages gencordic derives for 24-bit ports on static instances, every
+// other count on the dynamic-exit one; unit gain: the jobs one by one.
+bool launch_pol_lj_jobs(int nlive, int grid, hipStream_t st,
+		const dev::CoreParams &kp, const TileDescXY *tiles, uint32_t ntiles)
+{
+	using namespace dev;
+	if (nlive < 1 || nlive > kDynStages || kp.post_mul != 0)
+		return false;
+	const bool plain = (32 - kp.iw) - kp.in_shl >= 2 && kp.r >= 2 && kp.r <= 31;
+	switch (plain ? nlive : -1) {
+	case 20:
+		hipLaunchKernelGGL((topolar_lj_jobs<20, false, true>), dim3(grid),
+			dim3(kBlock), 0, st, kp, tiles, ntiles);
+		return true;
+	case 29:
+		hipLaunchKernelGGL((topolar_lj_jobs<29, false, true>), dim3(grid),
+			dim3(kBlock), 0, st, kp, tiles, ntiles);
+		return true;
+	default:
+		hipLaunchKernelGGL((topolar_lj_jobs<kDynStages, true, false>), dim3(grid),
+			dim3(kBlock), 0, st, kp, tiles, ntiles);
+		return true;
+	}
+}
+
 // WW = 35 .. 40: one dynamic-exit instance per width (LJ = 64 - WW)
 namespace {
 template <int LJ>

@@ -278,11 +278,26 @@ struct TailDesc {		// 32 bytes, one SAMPLE (rotator_job_tails)
 	uint64_t ox, oy;
 	uint64_t pad;
 };
+// Round 6: the data-fed kernels' jobs (CORDIC_JOBS_R2P / _P2R_XY / _MIX): up
+// to three inputs and two outputs per tile.  r2p: in0 = i_xval, in1 = i_yval,
+// o0 = o_mag, o1 = o_phase; p2r with per-sample vectors: in2 = address of the
+// tile's first i_phase word; mixer: in2 = {high: fcw, low: phase of the tile's
+// first sample}, both left-justified (as TileDesc::in of an NCO job).
+struct TileDescXY {		// 48 bytes (topolar_lj_jobs, rotator_xydir<.., JOBS>)
+	uint64_t in0, in1, in2;
+	uint64_t o0, o1;
+	uint32_t live;		// whole vectors (4 samples) of the tile; for a
+	uint32_t pad;		//   TAIL entry (one sample): unused
+};
 constexpr uint32_t kJobTileVecs = CORDIC_SEED_BLOCK * 2;	// = dev::kSeedBlock * kSeedSub
+// tiles of the data-fed kinds: whole passes of a 256-thread block (256 vectors),
+// at most as long as the seeded kernels' tiles, shorter for small sets so that
+// every CU still gets several blocks' worth (cordic_abi.cpp: xy_tile_vecs)
+constexpr uint32_t kJobPassVecs = 256;
 struct JobTables {
-	const uint32_t *tiles = nullptr;	// device: ntiles x TileDesc
+	const uint32_t *tiles = nullptr;	// device: ntiles x TileDesc (TileDescXY)
 	uint32_t ntiles = 0;
-	const uint32_t *tails = nullptr;	// device: ntails x TailDesc
+	const uint32_t *tails = nullptr;	// device: ntails x TailDesc (TileDescXY)
 	uint32_t ntails = 0;
 	uint64_t samples = 0;			// of all jobs
 };
@@ -330,6 +345,12 @@ int	launch_rotator(const cordic_config &cfg, Feed feed, const RotatorJob &job,
 // constant vector and the queue.  CORDIC_ERR_UNSUPPORTED: this core has no
 // seeded kernel -- the caller then runs the jobs one by one.
 int	launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &job,
+		const JobTables &tabs, void *stream);
+// the data-fed kinds of a job set in ONE launch (+ one for trailing samples):
+// kind = CORDIC_JOBS_R2P / _P2R_XY / _MIX, tabs of TileDescXY; `job` carries a
+// rotator plan's direction tables.  CORDIC_ERR_UNSUPPORTED: no tile-reading
+// instance for this core -- the caller runs the jobs one by one.
+int	launch_xy_jobs(const cordic_config &cfg, int kind, const RotatorJob &job,
 		const JobTables &tabs, void *stream);
 int	launch_topolar(const cordic_config &cfg, size_t n, const int32_t *x,
 		const int32_t *y, int32_t *mag, uint32_t *phase, void *stream,

@@ -269,6 +269,33 @@ __global__ __launch_bounds__(kBlock) void rotator_generic(CoreParams kp,
 	}
 }
 
+// one sample of rtl/topolar.v:122-152, 217-243, 251-271, literally
+__device__ __forceinline__ void generic_topolar(const CoreParams &kp, int32_t ix,
+		int32_t iy, int32_t &mag, uint32_t &ph)
+{
+	const int64_t ex = (int64_t)((uint64_t)(int64_t)ix << kp.in_shl);
+	const int64_t ey = (int64_t)((uint64_t)(int64_t)iy << kp.in_shl);
+	int64_t x, y;
+	uint32_t p;
+	fold_quadrant<int64_t>(ex, ey, ix < 0, iy < 0, x, y, p);
+	x = wrap_ww(x, kp);
+	y = wrap_ww(y, kp);
+	for (int s = 0; s < kp.nlive; s++) {
+		const int k = (s + 1 > 63) ? 63 : s + 1;
+		const uint32_t a = kp.angle[s];
+		const int64_t sy = y >> k, sx = x >> k;
+		if (y < 0) {
+			x = x - sy; y = y + sx; p -= a;
+		} else {
+			x = x + sy; y = y - sx; p += a;
+		}
+		x = wrap_ww(x, kp);
+		y = wrap_ww(y, kp);
+	}
+	mag = round_generic(x, kp);
+	ph = p >> kp.pw_shl;
+}
+
 template <typename IO = Io32>
 __global__ __launch_bounds__(kBlock) void topolar_generic(CoreParams kp,
 		const typename IO::ielem *__restrict__ xin,
@@ -279,30 +306,39 @@ __global__ __launch_bounds__(kBlock) void topolar_generic(CoreParams kp,
 	const size_t stride = (size_t)gridDim.x * kBlock;
 	for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
 			i += stride) {
-		const int32_t ix = sext32(xin[i], kp.iw);
-		const int32_t iy = sext32(yin[i], kp.iw);
-		const int64_t ex = (int64_t)((uint64_t)(int64_t)ix << kp.in_shl);
-		const int64_t ey = (int64_t)((uint64_t)(int64_t)iy << kp.in_shl);
-		int64_t x, y;
-		uint32_t p;
-		fold_quadrant<int64_t>(ex, ey, ix < 0, iy < 0, x, y, p);
-		x = wrap_ww(x, kp);
-		y = wrap_ww(y, kp);
-		for (int s = 0; s < kp.nlive; s++) {
-			const int k = (s + 1 > 63) ? 63 : s + 1;
-			const uint32_t a = kp.angle[s];
-			const int64_t sy = y >> k, sx = x >> k;
-			if (y < 0) {
-				x = x - sy; y = y + sx; p -= a;
-			} else {
-				x = x + sy; y = y - sx; p += a;
-			}
-			x = wrap_ww(x, kp);
-			y = wrap_ww(y, kp);
-		}
-		omag[i] = (typename IO::ielem)round_generic(x, kp);
-		oph[i] = (typename IO::uelem)(p >> kp.pw_shl);
+		int32_t mag;
+		uint32_t ph;
+		generic_topolar(kp, sext32(xin[i], kp.iw), sext32(yin[i], kp.iw), mag, ph);
+		omag[i] = (typename IO::ielem)mag;
+		oph[i] = (typename IO::uelem)ph;
 	}
+}
+
+// The samples behind a job's last whole vector for the data-fed kinds of a
+// job set (round 6): one lane per sample, one TileDescXY per sample.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void xy_job_tails(CoreParams kp,
+		const TileDescXY *__restrict__ t, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const TileDescXY d = t[i];
+	const int32_t ix = sext32(*reinterpret_cast<const int32_t *>((uintptr_t)d.in0), kp.iw);
+	const int32_t iy = sext32(*reinterpret_cast<const int32_t *>((uintptr_t)d.in1), kp.iw);
+	int32_t a;
+	uint32_t b;
+	if constexpr (KIND == CORDIC_JOBS_R2P) {
+		generic_topolar(kp, ix, iy, a, b);
+	} else {
+		const uint32_t P = KIND == CORDIC_JOBS_MIX ? (uint32_t)d.in2
+			: *reinterpret_cast<const uint32_t *>((uintptr_t)d.in2) << kp.pw_shl;
+		int32_t ry;
+		generic_rotate(kp, P, ix, iy, a, ry);
+		b = (uint32_t)ry;
+	}
+	*reinterpret_cast<int32_t *>((uintptr_t)d.o0) = a;
+	*reinterpret_cast<uint32_t *>((uintptr_t)d.o1) = b;
 }
 
 // ------------------------------------------------------ test-input kernels
@@ -1096,6 +1132,75 @@ int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j
 		else
 			hipLaunchKernelGGL(rotator_job_tails<Feed::PhaseArray_ConstXY>,
 				dim3(blocks), dim3(kBlock), 0, st, kp, t, tabs.ntails);
+		return check_launch();
+	}
+	return CORDIC_OK;
+}
+
+int launch_xy_jobs(const cordic_config &cfg, int kind, const RotatorJob &j,
+		const JobTables &tabs, void *stream)
+{
+	clear_stale_error();
+	const bool pol = kind == CORDIC_JOBS_R2P;
+	if (!config_sane(cfg))
+		return CORDIC_ERR_ARGS;
+	if (pol != (cfg.mode == CORDIC_R2P || cfg.mode == CORDIC_SR2P))
+		return CORDIC_ERR_MODE;
+	if (tabs.samples == 0)
+		return CORDIC_OK;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	CoreParams kp = make_params(cfg);
+	kp.xy_nco = kind == CORDIC_JOBS_MIX ? 1u : 0u;
+	const TileDescXY *tiles = reinterpret_cast<const TileDescXY *>(tabs.tiles);
+	if (tabs.ntiles) {
+		// the conditions of the single-call fast paths (launch_topolar:
+		// topolar_lj; launch_rot_feed: rotator_xydir), minus the batch-size
+		// thresholds -- a job set is one big batch
+		if ((cfg.flags & (CORDIC_FLAG_FORCE_GENERIC | CORDIC_FLAG_NO_LJ))
+				|| cfg.needs_wrap || cfg.nlive < 1)
+			return CORDIC_ERR_UNSUPPORTED;
+		const int cus = cus_of_current_device();
+		if (cus < 0)
+			return CORDIC_ERR_DEVICE;
+		const uint32_t cap = (uint32_t)cus * 8u;	// resident blocks
+		const int grid = (int)(tabs.ntiles < cap ? tabs.ntiles : cap);
+		bool done = false;
+		if (pol) {
+			if (cfg.ww <= 34)
+				done = launch_pol_lj_jobs(cfg.nlive, grid, st, kp, tiles, tabs.ntiles);
+			if (done)
+				g_last_kernel = CORDIC_KERNEL_LEFT_JUSTIFIED;
+		} else if (j.dir_table && j.dx.n > 0 && kp.post_mul == 0 && kp.in_shl >= 1
+				&& kp.in_shl <= 30 && cfg.ww <= 35
+				&& !(cfg.flags & CORDIC_FLAG_NO_TAILS)) {
+			dev::DirArgs da{j.dir_table, j.dx};
+			const size_t lds = dev::dx_lds_layout(j.dx, nullptr, nullptr);
+			if (lds <= 64 * 1024)
+				done = cfg.ww == 35
+					? launch_xydir_jobs_lj29(cfg.nlive, grid, st, kp, da, tiles,
+						tabs.ntiles, lds)
+					: launch_xydir_jobs_lj30(cfg.nlive, grid, st, kp, da, tiles,
+						tabs.ntiles, lds);
+			if (done)
+				g_last_kernel = CORDIC_KERNEL_DIRECTIONS;
+		}
+		if (!done)
+			return CORDIC_ERR_UNSUPPORTED;
+		if (int rc = check_launch())
+			return rc;
+	}
+	if (tabs.ntails) {
+		const unsigned blocks = (tabs.ntails + kBlock - 1) / kBlock;
+		const TileDescXY *t = reinterpret_cast<const TileDescXY *>(tabs.tails);
+		if (kind == CORDIC_JOBS_R2P)
+			hipLaunchKernelGGL(xy_job_tails<CORDIC_JOBS_R2P>, dim3(blocks),
+				dim3(kBlock), 0, st, kp, t, tabs.ntails);
+		else if (kind == CORDIC_JOBS_MIX)
+			hipLaunchKernelGGL(xy_job_tails<CORDIC_JOBS_MIX>, dim3(blocks),
+				dim3(kBlock), 0, st, kp, t, tabs.ntails);
+		else
+			hipLaunchKernelGGL(xy_job_tails<CORDIC_JOBS_P2R_XY>, dim3(blocks),
+				dim3(kBlock), 0, st, kp, t, tabs.ntails);
 		return check_launch();
 	}
 	return CORDIC_OK;

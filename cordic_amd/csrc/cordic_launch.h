@@ -60,10 +60,20 @@ namespace dev { struct DirArgs; }
 		const dev::DirArgs &da, const RotatorJob &j, size_t lds)
 CORDIC_XYDIR_LAUNCHER(launch_xydir_lj29);	// WW == 35
 CORDIC_XYDIR_LAUNCHER(launch_xydir_lj30);	// WW <= 34
+// ... and their tile-reading forms (cordic_jobset: CORDIC_JOBS_P2R_XY / _MIX)
+#define CORDIC_XYDIR_JOBS_LAUNCHER(NAME) \
+	bool NAME(int nlive, int grid, hipStream_t st, const dev::CoreParams &kp, \
+		const dev::DirArgs &da, const TileDescXY *tiles, uint32_t ntiles, \
+		size_t lds)
+CORDIC_XYDIR_JOBS_LAUNCHER(launch_xydir_jobs_lj29);
+CORDIC_XYDIR_JOBS_LAUNCHER(launch_xydir_jobs_lj30);
 CORDIC_POL_LAUNCHER(launch_pol_narrow);
 // WW <= 32, no reachable overflow: left-justified form, 7 instructions per
 // micro-rotation (cordic_device.h: topolar_lj)
 CORDIC_POL_LAUNCHER(launch_pol_lj);
+// its tile-reading form (cordic_jobset: CORDIC_JOBS_R2P)
+bool launch_pol_lj_jobs(int nlive, int grid, hipStream_t st,
+		const dev::CoreParams &kp, const TileDescXY *tiles, uint32_t ntiles);
 CORDIC_POL_LAUNCHER(launch_pol_ljw);
 CORDIC_POL_LAUNCHER(launch_pol_wide8);
 CORDIC_POL_LAUNCHER(launch_pol_wideall);

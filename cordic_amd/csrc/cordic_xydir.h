@@ -72,11 +72,18 @@ __device__ __forceinline__ void rot_stage_lj_early_dir(int64_t &x, int64_t &y,
 	op_mad(y, xr, s);
 }
 
-template <int LJ, int NLIVE>
+// JOBS (round 6; cordic_jobset, CORDIC_JOBS_P2R_XY / CORDIC_JOBS_MIX): the
+// arrays are not one stretch but `ntiles` tiles of many jobs, described by the
+// host (cordic_internal.h: TileDescXY); block b stages its tables ONCE and
+// then sweeps tiles b, b + gridDim.x, ... -- the per-call arguments xin .. nvec
+// are unused, and a mixer tile's accumulator starts from the descriptor's
+// {fcw, phase} pair instead of kp.phase0 / fcw / index0.
+template <int LJ, int NLIVE, bool JOBS = false>
 __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs da,
-		const i32x4g *__restrict__ xin, const i32x4g *__restrict__ yin,
-		const u32x4g *__restrict__ phin, i32x4g *__restrict__ ox,
-		i32x4g *__restrict__ oy, size_t nvec)
+		const i32x4g *__restrict__ xin_, const i32x4g *__restrict__ yin_,
+		const u32x4g *__restrict__ phin_, i32x4g *__restrict__ ox_,
+		i32x4g *__restrict__ oy_, size_t nvec_,
+		const TileDescXY *__restrict__ tiles, uint32_t ntiles)
 {
 	static_assert(LJ == 29 || LJ == 30, "WW <= 35 cores");
 	constexpr int kN = dx_levels(NLIVE);
@@ -150,12 +157,16 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 	const uint32_t k45 = vgpr_const(0x20000000u);
 	const bool full_ports = kp.iw == 32;	// wave-uniform: no sign extension
 
-	const size_t stride = (size_t)gridDim.x * kBlock;
-	size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-	// software prefetch, as in rotator_unrolled
 	// the mixer (cordic_plan_mix, round 5): the phases are not read but
 	// generated, phase0 + (index0 + i) * fcw -- wave-uniform choice
 	const bool gen_phase = kp.xy_nco != 0;
+	// one contiguous stretch: vectors g, g + stride, ... < nvec; a mixer's
+	// phase of vector g is acc0 + 4 g fcw (+ v fcw for its samples)
+	auto sweep = [&](const i32x4g *__restrict__ xin, const i32x4g *__restrict__ yin,
+			const u32x4g *__restrict__ phin, i32x4g *__restrict__ ox,
+			i32x4g *__restrict__ oy, const size_t nvec, size_t g,
+			const size_t stride, const uint32_t acc0, const uint32_t fcw) {
+	// software prefetch, as in rotator_unrolled
 	u32x4 nph{};
 	i32x4 nx{}, ny{};
 	if (g < nvec) {
@@ -183,11 +194,10 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 		}
 		uint32_t pb[kVec];
 		if (gen_phase) {
-			const uint32_t s0 = (uint32_t)(kp.index0 + g * kVec);
-			pb[0] = (kp.phase0 + 0x20000000u) + s0 * kp.fcw;
+			pb[0] = (acc0 + 0x20000000u) + (uint32_t)(g * kVec) * fcw;
 #pragma unroll
 			for (int v = 1; v < kVec; v++)
-				pb[v] = pb[v - 1] + kp.fcw;
+				pb[v] = pb[v - 1] + fcw;
 		} else {
 #pragma unroll
 			for (int v = 0; v < kVec; v++)
@@ -345,6 +355,23 @@ __global__ __launch_bounds__(kBlock) void rotator_xydir(CoreParams kp, DirArgs d
 		}
 		CORDIC_STORE_OUT(true, &ox[g], rx);
 		CORDIC_STORE_OUT(true, &oy[g], ry);
+	}
+	};	// sweep
+	if constexpr (!JOBS) {
+		sweep(xin_, yin_, phin_, ox_, oy_, nvec_,
+			(size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock,
+			kp.phase0 + (uint32_t)kp.index0 * kp.fcw, kp.fcw);
+	} else {
+		for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+			const TileDescXY d = tiles[t];
+			sweep(reinterpret_cast<const i32x4g *>((uintptr_t)d.in0),
+				reinterpret_cast<const i32x4g *>((uintptr_t)d.in1),
+				reinterpret_cast<const u32x4g *>((uintptr_t)d.in2),
+				reinterpret_cast<i32x4g *>((uintptr_t)d.o0),
+				reinterpret_cast<i32x4g *>((uintptr_t)d.o1),
+				(size_t)d.live, (size_t)threadIdx.x, (size_t)kBlock,
+				(uint32_t)d.in2, (uint32_t)(d.in2 >> 32));
+		}
 	}
 }
 

@@ -368,7 +368,7 @@ int	cordic_plan_nco(const cordic_plan *plan, size_t n,
 
 /* ------------------------------------------------------------ job sets
  *
- * Many SMALL jobs in one launch (round 5).  A launch costs ~10-20 us whatever
+ * Many SMALL jobs in one launch (round 5; data-fed kinds round 6).  A launch costs ~10-20 us whatever
  * it computes -- the runtime's dispatch, staging the seed table, filling and
  * draining 256 CUs -- which is the whole run time of a 2^16-sample job: an NCO
  * bank or a channeliser that hands the engine a thousand short blocks gets a
@@ -384,20 +384,50 @@ int	cordic_plan_nco(const cordic_plan *plan, size_t n,
  * state), on any stream, with any constant vector, and inside a HIP graph
  * capture; cordic_plan_*_batch are the one-shot forms (table built, uploaded
  * with a blocking copy, run, freed once the launch has passed: they cost a
- * host-side ~50 us per call more).  kind: the jobs' phases are ARRAYS
- * (cordic_plan_p2r_const per job: d_phase) or generated (cordic_plan_nco per
- * job: phase0, fcw, index0).  Results: bit for bit those of the per-job calls.
+ * host-side ~50 us per call more, and -- because they allocate and copy -- are
+ * NOT legal while `stream` is being captured: CORDIC_ERR_UNSUPPORTED; capture
+ * cordic_plan_run_jobs on a set made beforehand instead).  A set belongs to the
+ * plan's core and to the device that was current when it was cut
+ * (CORDIC_ERR_ARGS from cordic_plan_run_jobs otherwise).
+ *
+ * kind says where a job's inputs come from:
+ *   CORDIC_JOBS_PHASE_ARRAYS  cordic_plan_p2r_const per job: d_phase
+ *   CORDIC_JOBS_NCO           cordic_plan_nco per job: phase0, fcw, index0
+ * and, since round 6, the DATA-FED calls (what a channeliser hands over:
+ * blocks of I/Q samples; xval / yval of cordic_plan_run_jobs are ignored):
+ *   CORDIC_JOBS_R2P           cordic_r2p per job (rtl/topolar.v:59-64, driven
+ *                             per sample at bench/cpp/topolar_tb.cpp:127-147):
+ *                             d_xval, d_yval -> d_oxval = o_mag, d_oyval =
+ *                             o_phase (as uint32_t); the plan is one of an r2p /
+ *                             sr2p core
+ *   CORDIC_JOBS_P2R_XY        cordic_plan_p2r per job (rtl/cordic.v:58-63 with
+ *                             all three ports live): d_xval, d_yval, d_phase
+ *   CORDIC_JOBS_MIX           cordic_plan_mix per job: d_xval, d_yval rotated by
+ *                             phase0 + (index0 + i) * fcw
+ * These are cut into tiles of 256 .. 2048 whole vectors (shorter tiles for
+ * small sets, so that every CU gets several blocks) and run as ONE launch of
+ * the tile-reading instance of the call's own kernel (topolar_lj, rotator_xydir;
+ * + one small launch for trailing samples).  Tile-reading instances exist for
+ * the left-justified converter (WW <= 34, no reachable overflow, no unit gain:
+ * static for 20 and 29 stages, dynamic-exit otherwise) and for the looked-up-
+ * direction rotator at WW 35 with 16 / 24 / 29 stages and WW <= 34 with 16 / 19
+ * / 27; every other core runs its jobs one by one behind the same call.
+ * Results: bit for bit those of the per-job calls.
  * Cores without a table-seeded kernel (WW > 35, fewer than 11 live stages,
- * CORDIC_FLAG_NO_SEED) run the jobs one by one behind the same call.
+ * CORDIC_FLAG_NO_SEED) run constant-vector jobs one by one behind the same call.
  */
 typedef struct cordic_job {
-	const uint32_t *d_phase;	/* CORDIC_JOBS_PHASE_ARRAYS: n words    */
-	uint32_t phase0, fcw;		/* CORDIC_JOBS_NCO: phase0 +            */
+	const uint32_t *d_phase;	/* PHASE_ARRAYS, P2R_XY: n words        */
+	uint32_t phase0, fcw;		/* NCO, MIX: phase0 +                   */
 	uint64_t index0;		/*   (index0 + i) * fcw  (mod 2^PW)     */
-	int32_t	*d_oxval, *d_oyval;	/* n words each                         */
+	int32_t	*d_oxval, *d_oyval;	/* n words each (R2P: o_mag, o_phase)   */
 	uint64_t n;			/* samples                              */
+	const int32_t *d_xval, *d_yval;	/* R2P, P2R_XY, MIX: n words each       */
 } cordic_job;
-enum cordic_jobs_kind { CORDIC_JOBS_PHASE_ARRAYS = 0, CORDIC_JOBS_NCO = 1 };
+enum cordic_jobs_kind {
+	CORDIC_JOBS_PHASE_ARRAYS = 0, CORDIC_JOBS_NCO = 1,
+	CORDIC_JOBS_R2P = 2, CORDIC_JOBS_P2R_XY = 3, CORDIC_JOBS_MIX = 4
+};
 typedef struct cordic_jobset cordic_jobset;
 int	cordic_jobset_create(const cordic_plan *plan, int kind, size_t njobs,
 		const cordic_job *jobs, cordic_jobset **set);
@@ -412,6 +442,13 @@ int	cordic_plan_p2r_const_batch(const cordic_plan *plan, size_t njobs,
 		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream);
 int	cordic_plan_nco_batch(const cordic_plan *plan, size_t njobs,
 		const cordic_job *jobs, int32_t xval, int32_t yval, void *stream);
+/* the one-shot forms of the data-fed kinds */
+int	cordic_plan_r2p_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream);
+int	cordic_plan_p2r_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream);
+int	cordic_plan_mix_batch(const cordic_plan *plan, size_t njobs,
+		const cordic_job *jobs, void *stream);
 /* waits for and frees what the one-shot forms still hold (they free it
  * themselves, lazily, on later calls) */
 void	cordic_jobset_reap(void);
@@ -710,33 +747,37 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
  * Back-to-back jobs need no cordic_group_sync between them, also with
  * forwarding set: a job's kernels wait (in stream order, on the device) until
  * the previous job's pieces have left out0 / out1. */
-/* Placement of the shards' arrays.  What HBM delivers to a job's streams
- * depends on which allocations they run over: allocations come in CLASSES
- * (profiles/r05/pair_matrix.txt) -- two arrays of one class written together
- * run at 0.73-0.81 of the 8 TB/s peak, two of different classes at 0.93-0.95,
- * single arrays all alike; consecutive hipMallocs share a class in runs of
- * 2-16, nothing in the addresses shows it, and it holds for the arrays'
- * lifetime.  When a group allocates arrays of 64 MiB or more it therefore
- * allocates two more than it needs, times an arithmetic-free twin of the
- * job's traffic over the candidate role assignments (tens of milliseconds,
- * once per allocation), keeps the fastest and frees the rest.  While no pair
- * of written arrays reaches 0.93 of the peak it takes more candidates, each
- * tried against three of those at hand -- up to 24 for arrays of 512 MiB and
- * up (a box whose first allocations are one long run: up to a second, once),
- * 4 below -- and while a 1R2W job's full pattern stays under 0.845 up to ten
- * (six) more in the READ role, one at a time; spares are taken only while as
- * much memory again stays free.
- * On by default; cordic_group_set_placement(grp, 0) before the first
- * reserve / job call, or CORDIC_GROUP_PLACEMENT=0 in the environment, takes
- * the arrays as hipMalloc hands them out.  cordic_group_placement reports
- * what the last allocation of a shard saw: candidate arrays, probes run, the
- * times of the best and the worst pair of written arrays (0R2W) and, with
- * those chosen, of the best and the worst choice of the read arrays (the
- * job's full pattern); 0 candidates: not tuned. */
+/* Placement of the shards' arrays (OFF unless asked).  What HBM delivers to a
+ * job's streams depends on which allocations they run over: allocations come
+ * in CLASSES (profiles/r05/pair_matrix.txt) -- two arrays of one class written
+ * together run at 0.73-0.81 of the 8 TB/s peak, two of different classes at
+ * 0.93-0.95, single arrays all alike; nothing in the addresses shows it, and it
+ * holds for the arrays' lifetime.  A caller that wants the last ~5 % of a
+ * write-heavy job can ask the group to choose:
+ *   cordic_group_set_placement(grp, 1)  before the first reserve / job call, or
+ *   CORDIC_GROUP_PLACEMENT=1            in the environment (also read by
+ *                                        cordic_arrays_alloc).
+ * The group then allocates, for arrays of 64 MiB or more, up to TWO arrays more
+ * than it needs -- never more than a tenth of the memory that is free on the
+ * device at that moment -- times an arithmetic-free twin of the job's traffic
+ * over the candidate role assignments (10 + 3 launches for a 1R2W job: ~60 ms
+ * at 4 GiB per array, plus the two extra hipMallocs, 0.2-1 s each at that
+ * size), keeps the fastest and frees the rest before the call returns.  Cost,
+ * once per (re)allocation: that time, and 2 x the array size of HBM held for
+ * its duration.  Without it -- the default -- the arrays are what hipMalloc
+ * hands out, nothing is probed and nothing extra is allocated.
+ * cordic_group_placement reports what the last allocation of a shard saw:
+ * candidate arrays, probes run, the times of the best and the worst pair of
+ * written arrays (0R2W) and, with those chosen, of the best and the worst
+ * choice of the read arrays (the job's full pattern); 0 candidates: not tuned.
+ * (Rounds 4-5 had this on by default and kept taking candidates, up to 24,
+ * while no written pair was fast; bench.py still turns it on for its own
+ * arrays and says so in its line: roofline.placement.) */
 int	cordic_group_set_placement(cordic_group *grp, int enable);
 /* The same for callers of the stateless entry points: n_read (0..2) +
- * n_write (1..2) arrays of `bytes` bytes each on the current device, placed as
- * above (arrays under 64 MiB: plain hipMalloc); ptrs receives the read arrays
+ * n_write (1..2) arrays of `bytes` bytes each on the current device: plain
+ * hipMalloc, or -- with CORDIC_GROUP_PLACEMENT=1 in the environment and arrays
+ * of 64 MiB and more -- placed as above; ptrs receives the read arrays
  * first, then the written ones.  Synchronises `stream`, on which the probes
  * run.  cordic_arrays_free releases them (plain hipFree would do). */
 int	cordic_arrays_alloc(size_t bytes, int n_read, int n_write, void **ptrs,

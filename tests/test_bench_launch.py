@@ -15,7 +15,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+_DETAIL_N = [0]
+
+
+def _detail_path():
+    """a fresh --detail path per run (the default, ./bench_detail.json, is for
+    the driver's single run)"""
+    import tempfile
+    _DETAIL_N[0] += 1
+    return os.path.join(tempfile.gettempdir(), "bench_detail_test_%d_%d.json"
+                        % (os.getpid(), _DETAIL_N[0]))
+
+
 def run(args, env=None, timeout=600):
+    if "--detail" not in args:
+        args = list(args) + ["--detail", _detail_path()]
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         e.pop(k, None)
@@ -92,16 +106,163 @@ def test_launch_decisions_and_respawn_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def _line(stdout):
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_line  # noqa: E402
+
+
+def _line(stdout, want_detail=True):
     """The contract: stdout carries ONE line, the JSON record -- nothing else
-    (RCCL's version banner and the like go to stderr)."""
+    (RCCL's version banner and the like go to stderr) -- of at most 4 KB,
+    strict JSON, with the contract keys (bench_line.check).  Returns the
+    DETAIL record the line points to (what the line is a selection of), after
+    checking that the line agrees with it."""
     rows = [ln for ln in stdout.splitlines() if ln.strip()]
     assert len(rows) == 1 and rows[0].startswith("{"), stdout
-    return json.loads(rows[0])
+    line = bench_line.check(rows[0])
+    if not want_detail:
+        return line
+    with open(line["detail"]) as f:
+        d = json.load(f)
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step"):
+        assert line[k] == pytest.approx(d[k], rel=1e-5), k
+    assert line["roofline"]["frac"] == pytest.approx(d["roofline"]["frac"], rel=1e-5)
+    assert line["config"]["samples_per_gpu"] == d["config"]["samples_per_gpu"]
+    d["_line"] = line
+    return d
+
+
+def test_the_line_of_round_fives_records_fits():
+    """bench_line.render on the records that were LOST in round 5 (the 20.7 KB
+    default line the driver could not parse, and the 8-rank line): at most
+    4 KB, strict JSON, contract keys, `roofline` and `cpu_baseline` there as
+    numbers and tokens."""
+    seen = 0
+    for rel in ("profiles/bench_r05/default_driver_order.json",
+                "profiles/bench_r05/default.json",
+                "profiles/r05/bench_8_ranks_one_gpu.json"):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            text = [ln for ln in f.read().splitlines() if ln.startswith("{")][-1]
+        old = json.loads(text)
+        seen += 1
+        out = bench_line.render(old, "bench_detail.json")
+        assert len(out.encode()) <= 4096 < len(text), (rel, len(out))
+        line = bench_line.check(out)
+        assert line["value"] == pytest.approx(old["value"], rel=1e-5)
+        r = line["roofline"]
+        assert r["frac"] == pytest.approx(old["roofline"]["frac"], rel=1e-5)
+        assert set(r) <= set(bench_line.ROOF)
+        assert r["limiter"] in ("power", "hbm", "valu", "latency")
+        assert r["placement"] in ("on", "off")
+        for v in r.values():
+            assert v is None or isinstance(v, (int, float)) or len(v) <= 16
+        if "cpu_baseline" in old:
+            c = line["cpu_baseline"]
+            assert c["cores"] == old["cpu_baseline"]["cores"]
+            assert len(c["sample"]) <= 96
+        if old["n_gpus"] > 1:
+            sc = line["scale"]
+            assert sc["compute_only"] == pytest.approx(old["value"], rel=1e-5)
+            for v in sc.values():
+                assert v is None or isinstance(v, float)
+    assert seen, "no committed round-5 record found"
+
+
+def test_the_line_is_strict_json_and_shrinks_rather_than_overflows():
+    inf = float("inf")
+    detail = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1,
+              "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+              "data": "synthetic",
+              "config": {"workload": "w" * 5000, "kernel": "k" * 5000,
+                         "samples_per_gpu": 1},
+              "roofline": {"bound": "hbm", "achieved": float("nan"), "peak": 8000.0,
+                           "unit": "GB/s", "frac": inf, "traffic": None,
+                           "limiter": "power: a long sentence " * 50,
+                           "power": {"x": ["y" * 100] * 100}},
+              "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 1, "kind": "port",
+                               "sample": "s" * 5000, "cpu": "c" * 500}}
+    out = bench_line.render(detail, "/tmp/x.json")
+    assert len(out) <= 4096
+    line = bench_line.check(out)            # NaN / Infinity would raise here
+    assert line["roofline"]["achieved"] is None and line["roofline"]["frac"] is None
+    assert line["roofline"]["limiter"] == "power"
+    assert "power" not in line["roofline"]
+    with pytest.raises(ValueError):
+        bench_line.check('{"value": NaN}')
+    with pytest.raises(ValueError):
+        bench_line.check("{" + '"a": 1, ' * 1000 + '"b": 2}')
+
+
+def test_the_detail_file_is_written_atomically_and_never_over_devnull(tmp_path):
+    p = tmp_path / "d.json"
+    assert bench_line.write_detail({"a": float("nan"), "b": [1, 2]}, str(p)) == str(p)
+    assert json.loads(p.read_text()) == {"a": None, "b": [1, 2]}
+    before = os.stat(os.devnull)
+    assert bench_line.write_detail({"a": 1}, os.devnull) is None
+    after = os.stat(os.devnull)             # not replaced by a regular file
+    assert (before.st_ino, before.st_mode) == (after.st_ino, after.st_mode)
+    # an unwritable place falls back to /tmp and says where
+    got = bench_line.write_detail({"a": 1}, "/proc/nope/bench_detail_test.json")
+    assert got == "/tmp/bench_detail_test.json"
+    os.unlink(got)
 
 
 SMALL = ["--steps", "5", "--warmup", "1", "--log2-samples", "22",
          "--no-cpu-baseline", "--no-other-paths", "--no-pmc", "--no-power"]
+
+
+@pytest.mark.gpu
+def test_the_drivers_default_command_prints_one_small_line_quickly(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` exactly as the driver
+    runs it (cwd = the repo, no other flag): ONE line of at most 4 KB with
+    `roofline` (traffic measured by this run's counter passes) and
+    `cpu_baseline`, the full record in ./bench_detail.json, and all of it
+    inside a minute (round 5: 20.7 KB after 116 s, lost)."""
+    import shutil
+    import time
+    e = {k: v for k, v in os.environ.items()
+         if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CORDIC_SEED_MIN_SAMPLES")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "20",
+                        "--warmup", "5"], cwd=ROOT, env=e, text=True, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(rows) == 1
+    line = bench_line.check(rows[0])
+    assert wall < 60.0, (wall, line.get("wall_s"))
+    assert line["detail"] == "bench_detail.json"
+    with open(os.path.join(ROOT, "bench_detail.json")) as f:
+        d = json.load(f)
+    assert d["value"] == pytest.approx(line["value"], rel=1e-5)
+    assert line["metric"].startswith("Msamples/sec (sin+cos pairs) at 16-stage/32-bit")
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["config"]["samples_per_gpu"] == 1 << 30
+    assert line["digest_check"] == {"samples": 1 << 30, "equal": True}
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "valu") and roof["peak"] == 8000.0
+    assert roof["placement"] == "on"
+    assert roof["limiter"] in ("power", "hbm", "valu", "latency")
+    assert 0.3 < roof["frac"] < 1.0
+    if shutil.which("rocprofv3"):
+        assert 0.99 < roof["traffic_over_algorithmic"] < 1.02
+        assert roof["traffic"] == pytest.approx(
+            12.0 * (1 << 30) * roof["traffic_over_algorithmic"], rel=1e-4)
+        assert 30 < d["roofline"]["valu"]["instr_per_sample"] < 60
+        assert d["roofline"]["pmc"]["subject"] == "pmc_subject"
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert 0 < cpu["value_1thread"] <= cpu["value"] * 1.05
+    full = line["full_recurrence"]
+    assert 0 < full["value_per_gpu"] < line["value"]
+    assert d["full_recurrence_kernel"]["outputs_identical_to_seeded_kernel"] is True
+    # where the time of the command went, phase by phase (detail file)
+    assert sum(d["phases_s"].values()) <= d["wall_s"] + 0.5
+    assert "other_paths" not in d               # that is --full
 
 
 @pytest.mark.gpu
@@ -156,7 +317,7 @@ def test_multi_process_run_also_measures_the_one_process_layer():
 @pytest.mark.gpu
 def test_single_process_path_and_direct_agree():
     a = _line(run(["--gpus", "1", "--single-process"] + SMALL).stdout)
-    b = _line(run(["--gpus", "1"] + SMALL).stdout)
+    b = _line(run(["--gpus", "1", "--copy-probe"] + SMALL).stdout)
     assert a["n_gpus"] == b["n_gpus"] == 1
     assert a["digest"] == b["digest"]
     assert a["bit_exact_vs_oracle"] and b["bit_exact_vs_oracle"]
@@ -317,7 +478,7 @@ def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
            "--master-port", str(_free_port()), BENCH, "--gpus", str(ranks),
            "--workload", workload, "--steps", "4", "--warmup", "1",
            "--log2-samples", str(lg), "--no-cpu-baseline", "--no-other-paths",
-           "--no-pmc", "--no-power", "--no-copy-probe"]
+           "--no-pmc", "--no-power", "--no-copy-probe", "--detail", _detail_path()]
     r = subprocess.run(cmd, env=e, text=True, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -393,12 +554,22 @@ def test_the_drivers_multi_rank_command_on_one_gpu(workload, ranks):
         assert sc["compute_plus_gather"][key]["ms_per_step"] == g[key]["ms"]
         assert sc["compute_plus_gather"][key]["Msamples_per_s"] == pytest.approx(
             n_total / (g[key]["ms"] * 1e-3) / 1e6)
+    # ... and the printed line carries them as bare numbers (<= 4 KB at any
+    # rank count: _line checked that)
+    ls = d["_line"]["scale"]
+    assert ls["compute_only"] == pytest.approx(d["value"], rel=1e-5)
+    assert ls["compute_plus_gather"] == pytest.approx(
+        sc["compute_plus_gather"]["rccl"]["Msamples_per_s"], rel=1e-5)
+    assert ls["compute_plus_gather_peer"] == pytest.approx(
+        sc["compute_plus_gather"]["peer"]["Msamples_per_s"], rel=1e-5)
 
 
 def _torchrun(ranks, extra, env, timeout=900):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), BENCH, "--gpus", str(ranks)] + extra
+    if "--detail" not in cmd:
+        cmd += ["--detail", _detail_path()]
     e = dict(os.environ, **env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         e.pop(k, None)
@@ -496,6 +667,8 @@ def test_line_guard_prints_the_line_and_exits_zero(tmp_path):
     assert len(rows) == 1
     d = json.loads(rows[0])
     assert d == {"value": 1.0, "gather": {"rccl": {"error": "timed out"}}}
+    # (a guard without a --detail path prints the record as it is; bench.py's
+    # own guard goes through bench_line.publish)
     assert "'rccl' exceeded 0 s" in r.stderr
     # a rank other than 0 leaves quietly (after rank 0 had time to write)
     prog.write_text(prog.read_text().replace("LineGuard(0)", "LineGuard(3)"))

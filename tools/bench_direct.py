@@ -11,8 +11,11 @@ import numpy as np
 import torch
 
 import build_stamp
+
+T0 = time.perf_counter()
 from bench_common import (HBM_PEAK_GBS, MODE, SHARE_GPU, WORKLOADS, coll_device,
                           dist_init, emit, ranks_on_this_node, usable_cpus)
+from bench_line import publish
 from bench_oracle import cpu_baseline, oracle_digest_leg, reduce_digest_legs
 from bench_pmc import from_profile, measure_pmc
 from bench_power import finish_power, start_power
@@ -104,7 +107,8 @@ def bench_table(args, w, ca, dist, dev, world, rank):
             "bit_exact_vs_oracle": ok}
         if power is not None:
             line["roofline"]["power"] = power
-        emit(json.dumps(line))
+        line["wall_s"] = time.perf_counter() - T0
+        publish(line, args.detail, emit)
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
@@ -242,7 +246,8 @@ def run_direct(args, w, launch):
     barrier()
     elapsed = time.perf_counter() - t0
     power = finish_power(sampler, step, torch.cuda.synchronize, t0, elapsed,
-                         args.steps, float(n))
+                         args.steps, float(n),
+                         seconds=2.0 if args.full else 1.0)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -422,7 +427,8 @@ def run_direct(args, w, launch):
             out["full_recurrence_kernel"] = full
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, leg=leg)
-        emit(json.dumps(out))
+        out["wall_s"] = time.perf_counter() - T0
+        publish(out, args.detail, emit)
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

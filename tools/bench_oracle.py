@@ -73,26 +73,26 @@ def cpu_baseline(workload, seconds=12.0, leg=None):
         # the digest leg already pushed every sample of this run through the
         # oracle on all cores: that IS the bounded sample (not done twice)
         total, wall, cores = leg["samples"], leg["seconds"], leg["cores"]
-        sample = ("all %d samples of this run's %s workload (%d threads "
-                  "drawing 2^16-sample blocks, %.1f s), whose outputs' digest "
-                  "is what digest_check compares with the device's; includes "
-                  "making the inputs and the digest (~4 %% of the work)"
-                  % (total, workload, cores, wall))
+        sample = "all %d samples of this run (%s), %.1f s" % (total, workload, wall)
+        note = ("%d threads drawing 2^16-sample blocks; the outputs' digest is "
+                "what digest_check compares with the device's; includes making "
+                "the inputs and the digest (~4 %% of the work)" % cores)
     else:
         t0 = time.perf_counter()
         total = L.orc_throughput(C.byref(ocfg), kind, cores, seconds, mul,
                                  x0, 0)
         wall = time.perf_counter() - t0
-        sample = ("%d samples of the %s workload (%d threads x 2^16-sample "
-                  "blocks for %.0f s)" % (total, workload, cores, seconds))
+        sample = "%d samples of %s, %.0f s" % (total, workload, seconds)
+        note = "%d threads x 2^16-sample blocks" % cores
     return {
         "value": total / wall / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": sample + " through oracle/liboracle.so: gcc -O2 scalar "
-                  "restatement of the reference RTL -- the reference itself "
-                  "has no CPU compute path",
+        "sample": sample,
+        "sample_note": note + "; through oracle/liboracle.so: gcc -O2 scalar "
+                       "restatement of the reference RTL -- the reference "
+                       "itself has no CPU compute path",
         "value_1thread": one / 1e6,
         "cpu": cpu_model(),
         "cpus_visible": os.cpu_count(),

@@ -44,11 +44,50 @@ def from_profile(key, samples_per_launch=1 << 30):
     return out
 
 
+def subject_command(args):
+    """The process a counter pass runs: tools/pmc_subject (a C caller of the C
+    ABI: the workload's launches and nothing else, ~1 s) for the workloads it
+    covers, otherwise a stripped `bench.py` child (16-bit containers, table
+    cores, A/B flags: ~6 s of Python start-up per pass)."""
+    import cordic_amd as ca
+    from bench_common import MODE, WORKLOADS
+    w = WORKLOADS[args.workload]
+    subject = os.path.join(ROOT, "tools", "pmc_subject")
+    native = (w["kind"] in ("p2r", "nco", "r2p", "p2rxy", "ddc")
+              and not w.get("io16") and args.input == "ramp"
+              and os.access(subject, os.X_OK)
+              and not getattr(args, "no_lj", False))
+    if native:
+        m, iw, ow, xtra, pw, ns = w["cli"]
+        flags = 0
+        for on, bit in ((args.no_seed, ca.FLAG_NO_SEED),
+                        (args.generic, ca.FLAG_FORCE_GENERIC),
+                        (args.static_chunks, ca.FLAG_STATIC_CHUNKS),
+                        (args.no_tails, ca.FLAG_NO_TAILS)):
+            if on:
+                flags |= bit
+        return [subject, w["kind"], str(MODE[m]), str(iw), str(ow), str(xtra),
+                str(pw), str(ns), str(args.log2_samples),
+                str(w.get("shift", 0)), "3", "0x%x" % flags]
+    base = [sys.executable, BENCH, "--workload",
+            args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
+            str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
+            "--no-pmc", "--no-power", "--no-full-digest", "--no-placement",
+            "--detail", os.devnull]
+    for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
+                     ("--static-chunks", args.static_chunks),
+                     ("--no-tails", args.no_tails),
+                     ("--no-lj", getattr(args, "no_lj", False))):
+        if on:
+            base.append(flag)
+    return base
+
+
 def measure_pmc(args):
     """HBM bytes per launch and VALU instructions per sample of the workload's
     kernel, MEASURED now: separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE,
     SQ_INSTS_VALU -- the first two do not fit one pass, and PMC is never
-    combined with tracing) over a 3-step run of this same script, corrected as MI355X_MICROARCH.md prescribes for gfx950
+    combined with tracing) over a 3-launch run of the workload (subject_command), corrected as MI355X_MICROARCH.md prescribes for gfx950
     (FETCH_SIZE counts half of a wide coalesced read; both are in KiB)."""
     import csv
     import glob
@@ -62,17 +101,7 @@ def measure_pmc(args):
         kern = "rotator_unrolled"
     if args.no_tails and kern == "rotator_xydir":
         kern = "rotator_unrolled"
-    base = [sys.executable, BENCH, "--workload",
-            args.workload, "--steps", "3", "--warmup", "1", "--log2-samples",
-            str(args.log2_samples), "--input", args.input, "--no-cpu-baseline",
-            "--no-other-paths", "--no-copy-probe", "--no-pmc", "--no-power",
-            "--no-full-digest"]
-    for flag, on in (("--no-seed", args.no_seed), ("--generic", args.generic),
-                     ("--static-chunks", args.static_chunks),
-                     ("--no-tails", args.no_tails),
-                     ("--no-lj", getattr(args, "no_lj", False))):
-        if on:
-            base.append(flag)
+    base = subject_command(args)
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp")
     # one rocprofv3 pass per comma-separated item; "A+B" collects A and B in
@@ -104,7 +133,9 @@ def measure_pmc(args):
                     return {"error": "no %s rows for %s (rocprofv3 rc %d)"
                             % (ctr, kern, r.returncode)}
                 vals[ctr] = (sum(rows[ctr]) / len(rows[ctr]), len(rows[ctr]))
-    out = {"kernel": kern, "passes": counters}
+    out = {"kernel": kern, "passes": counters,
+           "subject": os.path.basename(base[0] if base[0] != sys.executable
+                                       else base[1])}
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
         out.update({

@@ -158,14 +158,16 @@ def start_power(device, enabled):
     return sp
 
 
-def finish_power(sampler, step, sync, t0, elapsed, steps, samples_per_step):
+def finish_power(sampler, step, sync, t0, elapsed, steps, samples_per_step,
+                 seconds=1.0):
     """The timed region is short (the governor is still settling): keep the
-    same kernel going for two more seconds and sample that as well."""
+    same kernel going for `seconds` more (one by default, two with bench.py
+    --full) and sample that as well."""
     if sampler is None:
         return None
     t1 = time.perf_counter()
     ms_step = elapsed / steps
-    more = max(1, min(4000, int(2.0 / max(ms_step, 1e-6))))
+    more = max(1, min(4000, int(seconds / max(ms_step, 1e-6))))
     th = getattr(sampler, "throttle", None)
     th0 = th.read() if th else None
     t1 = time.perf_counter()

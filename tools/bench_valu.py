@@ -231,6 +231,10 @@ def add_valu(roof, samples_per_s, pm, power, prof, workload=None):
         else:
             roof["limiter"] = ("latency / LDS: HBM %.2f, VALU issue %.2f, socket "
                                "below its limit" % (roof["frac"], vb["frac"]))
+        # the line carries the token in front of the colon; the sentence stays
+        # in the detail file
+        roof["limiter_note"] = roof["limiter"]
+        roof["limiter"] = roof["limiter"].split(":")[0].split(" ")[0]
         roof["bound_note"] = (
             "hbm frac %.3f vs valu_fraction %.3f (this instruction mix at the "
             "clock the power limit allowed) / valu_issue_fraction %.3f (the "
