@@ -623,25 +623,23 @@ def test_a_stalled_gather_is_cut_off_and_the_line_survives():
 @pytest.mark.gpu
 def test_one_rank_under_torchrun_measures_what_the_direct_run_measures():
     """N = 1 through the driver's multi-rank command (process group, host
-    group, guards) against the plain N = 1 run: same value within 2 % (best
-    of two each: the boxes' own run-to-run spread is ~1 %)."""
-    # (BASELINE's size and the default 100 steps: behind the rank-to-rank
-    # barrier that opens the timed region the first step runs ~0.3 ms long --
-    # the device idled through the collective -- which is 1.7 % of a 20-step
-    # run and 0.15 % of this one; profiles/r05/torchrun_vs_direct.txt)
+    group, guards) against the plain N = 1 run.  Which arrays a process gets
+    decides a few per cent of the rate (include/cordic_amd.h, "Placement"), so
+    the two PROCESSES are not compared with each other: in each of them the
+    whole-job `value` (host clock around barrier + synchronize) has to agree
+    with the kernels' own HIP-event time within 2 % -- the rendezvous must not
+    leak into the timed region."""
+    # (BASELINE's size and 100 steps: behind the rank-to-rank barrier that
+    # opens the timed region the first step runs ~0.3 ms long -- the device
+    # idled through the collective -- which is 1.7 % of a 20-step run and
+    # 0.15 % of this one; profiles/r05/torchrun_vs_direct.txt)
     args = ["--steps", "100", "--warmup", "5", "--log2-samples", "30",
             "--no-full-digest"] + QUIET
-
-    def best(fn):
-        vals = []
-        for _ in range(2):
-            r = fn()
-            assert r.returncode == 0, r.stderr[-2000:]
-            vals.append(_line(r.stdout)["value"])
-        return max(vals)
-    a = best(lambda: _torchrun(1, args, {}))
-    b = best(lambda: run(["--gpus", "1"] + args))
-    assert abs(a - b) / b < 0.02, (a, b)
+    for r in (_torchrun(1, args, {}), run(["--gpus", "1"] + args)):
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _line(r.stdout)
+        by_events = (1 << 30) / d["roofline"]["kernel_ms_avg"] / 1e3
+        assert abs(d["value"] - by_events) / by_events < 0.02, (d["value"], by_events)
 
 
 def test_line_guard_prints_the_line_and_exits_zero(tmp_path):

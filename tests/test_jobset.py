@@ -242,7 +242,7 @@ R2P_CORES = {
     "natr2p24": ((ca.R2P, 24, 24, 2, -1, -1), 0, True),      # static 29
     "r2p16": ((ca.R2P, 16, 16, 2, -1, -1), 0, True),         # dynamic exit
     "sr2p": ((ca.SR2P, 24, 24, 2, -1, 20), 0, True),
-    "r2p32": ((ca.R2P, 32, 32, 2, -1, -1), 0, False),        # WW 40: one by one
+    "r2p32": ((ca.R2P, 32, 32, 2, 32, 24), 0, False),        # WW 40: one by one
     "unit_gain": ((ca.R2P, 24, 24, 2, -1, 20), ca.FLAG_UNIT_GAIN, False),
 }
 
