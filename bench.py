@@ -967,8 +967,10 @@ def main():
     ap.add_argument("--small-batches-only", action="store_true",
                     help="print only the small-batch rows (one call per job "
                     "against one job set; other_paths.small_batches* of --full)")
-    ap.add_argument("--log2-samples", type=int, default=30,
-                    help="samples per GPU = 2^this")
+    ap.add_argument("--log2-samples", type=int, default=None,
+                    help="samples per GPU = 2^this (default: the size "
+                    "BASELINE.json states for the workload -- 2^32 for cfg5 / "
+                    "cfg5seq, 2^30 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-digest", action="store_true",
                     help="skip the oracle digest over ALL samples (rank 0, "
@@ -1027,6 +1029,8 @@ def main():
     ap.add_argument("--ramp-shift", type=int, default=-1,
                     help="experiments: phase ramp n << this (steeper ramps)")
     args = ap.parse_args()
+    if args.log2_samples is None:
+        args.log2_samples = WORKLOADS[args.workload].get("log2_samples", 30)
     if args.full:
         args.copy_probe = True
     if args.no_copy_probe:

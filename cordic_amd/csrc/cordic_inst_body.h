@@ -186,14 +186,12 @@ bool launch_seeded(int nlive, int grid, hipStream_t st, const dev::CoreParams &k
 	};
 #ifdef CORDIC_INST_DESC_STATIC
 	// a job set on 16 / 24 stages: the static instance that reads descriptors
-	if (sa.tiles != nullptr && !force_dyn()
-			&& desc_static(nlive, sa.dt.n, FEED == Feed::Nco_ConstXY)) {
+	if (sa.tiles != nullptr && !force_dyn() && desc_static(nlive, sa.dt.n)) {
 		if (nlive == 16)
 			return go(rotator_seeded<CORDIC_INST_CONTAINER, 16, kSeedStages, FEED,
 					false, Io32, false, true, true>);
-		if constexpr (FEED == Feed::PhaseArray_ConstXY)
-			return go(rotator_seeded<CORDIC_INST_CONTAINER, 24, kSeedStages, FEED,
-					false, Io32, false, true, true>);
+		return go(rotator_seeded<CORDIC_INST_CONTAINER, 24, kSeedStages, FEED,
+				false, Io32, false, true, true>);
 	}
 #endif
 	switch ((batch_needs_dyn || (!sa.queue && !sa.image_out) || force_dyn()) ? -1 : nlive) {

@@ -135,13 +135,16 @@ constexpr bool dt_always(int r)
 // Job sets (tile descriptors) run the dynamic-exit instance -- except on the
 // stage counts BASELINE names, for which the left-justified WW 35 unit
 // carries a static instance WITH the descriptor loop and the direction tails:
-// 16 stages (one always-lookup group: any feed), 24 stages on phase arrays
-// (an NCO bank's jobs each have their own increment: no per-launch choice of
-// the tails).  dtn = the tail groups the plan carries.
-constexpr bool desc_static(int nlive, int dtn, bool nco)
+// 16 stages (one always-lookup group) and 24 stages, phase arrays and -- since
+// round 6 -- NCO banks alike: whether a row takes the tails is the kernel's own
+// per-row test (first and last phase of the row less than 2^kDtCoherentLog2
+// apart), which an NCO job's rows pass or fail by the job's own increment, so
+// jobs with unlike increments share one launch.  dtn = the tail groups the
+// plan carries.
+constexpr bool desc_static(int nlive, int dtn)
 {
 	return dtn >= 1 && dtn == dt_levels(nlive - CORDIC_SEED_STAGES)
-		&& (nlive == 16 || (nlive == 24 && !nco));
+		&& (nlive == 16 || nlive == 24);
 }
 constexpr int dt_rest(int r)			// stages left to the phase chain
 {

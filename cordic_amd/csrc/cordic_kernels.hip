@@ -1075,7 +1075,7 @@ int launch_rotator_jobs(const cordic_config &cfg, Feed feed, const RotatorJob &j
 		// recurrence behind the seeds: no tail tables, an image slot of its own
 		const bool stat = cfg.ww == 35		// (the WideLJ<29> unit carries them)
 			&& !(cfg.flags & (CORDIC_FLAG_NO_TAILS | CORDIC_FLAG_NO_LJ))
-			&& desc_static(cfg.nlive, j.dt.n, feed == Feed::Nco_ConstXY);
+			&& desc_static(cfg.nlive, j.dt.n);
 		const int kJobImageKey = stat ? 0 : 4;
 		if (!stat)
 			sa.dt.n = 0;

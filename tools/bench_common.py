@@ -85,10 +85,13 @@ WORKLOADS = {
                   "32-bit containers, phase ramp n"),
     "natr2p24": dict(kind="r2p", cli=("r2p", 24, 24, 2, -1, -1), bytes=16,
                      desc="gencordic -t r2p -i 24 -o 24: WW32 PW32, 29 stages"),
+    # BASELINE.json configs[4]: 4 G samples on one GPU (2 x 16 GiB of outputs)
     "cfg5": dict(kind="nco", cli=("p2r", 32, 32, 2, 32, 16), bytes=8,
+                 log2_samples=32,
                  desc="fused NCO (phase = n*0x01234567) + 16-stage p2r, "
                  "store only"),
     "cfg5seq": dict(kind="nco", cli=("sp2r", 32, 32, 2, 32, 16), bytes=8,
+                    log2_samples=32,
                     desc="fused NCO + seqcordic arithmetic (NSTAGES-2)"),
 }
 MODE = {"p2r": 0, "r2p": 1, "sp2r": 2, "sr2p": 3}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """DESIGN.md section 4.4's kernel table, GENERATED from the committed bench
-lines of one sweep (profiles/bench_r05/*.json: tools/gpu_session.sh sweep on
+records of one sweep (profiles/bench_r06/*.json: tools/gpu_session.sh sweep on
 one box, one code state) -- so every number in it IS a committed line's.
 
     python tools/design_table.py            # print the block
@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEP = os.path.join(ROOT, "profiles", "bench_r05")
+SWEEP = os.path.join(ROOT, "profiles", "bench_r06")
 BEGIN = "<!-- BEGIN generated: tools/design_table.py -->"
 END = "<!-- END generated -->"
 ORDER = ["cfg2", "cfg4", "cfg5", "cfg5seq", "p2rxy", "ddc", "cfg3", "cfg1", "nat32",
@@ -25,9 +25,17 @@ ORDER = ["cfg2", "cfg4", "cfg5", "cfg5seq", "p2rxy", "ddc", "cfg3", "cfg1", "nat
 def load(name):
     try:
         with open(os.path.join(SWEEP, name)) as f:
-            lines = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+            text = f.read()
+    except OSError:
+        return None
+    try:                    # round 6: the run's detail record, one JSON document
+        return json.loads(text)
+    except ValueError:
+        pass
+    try:                    # rounds 1-5: the printed line
+        lines = [ln for ln in text.splitlines() if ln.startswith("{")]
         return json.loads(lines[-1])
-    except (OSError, ValueError, IndexError):
+    except (ValueError, IndexError):
         return None
 
 
@@ -69,7 +77,7 @@ def block():
     if d:
         cb = d.get("cpu_baseline") or {}
         tail.append("")
-        tail.append("Default line at the END of the same sweep (`python bench.py`): %s Gsample/s, "
+        tail.append("Default command at the END of the same sweep (`python bench.py`): %s Gsample/s, "
                     "%.3f of the HBM peak (same-run copy %s), `digest_check` over %d "
                     "samples equal: %s; CPU beside it: %s Msample/s on %s threads "
                     "(%s on one)." % (

@@ -41,7 +41,7 @@ KERNELS = [
      r"rotator_unrolled<cordic_amd::dev::WideLJ<29>, 16, 2, \(cordic_amd::Feed\)1, false, cordic_amd::dev::Io32, false>",
      "p2rxy: per-sample x, y and phase"),
     ("rotator_xydir_lj29_16", "cordic_inst_xydir_lj29.o",
-     r"rotator_xydir<29, 16>",
+     r"rotator_xydir<29, 16, false>",
      "p2rxy through a plan (round 4): per-sample x, y and phase, directions of "
      "stages 2-16 looked up in three groups of five"),
     ("topolar_lj_20", "cordic_inst_pol_lj.o",

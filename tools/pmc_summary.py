@@ -94,5 +94,17 @@ for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"),
             e["shader_clock_ghz"] = cyc / 8.0 / dur
             if e.get("SQ_INSTS_VALU"):
                 e["valu_cycles_per_inst"] = (cyc / 8.0) / (e["SQ_INSTS_VALU"] / 1024.0)
+# the stats pass's own bench record: code state, and the HIP-event time of the
+# launches the trace timed (round 6: every summary says what code it is of)
+try:
+    with open(os.path.join(out, "bench_detail.json")) as f:
+        det = json.load(f)
+    res["build"] = det.get("build")
+    res["workload"] = det["config"]["workload"]
+    res["samples_per_launch"] = det["config"]["samples_per_gpu"]
+    res["hip_event_kernel_ms_avg"] = det["roofline"]["kernel_ms_avg"]
+    res["bit_exact_vs_oracle"] = det.get("bit_exact_vs_oracle")
+except (OSError, ValueError, KeyError):
+    pass
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
