@@ -114,7 +114,7 @@ __device__ __forceinline__ int64_t sext64(int64_t v, int w)
 // instruction per four cycles and a SIMD keeps issuing from the wave it is on:
 // a full-rate 32-bit instruction (two cycles of the SIMD) leaves the other two
 // empty unless that wave steps aside and another one fills them.
-// tools/sched_probe (the r2p micro-rotation's seven instructions, 4 samples a
+// round 5's wave-issue probe (the r2p micro-rotation's seven instructions, 4 samples a
 // lane, 8 waves a SIMD, 2 ms bursts): 4.19 cycles per instruction as written,
 // 3.76 with the wait states hipcc happens to pad behind asm-defined registers,
 // 3.36 with `s_nop 0` behind every 32-bit instruction and none behind the
@@ -1819,7 +1819,7 @@ __global__ __launch_bounds__(kSeedBlock) void rotator_seeded(CoreParams kp,
 		// table in LDS) pull 4096-sample tiles from a counter IN ADDRESS
 		// ORDER, the way the hardware dispatcher hands out the blocks of a
 		// one-tile-per-block launch.  Measured with arithmetic-free kernels
-		// of this kernel's traffic (tools/hbm_probe2.hip, profiles/r02/
+		// of this kernel's traffic (round 2's streaming-pattern probe, profiles/r02/
 		// hbm_probe2.txt): a contiguous chunk per block or a grid-stride
 		// streams at 0.58-0.63 of the HBM peak -- hundreds of far-apart
 		// streams advancing at once -- where one-shot tiles reach 0.72-0.76
@@ -2201,36 +2201,6 @@ template <int NLIVE, int I, bool DYN> struct PolChainLJ {
 	}
 };
 
-#ifdef CORDIC_POL_M24
-// A/B (profiles/r06/ab_mad24.txt): micro-rotation K >= 8 of a WW <= 32 core on
-// plain 32-bit values, v_mad_i32_i24 instead of v_mad_i64_i32 on pairs.
-// rtl/topolar.v:226-243 with t = +1 (y >= 0) / -1.
-template <int NLIVE, int K> struct PolChainM24 {
-	static __device__ __forceinline__ void run(int32_t (&x)[kVec], int32_t (&y)[kVec],
-			uint32_t (&p)[kVec], const uint32_t one, const CoreParams &kp)
-	{
-		if constexpr (K <= NLIVE) {
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				int32_t mk, t, nt, sy, sx;
-				asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mk) : "v"(y[v]));
-				asm("v_or_b32 %0, %1, %2" : "=v"(t) : "v"(mk), "v"(one));
-				// -t = ~mk | 1  (src0 0xF0, src1 0xCC: ~a | b = 0xCF)
-				asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(nt)
-					: "v"(mk), "v"(one));
-				asm("v_ashrrev_i32 %0, %1, %2" : "=v"(sy) : "n"(K), "v"(y[v]));
-				asm("v_ashrrev_i32 %0, %1, %2" : "=v"(sx) : "n"(K), "v"(x[v]));
-				asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(x[v]) : "v"(sy), "v"(t));
-				asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(y[v]) : "v"(sx), "v"(nt));
-				asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(p[v])
-					: "s"(kp.angle[K - 1]), "v"(t));
-			}
-			PolChainM24<NLIVE, K + 1>::run(x, y, p, one, kp);
-		}
-	}
-};
-#endif
-
 // Stage 1 on the left-justified pairs: (y >>> 1) is bits 62..31 of y~, one
 // v_alignbit_b32 (the value fits 32 bits because y does).
 __device__ __forceinline__ void pol_stage1_lj(int64_t &x, int64_t &y, int64_t &p,
@@ -2358,42 +2328,6 @@ __device__ __forceinline__ void topolar_lj_sweep(const CoreParams &kp,
 		for (int v = 0; v < kVec; v++)	// (registers, no values: nothing to emit)
 			asm volatile("" : "=v"(m[v].t), "=v"(m[v].nt), "=v"(m[v].sy), "=v"(m[v].sx),
 					"=s"(m[v].cc));
-#endif
-#ifdef CORDIC_POL_M24
-		// A/B (profiles/r06/ab_mad24.txt): stages with a
-		// shift of 8 and more in a plain 32-bit container on v_mad_i32_i24
-		// (D = S0.i24 * S1.i24 + S2.i32): y >>> k fits 24 bits from k = 8,
-		// the multiplier is +/-1, the left-justified angle fits 24 bits from
-		// k = 7 -- no 64-bit operation in 13 of cfg3's 20 stages.
-		if constexpr (PLAIN && !DYN && NLIVE > 8) {
-			PolChainLJ<7, 1, false>::run(x, y, p, c, kp, m);
-			int32_t x32[kVec], y32[kVec];
-			uint32_t p32[kVec];
-			const uint32_t one = vgpr_const(1u);
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {	// value = pair >> 30: exact
-				x32[v] = (int32_t)__builtin_amdgcn_alignbit(
-					(uint32_t)((uint64_t)x[v] >> 32), (uint32_t)x[v], 30);
-				y32[v] = (int32_t)__builtin_amdgcn_alignbit(
-					(uint32_t)((uint64_t)y[v] >> 32), (uint32_t)y[v], 30);
-				p32[v] = __builtin_amdgcn_alignbit(
-					(uint32_t)((uint64_t)p[v] >> 32), (uint32_t)p[v], 30);
-			}
-			PolChainM24<NLIVE, 8>::run(x32, y32, p32, one, kp);
-			i32x4 rm;
-			u32x4 rp;
-#pragma unroll
-			for (int v = 0; v < kVec; v++) {
-				// rtl/topolar.v:251-263 on the plain value
-				const uint32_t b = ((uint32_t)x32[v] >> kp.r) & kp.round_bit;
-				rm[v] = (int32_t)((uint32_t)x32[v] + (uint32_t)kp.round_base + b) >> kp.r;
-				rp[v] = (p32[v] + 0x80000000u) >> kp.pw_shl;	// :269
-			}
-			apply_unit_gain<UG>(rm, kp);
-			CORDIC_STORE_OUT(true, &omag[g], IO::narrow(rm));
-			CORDIC_STORE_OUT(true, &oph[g], IO::narrow(rp));
-			continue;
-		}
 #endif
 		PolChainLJ<NLIVE, 1, DYN>::run(x, y, p, c, kp, m);
 

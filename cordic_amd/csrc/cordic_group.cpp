@@ -20,7 +20,7 @@
 // choices of three out of eight such arrays ranges from 0.75 to 0.82 -- a
 // property of the combination (the two written arrays most of all), stable
 // for the life of the allocations, not predictable from the virtual addresses
-// (tools/hbm_alloc_probe*.py, profiles/r02/hbm_placement.txt).  Since the
+// (round 2's allocation probes, profiles/r02/hbm_placement.txt).  Since the
 // group owns its arrays it can choose: when asked to
 // (cordic_group_set_placement; off by default since round 6) it allocates two
 // more arrays than a shard needs, times the arithmetic-free twin of the job's

@@ -179,6 +179,24 @@ def test_c_example_runs():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+def test_c_channeliser_example_runs_job_sets():
+    """examples/channeliser.c: CORDIC_JOBS_MIX + CORDIC_JOBS_R2P from plain
+    C99 -- 256 ragged blocks through mixer and converter as two launches,
+    word for word what 512 per-block calls deliver."""
+    exe = os.path.join(ROOT, "tools", "channeliser")
+    if not os.path.exists(exe):
+        pytest.skip("tools/channeliser not built")
+    r = subprocess.run([exe, "-c", "256", "-l", "14"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("job sets vs per-block calls: equal") == 4
+    assert "DIFFER" not in r.stdout
+    sets = float(re.search(r"two job sets :\s+([\d.]+) ms", r.stdout).group(1))
+    calls = float(re.search(r"512 calls  :\s+([\d.]+) ms", r.stdout).group(1))
+    assert sets < calls / 3.0, r.stdout
+
+
 def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
     """tools/host_selftest.cpp: the host-only sources compiled with
     -fsanitize=address,undefined and driven with random / hostile parameters,
