@@ -179,6 +179,9 @@ struct cordic_plan {
 	SeedImages *images = nullptr;
 	// batch size from which the table-driven kernels serve (< 0: default)
 	std::atomic<long long> min_samples{-1};
+	// an int16 entry point has been called on this plan: cordic_plan_prepare
+	// then also builds the int16 container's image (its own slot)
+	mutable std::atomic<bool> io16_used{false};
 };
 
 int cordic_last_kernel(void) { return g_last_kernel; }
@@ -360,10 +363,12 @@ int cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
 	if (!plan->d_table || !plan->images)
 		return CORDIC_ERR_UNSUPPORTED;
 	int rc = CORDIC_OK;
-	// one image per container the plan's entry points may run in: the 32-bit
-	// arrays' and, for cores whose ports fit, the int16 arrays'
+	// the image of the 32-bit arrays' container and -- only once the plan has
+	// served an int16 call: an image takes one of its eight write-once slots
+	// -- the int16 arrays' 
 	for (int io16 = 0; io16 < 2; io16++) {
-		if (io16 && (plan->cfg.iw > 16 || plan->cfg.ow > 16))
+		if (io16 && (plan->cfg.iw > 16 || plan->cfg.ow > 16
+				|| !plan->io16_used.load(std::memory_order_relaxed)))
 			break;
 		RotatorJob j;
 		j.x0 = xval; j.y0 = yval;
@@ -885,6 +890,7 @@ int cordic_plan_p2r16_const(const cordic_plan *plan, size_t n, int32_t xval,
 	RotatorJob j = job16(nullptr, nullptr, d_phase, d_oxval, d_oyval, n);
 	j.x0 = xval; j.y0 = yval;
 	attach_seed(plan, j);
+	plan->io16_used.store(true, std::memory_order_relaxed);
 	return with_queue(plan->queues, stream, [&](uint32_t *q) {
 		j.queue = q;
 		return launch_rotator(plan->cfg, Feed::PhaseArray_ConstXY, j, stream);
@@ -903,6 +909,7 @@ int cordic_plan_nco16(const cordic_plan *plan, size_t n, uint32_t phase0,
 	j.x0 = xval; j.y0 = yval; j.phase0 = phase0; j.fcw = fcw;
 	j.index0 = index0;
 	attach_seed(plan, j);
+	plan->io16_used.store(true, std::memory_order_relaxed);
 	return with_queue(plan->queues, stream, [&](uint32_t *q) {
 		j.queue = q;
 		return launch_rotator(plan->cfg, Feed::Nco_ConstXY, j, stream);

@@ -166,6 +166,29 @@ const uint32_t *seed_image_for(SeedImages &c, int container, int32_t x0, int32_t
 	return s.d;			// same stream: ordered behind the build
 }
 
+// Would seed_image_for() hand this launch an image -- one it holds and may use,
+// or one it could build now?  Nothing is changed (the batch-size rule asks
+// before the launch is shaped: ADVICE r05 -- a ninth constant vector, or a
+// captured launch nobody prepared, computes its prologue in every block and
+// wants the higher threshold).
+bool seed_image_would_serve(SeedImages &c, int container, int32_t x0, int32_t y0,
+		size_t bytes, hipStream_t st)
+{
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (st && hipStreamIsCapturing(st, &cs) != hipSuccess) {
+		(void)hipGetLastError();
+		cs = hipStreamCaptureStatusNone;
+	}
+	const bool capturing = cs != hipStreamCaptureStatusNone;
+	std::lock_guard<std::mutex> lock(c.mu);
+	for (int k = 0; k < c.used; k++) {
+		const SeedImages::Slot &s = c.slot[k];
+		if (s.container == container && s.x0 == x0 && s.y0 == y0 && s.bytes == bytes)
+			return !capturing || s.settled;
+	}
+	return !capturing && c.used < kSeedImageSlots;
+}
+
 // ------------------------------------------------------------ generic path
 //
 // Any parameter set, any alignment: one sample per lane per pass, 64-bit
@@ -837,26 +860,45 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			return CORDIC_ERR_DEVICE;
 		bool done = false;
 		// constant-vector feeds with a plan: table-seeded kernel
+		uint32_t *const seed_queue = (cfg.flags & CORDIC_FLAG_STATIC_CHUNKS)
+				? nullptr : j.queue;
+		// which container's instance serves the core: 3 int16 arrays,
+		// 0 32-bit registers, 1 / 2 left-justified by 29 / 30
+		const int container = j.io16 ? 3
+			: (cfg.ww <= 32 && (cfg.needs_wrap
+				|| (cfg.flags & CORDIC_FLAG_NO_LJ))) ? 0
+			: cfg.ww == 35 ? 1 : 2;
+		DtInfo seed_dt = j.dt;
+		if (cfg.flags & CORDIC_FLAG_NO_TAILS)
+			seed_dt.n = 0;	// A/B: phase recurrence behind the seeds
+		// buckets, seeds, the three tile-id slots of the queue and the
+		// direction tails
+		const size_t seed_lds = (dt_lds_layout(seed_dt,
+				(uint32_t)((size_t)j.seed_nbuckets * 8
+				+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr)
+				+ 15u) & ~(size_t)15;
+		// (the lower batch-size threshold only where an image really serves
+		// this launch; asked only for batches between the two thresholds)
+		auto big_enough = [&]() -> bool {
+			if (j.n < (size_t)kVec)
+				return false;
+			if (j.n >= seed_min_samples(cfg, j.min_samples, false))
+				return true;
+			return j.images && cfg.ww <= 35
+				&& j.n >= seed_min_samples(cfg, j.min_samples, true)
+				&& seed_image_would_serve(*j.images,
+					container + (seed_queue ? 0 : 8), kp.x0, kp.y0, seed_lds, st);
+		};
 		if (FEED != Feed::PhaseArray_XYArray && j.seed_table
 				&& j.seed_m == kSeedStages
-				&& (j.prepare_only || (j.n >= (size_t)kVec
-					&& j.n >= seed_min_samples(cfg, j.min_samples,
-						j.images != nullptr)))
-				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)) {
+				&& !(cfg.flags & CORDIC_FLAG_NO_SEED)
+				&& (j.prepare_only || big_enough())) {
 			static_assert(CORDIC_QUEUE_BYTES
 				== kQueueCounters * kQueueStride * 4, "queue layout");
-			uint32_t *queue = (cfg.flags & CORDIC_FLAG_STATIC_CHUNKS)
-					? nullptr : j.queue;
+			uint32_t *queue = seed_queue;
 			SeedArgs sa{j.seed_table, j.seed_S, j.seed_nbuckets,
-					j.seed_nleaves, queue, j.dt};
-			if (cfg.flags & CORDIC_FLAG_NO_TAILS)
-				sa.dt.n = 0;	// A/B: phase recurrence behind the seeds
-			// buckets, seeds, the three tile-id slots of the queue and the
-			// direction tails
-			const size_t lds = (dt_lds_layout(sa.dt,
-					(uint32_t)((size_t)j.seed_nbuckets * 8
-					+ (size_t)j.seed_nleaves * 4 * 16 + 16), nullptr, nullptr)
-					+ 15u) & ~(size_t)15;
+					j.seed_nleaves, queue, seed_dt};
+			const size_t lds = seed_lds;
 			// blocks per CU: 32 waves and 160 KiB of LDS to share
 			int per_cu = 32 / (kSeedBlock / 64);
 			const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
@@ -868,12 +910,6 @@ int launch_rot_feed(const cordic_config &cfg, const RotatorJob &j, void *stream)
 			if (g2 < 0)
 				return CORDIC_ERR_DEVICE;
 			if (per_cu >= 1 && lds <= 160 * 1024) {
-				// which container's instance serves the core: 3 int16 arrays,
-				// 0 32-bit registers, 1 / 2 left-justified by 29 / 30
-				const int container = j.io16 ? 3
-					: (cfg.ww <= 32 && (cfg.needs_wrap
-						|| (cfg.flags & CORDIC_FLAG_NO_LJ))) ? 0
-					: cfg.ww == 35 ? 1 : 2;
 				auto run = [&](Feed feed, const SeedArgs &a, const RotatorJob &jj,
 						int grid_) -> bool {
 					switch (container) {

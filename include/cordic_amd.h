@@ -314,7 +314,10 @@ int	cordic_plan_create(const cordic_config *cfg, cordic_plan **plan);
 /* Build the seed image of (xval, yval) now, on `stream` (see above), and
  * return when it is complete (a set-up call: it waits ~15 us for one block);
  * not inside a stream capture.  CORDIC_ERR_UNSUPPORTED for cores without a
- * seed table or when all image slots are taken. */
+ * seed table or when all image slots are taken.  The int16 containers
+ * (cordic_plan_p2r16_const / cordic_plan_nco16) keep an image of their own:
+ * it is built here too once the plan has served an int16 call (a plan that
+ * never does keeps all eight slots for the 32-bit arrays). */
 int	cordic_plan_prepare(const cordic_plan *plan, int32_t xval, int32_t yval,
 		void *stream);
 /* images held, launches served from one, launches that computed their own

@@ -171,6 +171,30 @@ def test_int16_and_int32_calls_on_one_plan_keep_separate_images():
     plan.close()
 
 
+def test_prepare_builds_the_int16_image_only_for_plans_that_use_int16_arrays():
+    """cordic_plan_prepare took TWO of a 16-bit core's eight
+    write-once slots per vector, for an int16 image most plans never use.  Now
+    the int16 image is built by prepare only once the plan has served an
+    int16 call."""
+    cfg, _ = both(ca.P2R, 16, 16, 2, 16, 16)
+    plan = ca.Plan(cfg)
+    for k in range(8):                  # eight vectors, eight slots
+        plan.prepare(100 + k, k)
+    assert plan.image_info["held"] == 8
+    plan.close()
+    plan = ca.Plan(cfg)
+    n = 1 << 14
+    p16 = torch.zeros(n, dtype=torch.int16, device=DEV)
+    a16 = torch.zeros_like(p16)
+    b16 = torch.zeros_like(p16)
+    plan.p2r_const(7, 0, p16, a16, b16)         # an int16 call: its own image
+    torch.cuda.synchronize()
+    assert plan.image_info["held"] == 1
+    plan.prepare(9, 9)                          # now both containers
+    assert plan.image_info["held"] == 3
+    plan.close()
+
+
 def test_first_use_on_one_stream_next_use_on_another():
     """The build runs on the first launch's stream; a launch on another stream
     right behind it (nothing synchronised in between) is ordered behind the
@@ -315,3 +339,49 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", script], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_the_lower_batch_size_threshold_needs_an_image_that_serves_the_launch():
+    """a plan takes its table kernels from 2^22 samples where the
+    prologue comes from an image, from 2^23 where every block computes it.
+    A NINTH constant vector (all eight slots taken) gets no image: at 2^22
+    samples it has to run the plain kernel, while a vector that holds a slot
+    runs the seeded one.  (The library's own thresholds: a child process
+    without the suite's CORDIC_SEED_MIN_SAMPLES=0.)"""
+    import subprocess
+    import sys
+    prog = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import torch, cordic_amd as ca\n"
+        "cfg = ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16)\n"
+        "plan = ca.Plan(cfg)\n"
+        "n = 1 << 22\n"
+        "ph = torch.zeros(n, dtype=torch.int32, device='cuda')\n"
+        "a = torch.empty_like(ph); b = torch.empty_like(ph)\n"
+        "ca.fill_phase_ramp(ph, 0, 8)\n"
+        "fam = []\n"
+        "for k in range(9):\n"
+        "    plan.p2r_const(1000 + k, 0, ph, a, b)\n"
+        "    torch.cuda.synchronize(); fam.append(ca.last_kernel())\n"
+        "plan.p2r_const(1003, 0, ph, a, b); fam.append(ca.last_kernel())\n"
+        "half = torch.zeros(n // 2, dtype=torch.int32, device='cuda')\n"
+        "plan.p2r_const(1003, 0, half, a[:n // 2], b[:n // 2]); fam.append(ca.last_kernel())\n"
+        "big = torch.zeros(2 * n, dtype=torch.int32, device='cuda')\n"
+        "a2 = torch.empty_like(big); b2 = torch.empty_like(big)\n"
+        "plan.p2r_const(1008, 0, big, a2, b2); fam.append(ca.last_kernel())\n"
+        "torch.cuda.synchronize()\n"
+        "print('FAM', fam, plan.image_info['held'])\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+           os.path.dirname(os.path.abspath(__file__))))
+    env = {k: v for k, v in os.environ.items() if k != "CORDIC_SEED_MIN_SAMPLES"}
+    r = subprocess.run([sys.executable, "-c", prog], env=env, text=True,
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("FAM")][-1]
+    fam = eval(line[4:line.rindex("]") + 1])
+    S, U = ca.KERNEL_SEEDED, ca.KERNEL_UNROLLED
+    # eight vectors take a slot each and the seeded kernel; the ninth runs the
+    # plain one at this size; a slot holder still the seeded one; below 2^22
+    # everybody the plain one; at 2^23 the ninth the seeded one (own prologue)
+    assert fam == [S] * 8 + [U, S, U, S], fam
+    assert line.rstrip().endswith(" 8")
