@@ -18,6 +18,80 @@ import oracle_lib as O  # noqa: E402
 from gpu_util import gpu_nco, gpu_p2r, gpu_plan_nco, gpu_plan_p2r, gpu_r2p  # noqa: E402
 from test_gpu_parity import rand_inputs  # noqa: E402
 
+
+
+def cut(rng, n):
+    """[0, n) as 1-6 consecutive ragged pieces (empty ones included)"""
+    k = int(rng.randint(1, 7))
+    at = sorted(int(v) for v in rng.randint(0, n + 1, k - 1))
+    return list(zip([0] + at, at + [n]))
+
+
+def jobset_fuzz(rng, plan, cfg, ocfg, x, y, ph, paths):
+    """Round 6: the same samples as a JOB SET of every kind the core's mode
+    has -- ragged pieces at odd offsets of the same arrays -- against the
+    oracle, piece by piece."""
+    import torch
+    n = len(x)
+    dev = [torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).cuda()
+           for v in (x, y, ph)]
+    oa = torch.empty(n, dtype=torch.int32, device="cuda")
+    ob = torch.empty(n, dtype=torch.int32, device="cuda")
+    pieces = cut(rng, n)
+    rot = cfg.mode in (ca.P2R, ca.SP2R)
+    kinds = ([ca.JOBS_P2R_XY, ca.JOBS_MIX, ca.JOBS_PHASE_ARRAYS, ca.JOBS_NCO]
+             if rot else [ca.JOBS_R2P])
+    x0, y0 = int(x[0]), int(y[n - 1])
+    for kind in kinds:
+        jobs, want = [], []
+        for lo, hi in pieces:
+            jb = dict(ox=oa[lo:hi], oy=ob[lo:hi], n=hi - lo)
+            if kind in (ca.JOBS_P2R_XY, ca.JOBS_MIX, ca.JOBS_R2P):
+                jb.update(x=dev[0][lo:hi], y=dev[1][lo:hi])
+            if kind in (ca.JOBS_P2R_XY, ca.JOBS_PHASE_ARRAYS):
+                jb["phase"] = dev[2][lo:hi]
+            if kind in (ca.JOBS_MIX, ca.JOBS_NCO):
+                jb.update(phase0=int(rng.randint(1 << 32)),
+                          fcw=int(rng.choice([1, 3, int(rng.randint(1 << 32))])),
+                          index0=int(rng.randint(1 << 40)))
+            jobs.append(jb)
+            if hi == lo:
+                want.append(None)
+            elif kind == ca.JOBS_R2P:
+                want.append(O.topolar(ocfg, x[lo:hi], y[lo:hi]))
+            elif kind == ca.JOBS_P2R_XY:
+                want.append(O.rotate(ocfg, x[lo:hi], y[lo:hi], ph[lo:hi]))
+            elif kind == ca.JOBS_PHASE_ARRAYS:
+                want.append(O.rotate(ocfg, x0, y0, ph[lo:hi]))
+            elif kind == ca.JOBS_MIX:
+                want.append(O.mix(ocfg, jb["phase0"], jb["fcw"], jb["index0"],
+                                  x[lo:hi], y[lo:hi]))
+            else:
+                want.append(O.nco(ocfg, hi - lo, jb["phase0"], jb["fcw"],
+                                  jb["index0"], x0, y0))
+        oa.fill_(0x5a5a5a5a)
+        ob.fill_(0x5a5a5a5a)
+        js = ca.Jobset(plan, kind, jobs)
+        js.run(x0, y0)
+        torch.cuda.synchronize()
+        fam = ca.last_kernel()
+        js.close()
+        ga, gb = oa.cpu().numpy(), ob.cpu().numpy()
+        for (lo, hi), w in zip(pieces, want):
+            if w is None:
+                continue
+            if not (np.array_equal(ga[lo:hi], w[0])
+                    and np.array_equal(gb[lo:hi].view(w[1].dtype), w[1])):
+                raise SystemExit("job set mismatch: kind %d core mode %d iw %d ow %d ww %d "
+                                 "pw %d nlive %d piece [%d, %d) of %r"
+                                 % (kind, cfg.mode, cfg.iw, cfg.ow, cfg.ww, cfg.pw,
+                                    cfg.nlive, lo, hi, pieces))
+        key = "jobs%d:%s" % (kind, {ca.KERNEL_SEEDED: "seeded",
+                                    ca.KERNEL_DIRECTIONS: "dirs",
+                                    ca.KERNEL_LEFT_JUSTIFIED: "lj"}.get(fam, "one-by-one"))
+        paths[key] = paths.get(key, 0) + 1
+
+
 ncfg = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 done = refused = 0
@@ -95,6 +169,7 @@ for t in range(ncfg):
         a = gpu_plan_nco(plan, n, p0, fcw, i0, x0, y0)
         b = O.nco(ocfg, n, p0 & 0xffffffff, fcw, i0, x0, y0)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (t, "nco")
+        jobset_fuzz(rng, plan, cfg, ocfg, x, y, ph, paths)
         plan.close()
     else:
         a = gpu_r2p(cfg, x, y)
@@ -107,6 +182,9 @@ for t in range(ncfg):
                                 bad[0], x[bad[0]], y[bad[0]], a[0][bad[0]],
                                 int(a[1][bad[0]]) & 0xffffffff, b[0][bad[0]],
                                 int(b[1][bad[0]]) & 0xffffffff, bad.size))
+        plan = ca.Plan(cfg)
+        jobset_fuzz(rng, plan, cfg, ocfg, x, y, ph, paths)
+        plan.close()
     done += 1
 print("fuzz ok: %d cores checked, %d refused by both; paths %s" % (done, refused, paths))
 
