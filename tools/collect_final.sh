@@ -13,6 +13,7 @@ cp gpurun_out/final/bench_8_ranks_one_gpu.json gpurun_out/final/bench_8_ranks_on
 grep -E "passed|failed" gpurun_out/final/gputests.log > profiles/$R/gputests_final.txt
 tail -n 3 gpurun_out/final/smoke.log >> profiles/$R/gputests_final.txt
 cp gpurun_out/env.log profiles/$R/box_env.txt 2>/dev/null
+cp gpurun_out/final/fuzz.txt profiles/$R/fuzz.txt 2>/dev/null
 f=$(ls gpurun_out/final/default_stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" profiles/$R/default_kernel_stats.csv
 cp gpurun_out/final/default_stats_detail.json profiles/$R/default_kernel_stats_detail.json

@@ -28,4 +28,5 @@ BENCH_TEST_SHARE_GPU=1 CORDIC_RCCL_LIB=$PWD/tests/rccl_shim/librccl_shim.so HSA_
 	timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
 	--master-port 29533 bench.py --gpus 8 --workload cfg4 --log2-samples 26 --steps 20 --warmup 5 \
 	--detail $OUT/bench_8_ranks_one_gpu.json > $OUT/bench_8_ranks_one_gpu.line 2> $OUT/bench_8_ranks_one_gpu.err
+for seed in 11 12 13; do timeout 900 python tools/fuzz_gpu.py 1500 $seed 2>&1 | grep "fuzz ok" >> $OUT/fuzz.txt; done
 wc -c $OUT/*.line
