@@ -448,9 +448,11 @@ def run_group(args, w, launch):
     x0, y0 = (1 << (iw - 1)) - 1, 0
     grp = ca.Group(cfg, devices=devices, first_shard=first, total_shards=total)
     # since round 6 the library takes its arrays as hipMalloc hands them out
-    # unless asked (include/cordic_amd.h, "Placement"); the bench asks, and
+    # unless asked (include/cordic_amd.h, "Placement"); the bench asks -- for
+    # --placement-spares arrays of ITS OWN memory (six: 24 GiB, under a tenth of
+    # what is free), spent only while no pair of written arrays is fast -- and
     # says so in the line (roofline.placement)
-    grp.set_placement(not args.no_placement)
+    grp.set_placement(0 if args.no_placement else args.placement_spares)
     seeded, seed_stages, tails = False, 0, []
     if kind in ("p2r", "nco") and not args.generic and not args.no_seed:
         probe_plan = ca.Plan(cfg)
@@ -706,10 +708,14 @@ def run_group(args, w, launch):
         # (cordic_group placement: include/cordic_amd.h)
         roof["placement"] = dict(
             grp_placement,
-            what="cordic_group_set_placement(grp, 1): arrays allocated with two "
-                 "spares, arithmetic-free probes of the job's traffic over the "
-                 "role assignments, best kept (off in the library by default; "
-                 "--no-placement: as hipMalloc hands them out)")
+            spares_allowed=args.placement_spares,
+            what="cordic_group_set_placement(grp, %d): arrays allocated with "
+                 "two spares -- further ones, up to that number and a tenth of "
+                 "the free memory, only while no pair of written arrays is fast "
+                 "--, arithmetic-free probes of the job's traffic over the role "
+                 "assignments, best kept (off in the library by default; "
+                 "--no-placement: as hipMalloc hands them out)"
+                 % args.placement_spares)
         if probes and probes[0]:
             # the plain-copy ceiling of THIS run on THESE arrays: best of the
             # probes before and after the timed region
@@ -915,6 +921,11 @@ def run_group(args, w, launch):
                     bench_paths.small_batches_xy())
             except Exception as e:            # never lose the main line
                 out["other_paths"]["small_batches_xy"] = {"error": repr(e)}
+            try:
+                out["other_paths"]["small_batches_nco"] = (
+                    bench_paths.small_batches_nco())
+            except Exception as e:            # never lose the main line
+                out["other_paths"]["small_batches_nco"] = {"error": repr(e)}
             lap("other_paths")
         out["phases_s"] = phases
         out["wall_s"] = time.perf_counter() - T_START
@@ -980,6 +991,10 @@ def main():
     ap.add_argument("--no-placement", action="store_true",
                     help="take the group's arrays as hipMalloc hands them out "
                          "instead of probing candidate allocations")
+    ap.add_argument("--placement-spares", type=int, default=6,
+                    help="spare arrays the bench lets cordic_group take while it "
+                    "places the run's arrays (cordic_group_set_placement(grp, N); "
+                    "1 = the library's own two)")
     ap.add_argument("--no-power", action="store_true",
                     help="skip the hwmon power / clock samples and the two "
                          "seconds of sustained running behind the timed region")
@@ -1049,7 +1064,8 @@ def main():
     # bench asks -- run_group through cordic_group_set_placement, the stateless
     # workloads' cordic_arrays_alloc through the environment (also inherited
     # by the ranks and sub-runs this process starts)
-    os.environ["CORDIC_GROUP_PLACEMENT"] = "0" if args.no_placement else "1"
+    os.environ["CORDIC_GROUP_PLACEMENT"] = ("0" if args.no_placement
+                                            else str(max(1, args.placement_spares)))
 
     if args.host_paths_only:
         import bench_paths
@@ -1058,7 +1074,8 @@ def main():
     if args.small_batches_only:
         import bench_paths
         print(json.dumps({"small_batches": bench_paths.small_batches(),
-                          "small_batches_xy": bench_paths.small_batches_xy()}))
+                          "small_batches_xy": bench_paths.small_batches_xy(),
+                          "small_batches_nco": bench_paths.small_batches_nco()}))
         return
     launch = resolve_launch(args)
     if launch == "spawn":

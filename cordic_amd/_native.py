@@ -667,7 +667,9 @@ class Group:
                "cordic_group_set_gather")
 
     def set_placement(self, enable):
-        _check(lib().cordic_group_set_placement(self._h, 1 if enable else 0),
+        """False / 0: off (the default); True / 1: two spare arrays; N >= 2:
+        up to N spares while no written pair is fast (include/cordic_amd.h)"""
+        _check(lib().cordic_group_set_placement(self._h, int(enable)),
                "cordic_group_set_placement")
 
     def placement(self, local_shard=0):

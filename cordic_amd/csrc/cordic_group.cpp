@@ -33,6 +33,7 @@
 #include <rccl/rccl.h>		// types only: the entry points come from dlopen
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,12 +80,20 @@ struct Shard {
 };
 
 constexpr uint64_t kPlaceMinWords = (uint64_t)1 << 24;	// arrays of 64 MiB and up
-constexpr int kPlaceSpare = 2;		// candidates beyond the need, at most
+constexpr int kPlaceSpare = 2;		// candidates beyond the need: set_placement(grp, 1)
+constexpr int kPlaceSpareMost = 16;	// ... and what a caller may ask for by number
+// a pair of written arrays is fast from 0.93 of the 8 TB/s peak (two arrays of
+// one class: <= 0.82); a caller's larger budget is spent only while none is
+constexpr double kPlaceGoodBytesPerMs = 0.93 * 8e9;
+constexpr int kPlaceTryAgainst = 3;	// a further candidate is tried against this many
+constexpr double kPlaceSeconds = 1.5;	// ... and no further one is taken after this long
 // ... and in bytes: a tenth of what is free on the device when the arrays are
 // allocated (round 6: the library may not transiently claim tens of GiB of a
 // caller's HBM; rounds 4-5 took up to 24 spares while no pair of written
 // arrays was fast -- allocations come in classes, profiles/r05/pair_matrix.txt
-// -- which bought ~5 % on one box in eight and is gone)
+// -- without asking.  A caller who names a NUMBER of spares,
+// cordic_group_set_placement(grp, N) with N >= 2, gets the same search bounded
+// by N, by this share of the free memory and by kPlaceSeconds)
 constexpr double kPlaceSpareFreeShare = 0.10;
 
 // The eight RCCL entry points the gather needs, resolved once per process.
@@ -150,7 +159,7 @@ struct cordic_group {
 	int32_t	*g0 = nullptr, *g1 = nullptr;
 	int	chunks = 1;
 	int	rroot = -1;	// root SHARD of the RCCL forwarding (-1: off)
-	bool	placement = false;	// cordic_group_set_placement
+	int	placement = 0;		// spare arrays allowed (0: off): cordic_group_set_placement
 	// the job size the shards' input arrays were last filled for by the fill
 	// kernels (0: not filled), and how many of them; what the CALLER wrote is
 	// tracked per shard and array (Shard::written)
@@ -249,15 +258,25 @@ float probe_ms(hipStream_t st, int reads, int writes, const void *r0, const void
 	return ms;
 }
 
+// cordic_group_set_placement / CORDIC_GROUP_PLACEMENT: 0 off, 1 the default
+// two spares, N >= 2 that many (kPlaceSpareMost at most)
+int placement_spares(int enable)
+{
+	return enable <= 0 ? 0 : enable == 1 ? kPlaceSpare
+		: enable > kPlaceSpareMost ? kPlaceSpareMost : enable;
+}
+
 // Allocate nread (0..2) + nwrite (1..2) arrays of `words` 32-bit words on the
 // current device.  With `tune`, allocate up to kPlaceSpare more than needed,
 // time the arithmetic-free twin of the traffic over the candidate assignments
 // -- first the written arrays (two: every pair, 0R2W), then the read ones over
 // what is left -- keep the best and free the rest.  A probe that cannot run
 // just means "in order".
-int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tune,
+int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, int spares_allowed,
 		void **reads, void **writes, PlaceStats *stats)
 {
+	const bool tune = spares_allowed > 0;
+	const auto t_begin = std::chrono::steady_clock::now();
 	const size_t need = (size_t)(nread + nwrite);
 	const size_t bytes = (size_t)(words ? words : 1) * 4;
 	std::vector<void *> pool;
@@ -272,8 +291,10 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 			return (size_t)0;
 		}
 		const size_t by_bytes = (size_t)((double)fr * kPlaceSpareFreeShare) / bytes;
-		return by_bytes < (size_t)kPlaceSpare ? by_bytes : (size_t)kPlaceSpare;
+		return by_bytes < (size_t)spares_allowed ? by_bytes : (size_t)spares_allowed;
 	};
+	// (the first round: two spares at most; a larger allowance is drawn on
+	// below, one array at a time, only while no written pair is fast)
 	const size_t want = need + (tune ? (size_t)kPlaceSpare : 0);
 	for (size_t k = 0; k < want; k++) {
 		void *p = nullptr;
@@ -350,6 +371,29 @@ int alloc_placed(hipStream_t st, uint64_t words, int nread, int nwrite, bool tun
 		for (size_t i = 0; i < pool.size() && !failed; i++)
 			for (size_t j = i + 1; j < pool.size() && !failed; j++)
 				try_pair(i, j);
+		// A caller that allowed more than kPlaceSpare spares: while no pair is
+		// fast (all candidates of one class: DESIGN.md section 3), one more
+		// array at a time, tried against a few of those at hand -- within the
+		// caller's number, the share of the free memory and kPlaceSeconds.
+		const float good = (float)((double)words * 8.0 / kPlaceGoodBytesPerMs);
+		while (!failed && best > good && pool.size() < need + spares) {
+			const std::chrono::duration<double> spent =
+				std::chrono::steady_clock::now() - t_begin;
+			if (spent.count() > kPlaceSeconds)
+				break;
+			void *p = nullptr;
+			if (!ok(hipMalloc(&p, bytes))) {
+				(void)hipGetLastError();
+				break;		// no room: make do with what there is
+			}
+			pool.push_back(p);
+			ps.candidates++;
+			const size_t last = pool.size() - 1;
+			const size_t step = last > (size_t)kPlaceTryAgainst
+				? last / (size_t)kPlaceTryAgainst : 1;
+			for (size_t i = 0; i < last && !failed && best > good; i += step)
+				try_pair(i, last);
+		}
 		if (failed) {
 			(void)hipGetLastError();
 			ps = PlaceStats{};
@@ -460,7 +504,7 @@ int ensure(cordic_group *g, uint64_t n_total, int inputs)
 			// everything at once: place the arrays by measurement
 			void *rd[2] = {nullptr, nullptr}, *wr[2] = {nullptr, nullptr};
 			PlaceStats ps;
-			const bool tune = g->placement && cap >= kPlaceMinWords;
+			const int tune = cap >= kPlaceMinWords ? g->placement : 0;
 			if (int rc = alloc_placed(s.compute, cap, nin, 2, tune, rd, wr, &ps))
 				return rc;
 			s.buf[0] = rd[0]; s.buf[1] = rd[1];
@@ -674,7 +718,7 @@ int cordic_group_create(const cordic_config *cfg, int nlocal, const int *devices
 	g->total = total_shards;
 	// off unless asked: cordic_group_set_placement, or CORDIC_GROUP_PLACEMENT=1
 	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
-		g->placement = e[0] == '1' && e[1] == 0;
+		g->placement = placement_spares(std::atoi(e));
 	DeviceScope scope;
 	g->shards.resize((size_t)nlocal);
 	int rc = CORDIC_OK;
@@ -729,9 +773,9 @@ int cordic_arrays_alloc(size_t bytes, int n_read, int n_write, void **ptrs,
 		return CORDIC_ERR_ARGS;
 	const uint64_t words = ((uint64_t)bytes + 3) / 4;
 	// plain hipMalloc unless CORDIC_GROUP_PLACEMENT=1 asks for the probes
-	bool tune = false;
+	int tune = 0;
 	if (const char *e = std::getenv("CORDIC_GROUP_PLACEMENT"))
-		tune = e[0] == '1' && e[1] == 0 && words >= kPlaceMinWords;
+		tune = words >= kPlaceMinWords ? placement_spares(std::atoi(e)) : 0;
 	void *rd[2] = {nullptr, nullptr}, *wr[2] = {nullptr, nullptr};
 	if (int rc = alloc_placed(static_cast<hipStream_t>(stream), words, n_read, n_write,
 			tune, rd, wr, nullptr))
@@ -757,7 +801,7 @@ int cordic_group_set_placement(cordic_group *grp, int enable)
 {
 	if (!grp)
 		return CORDIC_ERR_ARGS;
-	grp->placement = enable != 0;
+	grp->placement = placement_spares(enable);
 	return CORDIC_OK;
 }
 

@@ -764,18 +764,26 @@ int	cordic_group_reserve(cordic_group *grp, uint64_t n_total, int inputs);
  * than it needs -- never more than a tenth of the memory that is free on the
  * device at that moment -- times an arithmetic-free twin of the job's traffic
  * over the candidate role assignments (10 + 3 launches for a 1R2W job: ~60 ms
- * at 4 GiB per array, plus the two extra hipMallocs, 0.2-1 s each at that
- * size), keeps the fastest and frees the rest before the call returns.  Cost,
- * once per (re)allocation: that time, and 2 x the array size of HBM held for
- * its duration.  Without it -- the default -- the arrays are what hipMalloc
+ * at 4 GiB per array, plus the two extra hipMallocs), keeps the fastest and
+ * frees the rest before the call returns.  Cost, once per (re)allocation: that
+ * time, and 2 x the array size of HBM held for its duration.  With two spares
+ * a process whose first five allocations share a class finds no fast pair
+ * (about every second process on the boxes measured): a caller that can spare
+ * more names a NUMBER -- cordic_group_set_placement(grp, N) /
+ * CORDIC_GROUP_PLACEMENT=N, 2 <= N <= 16 -- and the group then goes on, one
+ * array at a time, while no pair of written arrays reaches 0.93 of the HBM
+ * peak: at most N spares, still at most a tenth of the free memory (six 4 GiB
+ * arrays on an otherwise empty MI355X), and no further array once 1.5 s have
+ * passed.  Without any of it -- the default -- the arrays are what hipMalloc
  * hands out, nothing is probed and nothing extra is allocated.
  * cordic_group_placement reports what the last allocation of a shard saw:
  * candidate arrays, probes run, the times of the best and the worst pair of
  * written arrays (0R2W) and, with those chosen, of the best and the worst
  * choice of the read arrays (the job's full pattern); 0 candidates: not tuned.
- * (Rounds 4-5 had this on by default and kept taking candidates, up to 24,
- * while no written pair was fast; bench.py still turns it on for its own
- * arrays and says so in its line: roofline.placement.) */
+ * (Rounds 4-5 had this on by default and kept taking candidates, up to 24 and
+ * 96 GiB, while no written pair was fast; bench.py asks for six spares for its
+ * own arrays and says so: roofline.placement in its line, the candidates and
+ * probes in its detail record.) */
 int	cordic_group_set_placement(cordic_group *grp, int enable);
 /* The same for callers of the stateless entry points: n_read (0..2) +
  * n_write (1..2) arrays of `bytes` bytes each on the current device: plain

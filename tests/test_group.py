@@ -233,6 +233,18 @@ def test_placement_of_the_arrays():
     rx, ry = oracle_p2r(ocfg, 0, n_total)
     want = (cpu_digest(rx, 0) + cpu_digest(ry, 1 << 40)) % 2**64
     assert digests == [want, want, want]
+    # a caller that names a NUMBER of spares gets more candidates while no
+    # written pair is fast (arrays this small never reach the mark: the whole
+    # allowance is drawn), each further one tried against three at hand
+    g = ca.Group(cfg, devices=[0])
+    g.set_placement(6)
+    g.fill_phase_ramp(n_total, 0)
+    g.p2r_const(n_total, AMP, 0)
+    info = g.placement(0)
+    assert 5 <= info["candidates"] <= 9 and info["probes"] >= 13
+    assert info["probes"] <= 10 + 3 * (info["candidates"] - 5) + 7
+    assert g.digest(n_total) == want
+    g.close()
     # store-only job: two written arrays out of four candidates, every pair
     g = ca.Group(ca.Config.from_cli(ca.P2R, 32, 32, 2, 32, 16), devices=[0])
     g.set_placement(True)

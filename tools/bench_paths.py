@@ -347,3 +347,65 @@ def small_batches_xy(log2_total=26, log2_job=16):
             "job_set_digest_equals_oracle": got == want}
     return res
 
+
+def small_batches_nco(log2_total=26, log2_job=16):
+    """NCO BANKS as job sets: 1024 NCO jobs of 2^16
+    samples on BASELINE's 16- and 24-stage cores -- one job set against ONE
+    long cordic_plan_nco call over the same 2^26 samples, with a slow increment
+    (rows take the direction tails), with 0x01234567 (cfg5's; on 24 stages the
+    rows run the recurrence behind the seeds), and with a DIFFERENT increment
+    per job (what a bank is; no single long call to compare with).  Since
+    round 6 the 24-stage sets run the static descriptor instance: the kernel's
+    per-row test chooses the tails job by job.  Equal-increment sets are
+    checked against the oracle's digest of the one long job."""
+    import cordic_amd as ca
+    import oracle_lib as O
+    from gpu_util import gpu_digest
+    total, n = 1 << log2_total, 1 << log2_job
+    nj = total // n
+    a = torch.empty(total, dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    res = {"samples": total, "jobs": nj, "samples_per_job": n, "rows": {}}
+
+    def timed(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    for wl in ("cfg2", "cfg4"):
+        m, iw, ow, xtra, pw, ns = WORKLOADS[wl]["cli"]
+        cfg = ca.Config.from_cli(MODE[m], iw, ow, xtra, pw, ns)
+        ocfg = O.config_cli(MODE[m], iw, ow, xtra, pw, ns)
+        plan = ca.Plan(cfg)
+        plan.set_min_samples(-1)
+        x0 = (1 << (iw - 1)) - 1
+        for name, fcw in (("slow", 0x00000123), ("cfg5", 0x01234567), ("bank", None)):
+            jobs = [dict(ox=a[k * n:(k + 1) * n], oy=b[k * n:(k + 1) * n], n=n,
+                         phase0=0, index0=k * n if fcw is not None else 0,
+                         fcw=fcw if fcw is not None else
+                         (0x00000101 * (k + 1)) & 0xffffffff)
+                    for k in range(nj)]
+            js = ca.Jobset(plan, ca.JOBS_NCO, jobs)
+            a.zero_()
+            b.zero_()
+            ms_set = timed(lambda: js.run(x0, 0))
+            row = {"core": wl, "stages": ns, "job_set_ms": ms_set,
+                   "job_set_Msamples_per_s": total / ms_set / 1e3}
+            if fcw is not None:
+                got = (gpu_digest(a, 0) + gpu_digest(b, 1 << 40)) % (1 << 64)
+                want, _ = O.job_digest(ocfg, "nco", 0, total, 0, fcw, x0, 0)
+                ms_long = timed(lambda: plan.nco(total, 0, fcw, 0, x0, 0, a, b))
+                row.update({"one_long_call_Msamples_per_s": total / ms_long / 1e3,
+                            "job_set_over_one_long_call": ms_long / ms_set,
+                            "job_set_digest_equals_oracle": got == want})
+            js.close()
+            res["rows"]["%s_%s" % (wl, name)] = row
+        plan.close()
+    return res
+

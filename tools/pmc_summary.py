@@ -75,8 +75,27 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"),
     for row in csv.DictReader(open(f)):
         sk = short(row["Name"])
         if sk and sk in res["kernels"]:
-            res["kernels"][sk]["kernel_trace_avg_ns"] = float(row["AverageNs"])
-            res["kernels"][sk]["kernel_trace_calls"] = int(row["Calls"])
+            e = res["kernels"][sk]
+            # several instances of one family may appear (cfg5: the NCO
+            # instance does the work, the phase-array one builds the seed
+            # image once): the one that took the time is the workload's
+            total = float(row["TotalDurationNs"])
+            if total < e.get("kernel_trace_total_ns", 0.0):
+                continue
+            calls, avg, mn = int(row["Calls"]), float(row["AverageNs"]), float(row["MinNs"])
+            e["kernel_trace_total_ns"] = total
+            e["kernel_trace_avg_ns"] = avg
+            e["kernel_trace_calls"] = calls
+            e["kernel_trace_name"] = row["Name"].split("(cordic_amd::dev::CoreParams")[0]
+            # the one-block launch that builds a plan's seed image carries the
+            # same name as the workload's launches (~15 us): left out of the
+            # figure that is compared with the HIP-event time
+            if calls > 1 and mn < 0.1 * avg:
+                e["kernel_trace_avg_ns_full_launches"] = (total - mn) / (calls - 1)
+                e["kernel_trace_full_launches"] = calls - 1
+            else:
+                e["kernel_trace_avg_ns_full_launches"] = avg
+                e["kernel_trace_full_launches"] = calls
 # clock and issue rate from the pass that collected GRBM_GUI_ACTIVE
 for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"),
                    recursive=True):
