@@ -485,3 +485,71 @@ def test_bad_data_fed_jobs_are_refused():
     with pytest.raises(ca.CordicError):                 # another core's plan
         js.run(plan=other)
     js.close(); rot.close(); pol.close(); other.close()
+
+
+@pytest.mark.parametrize("kind", ["r2p", "mix"])
+def test_a_thousand_ragged_data_fed_jobs(kind):
+    """1024 jobs of 0 .. 9000 samples each at odd word offsets of shared arrays
+    (most of them shorter than a tile, many not a multiple of four samples):
+    one launch + one for the trailing samples; per job the oracle's bits, and
+    not a word outside the jobs' outputs touched."""
+    r2p = kind == "r2p"
+    args = (ca.R2P, 24, 24, 2, -1, 20) if r2p else (ca.P2R, 32, 32, 2, 32, 24)
+    cfg, ocfg = both(*args)
+    plan = ca.Plan(cfg)
+    rng = np.random.RandomState(53)
+    nj = 1024
+    sizes = [int(v) for v in rng.randint(0, 9001, nj)]
+    sizes[5] = sizes[700] = 0
+    offs = [int(v) for v in rng.randint(0, 4, nj)]
+    total = sum(sizes) + 32 * nj
+    xv, xbig = carve(total, sizes, offs)
+    yv, ybig = carve(total, sizes, offs[::-1])
+    av, abig = carve(total, sizes, [(o + 1) % 4 for o in offs])
+    bv, bbig = carve(total, sizes, [(o + 2) % 4 for o in offs])
+    hx = _iq(rng, total, cfg.iw)
+    hy = _iq(rng, total, cfg.iw)
+    xbig.copy_(dev_i32(hx))
+    ybig.copy_(dev_i32(hy))
+    jobs = []
+    for k in range(nj):
+        jb = dict(x=xv[k], y=yv[k], ox=av[k], oy=bv[k], n=sizes[k])
+        if not r2p:
+            jb.update(phase0=int(rng.randint(0, 1 << 32, dtype=np.uint64)),
+                      fcw=int(rng.choice([1, 257, int(rng.randint(0, 1 << 32,
+                                                                   dtype=np.uint64))])),
+                      index0=int(rng.randint(0, 1 << 40, dtype=np.uint64)))
+        jobs.append(jb)
+    js = ca.Jobset(plan, ca.JOBS_R2P if r2p else ca.JOBS_MIX, jobs)
+    assert js.info["samples"] == sum(sizes)
+    assert js.info["tail_samples"] == sum(n % 4 for n in sizes)
+    abig.fill_(0x5a5a5a5a); bbig.fill_(0x5a5a5a5a)
+    js.run()
+    torch.cuda.synchronize()
+    ga, gb = to_np(abig), to_np(bbig)
+    xh, yh = to_np(xbig), to_np(ybig)
+    base = abig.data_ptr()
+
+    def span(view):
+        lo = (view.data_ptr() - base) // 4
+        return lo, lo + view.numel()
+    touched_a = np.zeros(total, dtype=bool)
+    for k in range(nj):
+        if not sizes[k]:
+            continue
+        lo, hi = span(av[k])
+        xl = (xv[k].data_ptr() - xbig.data_ptr()) // 4
+        yl = (yv[k].data_ptr() - ybig.data_ptr()) // 4
+        jx, jy = xh[xl:xl + sizes[k]], yh[yl:yl + sizes[k]]
+        if r2p:
+            wa, wb = O.topolar(ocfg, jx, jy)
+            wb = wb.view(np.int32)
+        else:
+            wa, wb = O.mix(ocfg, jobs[k]["phase0"], jobs[k]["fcw"], jobs[k]["index0"], jx, jy)
+        bl = (bv[k].data_ptr() - bbig.data_ptr()) // 4
+        assert np.array_equal(ga[lo:hi], wa), k
+        assert np.array_equal(gb[bl:bl + sizes[k]], wb), k
+        touched_a[lo:hi] = True
+    assert np.all(ga[~touched_a] == 0x5a5a5a5a)
+    assert int((bbig == 0x5a5a5a5a).sum().item()) >= bbig.numel() - sum(sizes)
+    js.close(); plan.close()
