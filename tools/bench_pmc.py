@@ -113,7 +113,7 @@ def measure_pmc(args):
             r = subprocess.run(["rocprofv3", "--pmc"] + names + [
                                 "--output-format", "csv", "-d", td, "--"] + base,
                                cwd="/tmp", env=env, capture_output=True,
-                               text=True, timeout=600)
+                               text=True, timeout=150)
             rows = {c: [] for c in names}
             for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"),
                                recursive=True):
