@@ -219,3 +219,42 @@ def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
                        timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "host selftest ok" in r.stdout
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """The ctypes view (cordic_amd/_native.py) against include/cordic_amd.h as
+    a C compiler lays it out: size of every struct that crosses the boundary
+    and the offset of every field -- a field added on one side only (round 6
+    added d_xval / d_yval to cordic_job) fails here, on a CPU box."""
+    import ctypes as C
+    import cordic_amd._native as N
+    pairs = [("cordic_config", N._CConfig), ("cordic_job", N._CJob),
+             ("cordic_table_config", N._CTableConfig),
+             ("cordic_queue_info", N._CQueueInfo),
+             ("cordic_quad_config", N._CQuadConfig),
+             ("cordic_p2r_quality", N._CP2RQuality),
+             ("cordic_r2p_quality", N._CR2PQuality),
+             ("cordic_host_stats", N._CHostStats)]
+    body = ['#include <stddef.h>', '#include <stdio.h>', '#include "cordic_amd.h"',
+            'int main(void) {']
+    for cname, cls in pairs:
+        body.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            body.append('printf("%s %s %%zu\\n", offsetof(%s, %s));'
+                        % (cname, fname, cname, fname))
+    body.append('return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(body) + "\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr          # (a field the header lacks)
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout
+    want = {}
+    for ln in out.splitlines():
+        a, b, c = ln.split()
+        want[(a, b)] = int(c)
+    for cname, cls in pairs:
+        assert C.sizeof(cls) == want[(cname, "size")], cname
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == want[(cname, fname)], (cname, fname)
